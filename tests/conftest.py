@@ -1,0 +1,65 @@
+"""pytest configuration.
+
+Markers: `gpu` = needs a real MI355X (run with `-m gpu` on the GPU box).  Everything else
+runs on CPU.  The oracle (oracle/) is test infrastructure: only tests import it.
+"""
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
+
+
+@pytest.fixture(scope="session")
+def coracle():
+    import coracle as m
+    m.build()
+    return m
+
+
+@pytest.fixture(scope="session")
+def pyoracle():
+    import pyoracle as m
+    return m
+
+
+def _load_sig_file(path):
+    with open(path) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def sbt_v5_leaves():
+    """{leaf position: first sketch dict} of the reference fixture tests/data/v5.sbt.json."""
+    tree = _load_sig_file(os.path.join(GOLDEN, "v5.sbt.json"))
+    out = {}
+    for pos, leaf in tree["leaves"].items():
+        sig = _load_sig_file(os.path.join(GOLDEN, "sbt_v5", leaf["filename"] + ".sig"))
+        out[int(pos)] = sig[0]["signatures"][0]
+    return out
+
+
+@pytest.fixture(scope="session")
+def sbt_subset_sketches():
+    """First sketch of each of the 100 leaf signatures of tests/data/.sbt.subset (k=21, scaled, abund)."""
+    with gzip.open(os.path.join(GOLDEN, "sbt_subset_sigs.json.gz"), "rt") as fh:
+        d = json.load(fh)
+    return [d[k][0]["signatures"][0] for k in sorted(d)]
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (sourmash-rust_amd/)."""
+    from __graft_entry__ import load_package
+    return load_package()
