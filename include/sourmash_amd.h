@@ -1,0 +1,78 @@
+/*
+ * include/sourmash_amd.h -- ADDITIVE entry points of the MI355X implementation.
+ *
+ * The reference ABI (sourmash.h) hands the library one NUL-terminated C string and one pair of
+ * sketches per call.  These symbols add what a GPU needs: explicit lengths, many records per
+ * call, device-resident buffers, and an N x M compare block.  None of them changes or shadows
+ * a reference symbol.  Plain pointers and sizes only; `stream` is a hipStream_t passed as
+ * void* (NULL = the library's own stream).  "dev" pointers are HIP device pointers.
+ *
+ * Error convention: same thread-local slot as sourmash.h; functions returning int return 0 on
+ * success and the SourmashErrorCode otherwise.
+ */
+#ifndef SOURMASH_AMD_H_INCLUDED
+#define SOURMASH_AMD_H_INCLUDED
+
+#include "sourmash.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1 when a HIP device can be used, 0 otherwise (never raises). */
+int smh_device_available(void);
+/* device ordinal in use and its compute-unit count (0 on failure, error slot set) */
+int smh_device_info(int *device, int *compute_units);
+
+/* KmerMinHash::add_sequence (reference src/lib.rs:252-305) with an explicit length: the bytes
+ * may contain NUL.  Same semantics and errors as kmerminhash_add_sequence. */
+int smh_add_sequence_len(KmerMinHash *ptr, const char *seq, uint64_t len, bool force);
+
+/* Many records in one call, as if add_sequence were called on each in order
+ * (offsets: n_records+1 host entries into seq).  Every record is processed; the first record
+ * that the reference would have failed on is the reported error.  *_dev: seq is a device
+ * pointer (inputs already resident in HBM). */
+int smh_add_sequences(KmerMinHash *ptr, const char *seq, const uint64_t *offsets,
+                      uint32_t n_records, bool force);
+int smh_add_sequences_dev(KmerMinHash *ptr, const void *seq_dev, uint64_t total_len,
+                          const uint64_t *offsets, uint32_t n_records, bool force, void *stream);
+
+/* add_hash over an array (reference src/lib.rs:412-417 add_many) */
+int smh_add_many(KmerMinHash *ptr, const uint64_t *hashes, uint64_t n);
+
+/* murmur64 of n byte strings (offsets: n+1 host entries) on the device
+ * (reference src/lib.rs:33-35 _hash_murmur) */
+int smh_hash_words(const char *bytes, const uint64_t *offsets, uint32_t n, uint64_t seed,
+                   uint64_t *out);
+
+/* rows x cols block of compare / intersection_size / count_common / containment between
+ * host sketches (reference src/lib.rs:428-436,470-508, src/index.rs:146-154).  Row i is `self`,
+ * so its `num` truncates the union walk.  Outputs are row-major n_rows*n_cols, any may be NULL.
+ * check_compatible (reference src/lib.rs:176-190) is applied to every pair first. */
+int smh_compare_block(KmerMinHash *const *rows, uint32_t n_rows, KmerMinHash *const *cols,
+                      uint32_t n_cols, double *jaccard, uint64_t *common, uint64_t *size,
+                      uint64_t *count_common, double *containment);
+
+/* The same on device-resident sketches in CSR form: hashes_dev[offsets[i]..offsets[i+1]) is
+ * sketch i, ascending and distinct; offsets are HOST arrays.  All sketches share ksize / seed /
+ * max_hash / molecule (the caller's index guarantees it); `num` is the rows' num (0 = scaled).
+ * Output pointers are device pointers, row-major, any may be NULL. */
+int smh_compare_block_dev(const uint64_t *row_hashes_dev, const uint64_t *row_offsets, uint32_t n_rows,
+                          const uint64_t *col_hashes_dev, const uint64_t *col_offsets, uint32_t n_cols,
+                          uint32_t num, double *jaccard_dev, uint64_t *common_dev, uint64_t *size_dev,
+                          uint64_t *count_common_dev, double *containment_dev, void *stream);
+
+/* deterministic synthetic DNA of SURVEY.md 8d written to device memory (benchmark input) */
+int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
+                      void *stream);
+
+/* HIP-event timing of the library's kernels, on the stream they run on.
+ * name: "dna_rolling", "dna_generic", "hash_windows", "compare_wave", "compare_tiled". */
+void smh_profile_enable(int on);
+void smh_profile_reset(void);
+int smh_profile_get(const char *name, double *total_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+// device.hpp -- HIP device context of the host library: lazy initialisation (so that the
+// shared object loads and every C-ABI symbol resolves on a machine without a GPU), the
+// library's own stream, grow-only device buffers and per-kernel HIP-event timers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace smh {
+
+[[noreturn]] void throw_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define HIP_CHECK(expr)                                                  \
+  do {                                                                   \
+    hipError_t e_ = (expr);                                              \
+    if (e_ != hipSuccess) ::smh::throw_hip(e_, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+// grow-only device allocation (never shrinks; freed with the context or explicitly)
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  void ensure(size_t need);
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer();
+};
+
+// pinned host staging buffer for H2D/D2H copies of the legacy (host-pointer) ABI
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  void ensure(size_t need);
+  ~PinnedBuffer();
+};
+
+struct KernelTimes {
+  double ms = 0.0;
+  uint64_t launches = 0;
+};
+
+class Device {
+ public:
+  // Throws Error(kInternal) when no HIP device is usable: the product path never falls
+  // back to the CPU.
+  static Device& get();
+  static bool available();  // true when a GPU can be initialised (no throw)
+
+  int id() const { return device_; }
+  int cu_count() const { return cus_; }
+  hipStream_t stream() const { return stream_; }
+  std::recursive_mutex& mutex() { return mu_; }
+
+  // scratch shared by the fold / sort primitives (guarded by mutex())
+  DeviceBuffer scratch;
+
+  // HIP-event timing of named kernels (enabled by smh_profile_enable)
+  void profile_enable(bool on);
+  bool profiling() const { return profiling_; }
+  void prof_begin(hipStream_t s);
+  void prof_end(const char* name, hipStream_t s);
+  KernelTimes prof_get(const std::string& name);  // synchronises pending events
+  void prof_reset();
+
+ private:
+  Device();
+  int device_ = 0;
+  int cus_ = 256;
+  hipStream_t stream_ = nullptr;
+  std::recursive_mutex mu_;
+  bool profiling_ = false;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> pending_;
+  hipEvent_t cur_start_ = nullptr;
+  std::map<std::string, KernelTimes> times_;
+  void drain();
+};
+
+}  // namespace smh

@@ -1,0 +1,511 @@
+// ffi.cpp -- the C ABI: every symbol of include/sourmash.h (the reference's surface, restating
+// src/ffi.rs and src/utils.rs) and the additive MI355X entry points of include/sourmash_amd.h.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sourmash_amd.h"
+#include "minhash.hpp"
+#include "signature.hpp"
+
+using smh::Error;
+
+struct KmerMinHash : smh::KmerMinHash {
+  using smh::KmerMinHash::KmerMinHash;
+  KmerMinHash() = default;
+  KmerMinHash(const smh::KmerMinHash& o) : smh::KmerMinHash(o) {}
+};
+struct Signature : smh::Signature {
+  Signature() = default;
+  Signature(const smh::Signature& o) : smh::Signature(o) {}
+};
+
+namespace {
+
+bool g_panic_hook = false;  // sourmash_init() installs the hook that records panics (utils.rs:100-104)
+
+void set_last_error(const Error& e) {
+  // utils.rs:154-166: an Err is always stored; a panic only reaches the slot through the hook
+  if (e.code == smh::kPanic && !g_panic_hook) return;
+  auto& slot = smh::last_error();
+  slot.set = true;
+  slot.code = e.code;
+  slot.message = e.message;
+}
+
+// landing pad: run f, on failure fill the slot and hand back an all-zero value
+template <class R, class F>
+R pad(F&& f) {
+  try {
+    return f();
+  } catch (const Error& e) {
+    set_last_error(e);
+  } catch (const std::bad_alloc&) {
+    set_last_error(Error(smh::kPanic, "sourmash panicked: memory allocation failed"));
+  } catch (const std::exception& e) {
+    set_last_error(Error(smh::kPanic, std::string("sourmash panicked: ") + e.what()));
+  }
+  R zero;
+  memset(&zero, 0, sizeof zero);
+  return zero;
+}
+template <class F>
+void pad_void(F&& f) {
+  (void)pad<int>([&] { f(); return 0; });
+}
+// additive ABI: 0 on success, else the error code (slot also set)
+template <class F>
+int pad_code(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const Error& e) {
+    auto& slot = smh::last_error();
+    slot.set = true; slot.code = e.code; slot.message = e.message;
+    return (int)e.code;
+  } catch (const std::exception& e) {
+    auto& slot = smh::last_error();
+    slot.set = true; slot.code = smh::kPanic; slot.message = std::string("sourmash panicked: ") + e.what();
+    return (int)smh::kPanic;
+  }
+}
+
+void require(const void* p, const char* what) {
+  if (!p) smh::throw_panic(std::string("assertion failed: !") + what + ".is_null()");
+}
+
+SourmashStr str_from_string(const std::string& s) {  // utils.rs:201-210 from_string: owned copy
+  SourmashStr r;
+  r.len = s.size();
+  r.data = (char*)malloc(s.size() ? s.size() : 1);
+  if (s.size()) memcpy(r.data, s.data(), s.size());
+  r.owned = true;
+  return r;
+}
+
+bool utf8_cstr_ok(const char* s) {
+  const unsigned char* p = (const unsigned char*)s;
+  while (*p) {
+    unsigned char c = *p;
+    int need;
+    if (c < 0x80) { p++; continue; }
+    else if (c >= 0xC2 && c <= 0xDF) need = 1;
+    else if (c >= 0xE0 && c <= 0xEF) need = 2;
+    else if (c >= 0xF0 && c <= 0xF4) need = 3;
+    else return false;
+    unsigned char lo = 0x80, hi = 0xBF;
+    if (c == 0xE0) lo = 0xA0; else if (c == 0xED) hi = 0x9F; else if (c == 0xF0) lo = 0x90; else if (c == 0xF4) hi = 0x8F;
+    if (p[1] < lo || p[1] > hi) return false;
+    for (int j = 2; j <= need; j++) if (p[j] < 0x80 || p[j] > 0xBF) return false;
+    p += need + 1;
+  }
+  return true;
+}
+
+template <class T>
+T** leak_array(std::vector<T*>& v, uintptr_t* size) {
+  T** arr = (T**)malloc((v.size() ? v.size() : 1) * sizeof(T*));
+  for (size_t i = 0; i < v.size(); i++) arr[i] = v[i];
+  *size = v.size();
+  return arr;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ hashing / sketching
+
+uint64_t hash_murmur(const char* kmer, uint64_t seed) {
+  return pad<uint64_t>([&] {
+    require(kmer, "kmer");
+    const uint64_t off[2] = {0, (uint64_t)strlen(kmer)};
+    uint64_t h = 0;
+    smh::Engine::get().hash_words((const uint8_t*)kmer, off, 1, seed, &h);
+    return h;
+  });
+}
+
+KmerMinHash* kmerminhash_new(uint32_t n, uint32_t k, bool prot, uint64_t seed, uint64_t mx, bool track_abundance) {
+  return pad<KmerMinHash*>([&] { return new KmerMinHash(n, k, prot, seed, mx, track_abundance); });
+}
+
+void kmerminhash_free(KmerMinHash* ptr) { delete ptr; }
+
+void kmerminhash_add_sequence(KmerMinHash* ptr, const char* sequence, bool force) {
+  pad_void([&] {
+    require(ptr, "ptr");
+    require(sequence, "sequence");
+    ptr->add_sequence((const uint8_t*)sequence, strlen(sequence), force);
+  });
+}
+
+void kmerminhash_add_hash(KmerMinHash* ptr, uint64_t h) {
+  pad_void([&] { require(ptr, "ptr"); ptr->add_hash(h); });
+}
+
+void kmerminhash_add_word(KmerMinHash* ptr, const char* word) {
+  pad_void([&] {
+    require(ptr, "ptr");
+    require(word, "word");
+    ptr->add_word((const uint8_t*)word, strlen(word));
+  });
+}
+
+void kmerminhash_add_from(KmerMinHash* ptr, const KmerMinHash* other) {
+  pad_void([&] { require(ptr, "ptr"); require(other, "other"); ptr->add_from(*other); });
+}
+
+void kmerminhash_merge(KmerMinHash* ptr, const KmerMinHash* other) {
+  pad_void([&] { require(ptr, "ptr"); require(other, "other"); ptr->merge(*other); });
+}
+
+// ------------------------------------------------------------------ comparing
+
+double kmerminhash_compare(KmerMinHash* ptr, const KmerMinHash* other) {
+  return pad<double>([&] { require(ptr, "ptr"); require(other, "other"); return ptr->compare(*other); });
+}
+
+uint64_t kmerminhash_count_common(KmerMinHash* ptr, const KmerMinHash* other) {
+  return pad<uint64_t>([&] { require(ptr, "ptr"); require(other, "other"); return ptr->count_common(*other); });
+}
+
+uint64_t kmerminhash_intersection(KmerMinHash* ptr, const KmerMinHash* other) {
+  // src/ffi.rs:304-307: the SIZE of the combined sketch; any Err of intersection() reads as 0
+  return pad<uint64_t>([&] {
+    require(ptr, "ptr");
+    require(other, "other");
+    try {
+      uint64_t common = 0, size = 0;
+      ptr->intersection_size(*other, &common, &size);
+      return size;
+    } catch (const Error& e) {
+      if (e.code == smh::kPanic || e.code == smh::kInternal) throw;
+      return (uint64_t)0;
+    }
+  });
+}
+
+// ------------------------------------------------------------------ accessors
+
+const uint64_t* kmerminhash_get_mins(KmerMinHash* ptr) {
+  return pad<const uint64_t*>([&] {
+    require(ptr, "ptr");
+    uint64_t* out = (uint64_t*)malloc((ptr->mins.size() ? ptr->mins.size() : 1) * sizeof(uint64_t));
+    if (!ptr->mins.empty()) memcpy(out, ptr->mins.data(), ptr->mins.size() * sizeof(uint64_t));
+    return (const uint64_t*)out;
+  });
+}
+
+uintptr_t kmerminhash_get_mins_size(KmerMinHash* ptr) {
+  return pad<uintptr_t>([&] { require(ptr, "ptr"); return (uintptr_t)ptr->mins.size(); });
+}
+
+uint64_t kmerminhash_get_min_idx(KmerMinHash* ptr, uint64_t idx) {
+  return pad<uint64_t>([&] {
+    require(ptr, "ptr");
+    if (idx >= ptr->mins.size()) smh::throw_panic("index out of bounds");
+    return ptr->mins[idx];
+  });
+}
+
+void kmerminhash_mins_push(KmerMinHash* ptr, uint64_t val) {
+  pad_void([&] { require(ptr, "ptr"); ptr->mins.push_back(val); });
+}
+
+const uint64_t* kmerminhash_get_abunds(KmerMinHash* ptr) {
+  return pad<const uint64_t*>([&] {
+    require(ptr, "ptr");
+    if (!ptr->has_abunds) return (const uint64_t*)nullptr;
+    uint64_t* out = (uint64_t*)malloc((ptr->abunds.size() ? ptr->abunds.size() : 1) * sizeof(uint64_t));
+    if (!ptr->abunds.empty()) memcpy(out, ptr->abunds.data(), ptr->abunds.size() * sizeof(uint64_t));
+    return (const uint64_t*)out;
+  });
+}
+
+uintptr_t kmerminhash_get_abunds_size(KmerMinHash* ptr) {
+  return pad<uintptr_t>([&] { require(ptr, "ptr"); return (uintptr_t)(ptr->has_abunds ? ptr->abunds.size() : 0); });
+}
+
+uint64_t kmerminhash_get_abund_idx(KmerMinHash* ptr, uint64_t idx) {
+  return pad<uint64_t>([&] {
+    require(ptr, "ptr");
+    if (!ptr->has_abunds) return (uint64_t)0;
+    if (idx >= ptr->abunds.size()) smh::throw_panic("index out of bounds");
+    return ptr->abunds[idx];
+  });
+}
+
+void kmerminhash_abunds_push(KmerMinHash* ptr, uint64_t val) {
+  pad_void([&] { require(ptr, "ptr"); if (ptr->has_abunds) ptr->abunds.push_back(val); });
+}
+
+bool kmerminhash_is_protein(KmerMinHash* ptr) { return pad<bool>([&] { require(ptr, "ptr"); return ptr->is_protein; }); }
+uint64_t kmerminhash_seed(KmerMinHash* ptr) { return pad<uint64_t>([&] { require(ptr, "ptr"); return ptr->seed; }); }
+bool kmerminhash_track_abundance(KmerMinHash* ptr) { return pad<bool>([&] { require(ptr, "ptr"); return ptr->has_abunds; }); }
+uint32_t kmerminhash_num(KmerMinHash* ptr) { return pad<uint32_t>([&] { require(ptr, "ptr"); return ptr->num; }); }
+uint32_t kmerminhash_ksize(KmerMinHash* ptr) { return pad<uint32_t>([&] { require(ptr, "ptr"); return ptr->ksize; }); }
+uint64_t kmerminhash_max_hash(KmerMinHash* ptr) { return pad<uint64_t>([&] { require(ptr, "ptr"); return ptr->max_hash; }); }
+
+// ------------------------------------------------------------------ Signature
+
+Signature* signature_new(void) { return pad<Signature*>([&] { return new Signature(); }); }
+void signature_free(Signature* ptr) { delete ptr; }
+
+void signature_set_name(Signature* ptr, const char* name) {
+  pad_void([&] {
+    require(ptr, "ptr"); require(name, "name");
+    if (utf8_cstr_ok(name)) { ptr->has_name = true; ptr->name = name; }  // ffi.rs:357-359: silently ignored otherwise
+  });
+}
+void signature_set_filename(Signature* ptr, const char* name) {
+  pad_void([&] {
+    require(ptr, "ptr"); require(name, "name");
+    if (utf8_cstr_ok(name)) { ptr->has_filename = true; ptr->filename = name; }
+  });
+}
+void signature_push_mh(Signature* ptr, const KmerMinHash* other) {
+  pad_void([&] { require(ptr, "ptr"); require(other, "other"); ptr->signatures.push_back(*other); });
+}
+void signature_set_mh(Signature* ptr, const KmerMinHash* other) {
+  pad_void([&] { require(ptr, "ptr"); require(other, "other"); ptr->signatures.assign(1, *other); });
+}
+SourmashStr signature_get_name(Signature* ptr) {
+  return pad<SourmashStr>([&] { require(ptr, "ptr"); return str_from_string(ptr->has_name ? ptr->name : ""); });
+}
+SourmashStr signature_get_filename(Signature* ptr) {
+  return pad<SourmashStr>([&] { require(ptr, "ptr"); return str_from_string(ptr->has_filename ? ptr->filename : ""); });
+}
+SourmashStr signature_get_license(Signature* ptr) {
+  return pad<SourmashStr>([&] { require(ptr, "ptr"); return str_from_string(ptr->license); });
+}
+KmerMinHash* signature_first_mh(Signature* ptr) {
+  return pad<KmerMinHash*>([&] {
+    require(ptr, "ptr");
+    if (!ptr->signatures.empty()) return new KmerMinHash(ptr->signatures[0]);
+    return new KmerMinHash();  // ffi.rs:468-471 "this is totally wrong": a Default sketch
+  });
+}
+bool signature_eq(Signature* ptr, Signature* other) {
+  return pad<bool>([&] { require(ptr, "ptr"); require(other, "other"); return smh::signature_equal(*ptr, *other); });
+}
+SourmashStr signature_save_json(Signature* ptr) {
+  return pad<SourmashStr>([&] {
+    require(ptr, "ptr");
+    std::string out;
+    smh::signature_to_json(out, *ptr);
+    return str_from_string(out);
+  });
+}
+KmerMinHash** signature_get_mhs(Signature* ptr, uintptr_t* size) {
+  return pad<KmerMinHash**>([&] {
+    require(ptr, "ptr");
+    std::vector<KmerMinHash*> v;
+    for (auto& mh : ptr->signatures) v.push_back(new KmerMinHash(mh));
+    return leak_array(v, size);
+  });
+}
+SourmashStr signatures_save_buffer(Signature** ptr, uintptr_t size) {
+  return pad<SourmashStr>([&] {
+    require(ptr, "ptr");
+    std::vector<const smh::Signature*> v;
+    for (uintptr_t i = 0; i < size; i++) {
+      if (!ptr[i]) smh::throw_panic("called `Option::unwrap()` on a `None` value");
+      v.push_back(ptr[i]);
+    }
+    return str_from_string(smh::signatures_to_json(v));
+  });
+}
+
+static Signature** load_common(const std::string& data, uintptr_t ksize, const char* select_moltype, uintptr_t* size) {
+  if (select_moltype && !utf8_cstr_ok(select_moltype)) throw Error(smh::kUtf8Error, "invalid utf-8 sequence");
+  std::vector<smh::Signature> sigs = smh::load_signatures(data.data(), data.size(), ksize, select_moltype);
+  std::vector<Signature*> v;
+  for (auto& s : sigs) v.push_back(new Signature(s));
+  return leak_array(v, size);
+}
+
+Signature** signatures_load_path(const char* ptr, bool ignore_md5sum, uintptr_t ksize, const char* select_moltype,
+                                 uintptr_t* size) {
+  (void)ignore_md5sum;  // ffi.rs:555 "TODO: implement ignore_md5sum"
+  return pad<Signature**>([&] {
+    require(ptr, "ptr");
+    if (!utf8_cstr_ok(ptr)) throw Error(smh::kUtf8Error, "invalid utf-8 sequence");
+    return load_common(smh::read_file(ptr), ksize, select_moltype, size);
+  });
+}
+
+Signature** signatures_load_buffer(const char* ptr, uintptr_t insize, bool ignore_md5sum, uintptr_t ksize,
+                                   const char* select_moltype, uintptr_t* size) {
+  (void)ignore_md5sum;
+  return pad<Signature**>([&] {
+    require(ptr, "ptr");
+    return load_common(std::string(ptr, insize), ksize, select_moltype, size);
+  });
+}
+
+// ------------------------------------------------------------------ errors and strings
+
+void sourmash_err_clear(void) {
+  auto& s = smh::last_error();
+  s.set = false; s.code = 0; s.message.clear();
+}
+
+SourmashStr sourmash_err_get_backtrace(void) {
+  SourmashStr r = {nullptr, 0, false};  // no backtrace is captured: the reference returns Default then
+  return r;
+}
+
+SourmashErrorCode sourmash_err_get_last_code(void) {
+  auto& s = smh::last_error();
+  return s.set ? s.code : SOURMASH_ERROR_CODE_NO_ERROR;
+}
+
+SourmashStr sourmash_err_get_last_message(void) {
+  auto& s = smh::last_error();
+  if (!s.set) { SourmashStr r = {nullptr, 0, false}; return r; }
+  return str_from_string(s.message);
+}
+
+void sourmash_init(void) { g_panic_hook = true; }
+
+void sourmash_str_free(SourmashStr* s) {
+  if (s && s->owned) {
+    free(s->data);
+    s->data = nullptr; s->len = 0; s->owned = false;
+  }
+}
+
+SourmashStr sourmash_str_from_cstr(const char* s) {
+  // utils.rs:220-234: borrows the bytes but marks them owned; the caller clears `owned` if it
+  // keeps the memory
+  return pad<SourmashStr>([&] {
+    if (!s || !utf8_cstr_ok(s)) throw Error(smh::kUtf8Error, "invalid utf-8 sequence");
+    SourmashStr r;
+    r.data = (char*)s; r.len = strlen(s); r.owned = true;
+    return r;
+  });
+}
+
+// ================================================================== additive MI355X ABI
+
+int smh_device_available(void) { return smh::Device::available() ? 1 : 0; }
+
+int smh_device_info(int* device, int* compute_units) {
+  return pad_code([&] {
+    auto& d = smh::Device::get();
+    if (device) *device = d.id();
+    if (compute_units) *compute_units = d.cu_count();
+  });
+}
+
+int smh_add_sequence_len(KmerMinHash* ptr, const char* seq, uint64_t len, bool force) {
+  return pad_code([&] { require(ptr, "ptr"); require(seq, "seq"); ptr->add_sequence((const uint8_t*)seq, len, force); });
+}
+
+int smh_add_sequences(KmerMinHash* ptr, const char* seq, const uint64_t* offsets, uint32_t n_records, bool force) {
+  return pad_code([&] {
+    require(ptr, "ptr"); require(seq, "seq"); require(offsets, "offsets");
+    if (n_records == 0) return;
+    auto& dev = smh::Device::get();
+    auto& E = smh::Engine::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    const uint64_t base = offsets[0], total = offsets[n_records] - base;
+    std::vector<uint64_t> rel(n_records + 1);
+    for (uint32_t i = 0; i <= n_records; i++) rel[i] = offsets[i] - base;
+    E.seqbuf.ensure(total + 64);
+    if (total) HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq + base, total, hipMemcpyHostToDevice, dev.stream()));
+    ptr->add_sequences_device(E.seqbuf.as<uint8_t>(), total, rel.data(), n_records, force, dev.stream(), nullptr);
+  });
+}
+
+int smh_add_sequences_dev(KmerMinHash* ptr, const void* seq_dev, uint64_t total_len, const uint64_t* offsets,
+                          uint32_t n_records, bool force, void* stream) {
+  return pad_code([&] {
+    require(ptr, "ptr"); require(seq_dev, "seq_dev"); require(offsets, "offsets");
+    ptr->add_sequences_device((const uint8_t*)seq_dev, total_len, offsets, n_records, force, (hipStream_t)stream,
+                              nullptr);
+  });
+}
+
+int smh_add_many(KmerMinHash* ptr, const uint64_t* hashes, uint64_t n) {
+  return pad_code([&] { require(ptr, "ptr"); if (n) require(hashes, "hashes"); ptr->add_many(hashes, n); });
+}
+
+int smh_hash_words(const char* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out) {
+  return pad_code([&] {
+    require(offsets, "offsets"); require(out, "out");
+    smh::Engine::get().hash_words((const uint8_t*)bytes, offsets, n, seed, out);
+  });
+}
+
+int smh_compare_block(KmerMinHash* const* rows, uint32_t n_rows, KmerMinHash* const* cols, uint32_t n_cols,
+                      double* jaccard, uint64_t* common, uint64_t* size, uint64_t* count_common,
+                      double* containment) {
+  return pad_code([&] {
+    if (n_rows == 0 || n_cols == 0) return;
+    require(rows, "rows"); require(cols, "cols");
+    std::vector<const smh::KmerMinHash*> R(n_rows), C(n_cols);
+    std::vector<uint32_t> nums(n_rows);
+    for (uint32_t i = 0; i < n_rows; i++) { require(rows[i], "rows[i]"); R[i] = rows[i]; nums[i] = rows[i]->num; }
+    for (uint32_t j = 0; j < n_cols; j++) { require(cols[j], "cols[j]"); C[j] = cols[j]; }
+    for (uint32_t i = 0; i < n_rows; i++)
+      for (uint32_t j = 0; j < n_cols; j++) R[i]->check_compatible(*C[j]);
+    smh::Engine::get().compare_host(R, C, nums.data(), 0, common, size, jaccard, count_common, containment);
+  });
+}
+
+int smh_compare_block_dev(const uint64_t* row_hashes_dev, const uint64_t* row_offsets, uint32_t n_rows,
+                          const uint64_t* col_hashes_dev, const uint64_t* col_offsets, uint32_t n_cols,
+                          uint32_t num, double* jaccard_dev, uint64_t* common_dev, uint64_t* size_dev,
+                          uint64_t* count_common_dev, double* containment_dev, void* stream) {
+  return pad_code([&] {
+    if (n_rows == 0 || n_cols == 0) return;
+    require(row_offsets, "row_offsets"); require(col_offsets, "col_offsets");
+    auto& dev = smh::Device::get();
+    auto& E = smh::Engine::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = stream ? (hipStream_t)stream : dev.stream();
+    uint32_t mr = 0, mc = 0;
+    for (uint32_t i = 0; i < n_rows; i++) mr = std::max<uint32_t>(mr, (uint32_t)(row_offsets[i + 1] - row_offsets[i]));
+    for (uint32_t j = 0; j < n_cols; j++) mc = std::max<uint32_t>(mc, (uint32_t)(col_offsets[j + 1] - col_offsets[j]));
+    E.cmp_oa.ensure((size_t)(n_rows + 1) * 8);
+    E.cmp_ob.ensure((size_t)(n_cols + 1) * 8);
+    HIP_CHECK(hipMemcpyAsync(E.cmp_oa.ptr, row_offsets, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(E.cmp_ob.ptr, col_offsets, (size_t)(n_cols + 1) * 8, hipMemcpyHostToDevice, s));
+    smh::SketchSet R, C;
+    R.hashes = row_hashes_dev; R.offsets = E.cmp_oa.as<uint64_t>(); R.n = n_rows;
+    C.hashes = col_hashes_dev; C.offsets = E.cmp_ob.as<uint64_t>(); C.n = n_cols;
+    smh::CompareOut o;
+    o.jaccard = jaccard_dev; o.common = common_dev; o.size = size_dev; o.count_common = count_common_dev;
+    o.containment = containment_dev;
+    smh::launch_compare_block(R, C, num, nullptr, o, dev, s, mr, mc);
+    HIP_CHECK(hipStreamSynchronize(s));  // the offset staging buffers are reused by the next call
+  });
+}
+
+int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every, void* stream) {
+  return pad_code([&] {
+    require(out_dev, "out_dev");
+    auto& dev = smh::Device::get();
+    smh::launch_synth_dna((uint8_t*)out_dev, start, len, seed, n_every, stream ? (hipStream_t)stream : dev.stream());
+  });
+}
+
+void smh_profile_enable(int on) {
+  (void)pad_code([&] { smh::Device::get().profile_enable(on != 0); });
+}
+void smh_profile_reset(void) {
+  (void)pad_code([&] { smh::Device::get().prof_reset(); });
+}
+int smh_profile_get(const char* name, double* total_ms, uint64_t* launches) {
+  return pad_code([&] {
+    require(name, "name");
+    auto t = smh::Device::get().prof_get(name);
+    if (total_ms) *total_ms = t.ms;
+    if (launches) *launches = t.launches;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// kernels.hpp -- launch interfaces of the HIP kernels (sketch_kernels.hip, sort.hip,
+// compare_kernels.hip).  Plain structs and pointers; no torch types anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device.hpp"
+
+namespace smh {
+
+// Where the hash kernels append the hashes that pass the threshold.  `count` keeps counting
+// past `capacity`, so an overflowing launch reports exactly how much room a re-run needs.
+struct CandSink {
+  uint64_t* hash = nullptr;
+  uint64_t* pos = nullptr;  // stream position of the k-mer (only when order matters: Q3/Q4)
+  unsigned long long* count = nullptr;
+  uint64_t capacity = 0;
+};
+
+// One flat byte buffer holding 1..nrec records.  Record r is [starts[r], starts[r+1]);
+// bytes at or beyond vends[r] are not part of it (force=false truncation, reference
+// src/lib.rs:268-273).  starts == nullptr means a single record [0, len) ending at vend0.
+struct SeqBatch {
+  const uint8_t* seq = nullptr;
+  uint64_t len = 0;
+  const uint64_t* starts = nullptr;
+  const uint64_t* vends = nullptr;
+  uint32_t nrec = 1;
+  uint64_t vend0 = 0;
+};
+
+struct HashParams {
+  uint32_t ksize = 31;
+  uint64_t seed = 42;
+  const uint64_t* thr_ptr = nullptr;  // device-resident threshold (num-mode rounds) or null
+  uint64_t thr = ~0ull;               // used when thr_ptr is null
+  uint64_t pos_base = 0;
+  uint64_t range_lo = 0, range_hi = 0;  // k-mer start positions [lo, hi) handled by this launch
+};
+
+// DNA arm of add_sequence (reference src/lib.rs:258-274): canonical k-mer + murmur64 + filter.
+// Picks the rolling 2-bit kernel for ksize <= 32 and the byte-wise kernel otherwise.
+void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sink, Device& dev,
+                     hipStream_t s, bool force_generic = false);
+
+// smallest position of a byte outside [ACGTacgt] per record -> vends (atomicMin); vends must be
+// pre-filled with the record ends.  (reference src/lib.rs:795-804 _checkdna, applied per byte)
+void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s);
+
+// hash every window of `win` bytes inside each segment of a byte buffer (protein arm second
+// phase, reference src/lib.rs:289-300), or whole segments when win == 0 (add_word / hash_murmur,
+// reference src/lib.rs:247-250, src/ffi.rs:15-24).  Output: out[i] for whole-segment mode, the
+// candidate sink otherwise.
+void launch_hash_segments(const uint8_t* bytes, const uint64_t* seg_offsets, uint32_t nseg,
+                          uint64_t seed, uint64_t* out, hipStream_t s);
+void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* seg_offsets,
+                         uint32_t nseg, uint32_t win, const HashParams& p, const CandSink& sink,
+                         hipStream_t s);
+
+// six-frame translation (reference src/lib.rs:277-301, 779-793).  seg_offsets (device, nseg+1
+// entries, nseg = 6*nrec) gives where each (record, frame, strand) segment lives in `residues`;
+// unknown codons are written as 0xFF and skipped by launch_hash_windows; bad_utf8[seg] is set when
+// a codon chunk is not valid UTF-8 (the reference panics there).
+void launch_translate(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t nseg, uint64_t total,
+                      uint8_t* residues, uint32_t* bad_utf8, hipStream_t s);
+
+// synthetic DNA generator (same definition as oracle osynth_dna)
+void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
+                      hipStream_t s);
+
+// --- sort.hip -----------------------------------------------------------------------
+// LSD radix sort, ping-pong between (k0,v0) and (k1,v1); returns which pair holds the result.
+int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
+                   DeviceBuffer& scratch, hipStream_t s);
+// unique keys + run start indices of a sorted array; returns the number of runs (syncs).
+uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
+                               DeviceBuffer& scratch, hipStream_t s);
+void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t n, const uint64_t* weights,
+                const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos, hipStream_t s);
+
+// --- compare_kernels.hip ---------------------------------------------------------------
+// Sketches as CSR: hashes[offsets[i] .. offsets[i+1]) ascending and unique.
+struct SketchSet {
+  const uint64_t* hashes = nullptr;
+  const uint64_t* offsets = nullptr;  // n+1 entries
+  uint32_t n = 0;
+};
+struct CompareOut {
+  uint64_t* common = nullptr;  // |A ^ B ^ bottom_n(A u B)|   (reference src/lib.rs:470-499)
+  uint64_t* size = nullptr;    // |bottom_n(A u B)|
+  double* jaccard = nullptr;   // common / max(1, size)        (reference src/lib.rs:501-508)
+  uint64_t* count_common = nullptr;  // |A ^ B| untruncated     (reference src/lib.rs:428-436)
+  double* containment = nullptr;     // |A ^ B| / |A|           (reference src/index.rs:146-154)
+};
+// rows x cols block; num = truncation length of the union walk (row's `num`; 0 = unbounded),
+// row_nums (device, nullable) overrides it per row.
+// max_row_len / max_col_len: longest sketch on each side (decides LDS staging).
+void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
+                          const uint32_t* row_nums, const CompareOut& out, Device& dev,
+                          hipStream_t s, uint32_t max_row_len, uint32_t max_col_len);
+
+}  // namespace smh

@@ -1,0 +1,638 @@
+// minhash.cpp -- host logic of KmerMinHash + the engine that feeds the HIP kernels.
+//
+// Division of labour (DESIGN.md "fold"):
+//   device : k-mer walk, canonicalisation, murmur64, threshold filter (sketch_kernels.hip);
+//            radix sort, distinct + run boundaries + first position, bottom-n cut (sort.hip);
+//            every sketch comparison (compare_kernels.hip)
+//   host   : applying the resulting delta (<= num entries in num mode, the distinct retained
+//            hashes in scaled mode) to the sorted vector, with the reference's abundance
+//            quirk Q3, and the scalar API (add_hash, merge, check_compatible).
+#include "minhash.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace smh {
+
+// ------------------------------------------------------------------------------------
+// scalar host methods
+
+KmerMinHash::KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track)
+    : num(n), ksize(k), is_protein(prot), seed(seed_), max_hash(mx), has_abunds(track) {
+  mins.reserve(n > 0 ? n : 1000);
+  if (track) abunds.reserve(mins.capacity());
+}
+
+void KmerMinHash::check_compatible(const KmerMinHash& o) const {
+  if (ksize != o.ksize) throw_mismatch(kMismatchKSizes);
+  if (is_protein != o.is_protein) throw_mismatch(kMismatchDNAProt);
+  if (max_hash != o.max_hash) throw_mismatch(kMismatchMaxHash);
+  if (seed != o.seed) throw_mismatch(kMismatchSeed);
+}
+
+// reference src/lib.rs:192-245 (quirks Q3, Q4)
+void KmerMinHash::add_hash(uint64_t hash) {
+  const uint64_t current_max = mins.empty() ? UINT64_MAX : mins.back();
+  if (!(hash <= max_hash || max_hash == 0)) return;
+  if (mins.empty()) {
+    mins.push_back(hash);
+    if (has_abunds) abunds.push_back(1);
+    return;
+  }
+  if (hash <= max_hash || current_max > hash || (uint32_t)mins.size() < num) {
+    size_t pos = std::lower_bound(mins.begin(), mins.end(), hash) - mins.begin();
+    if (pos == mins.size()) {
+      mins.push_back(hash);
+      if (has_abunds) abunds.push_back(1);
+    } else if (mins[pos] != hash) {
+      mins.insert(mins.begin() + pos, hash);
+      if (has_abunds) {
+        if (pos > abunds.size()) throw_panic("insertion index is out of bounds");
+        abunds.insert(abunds.begin() + pos, 1);
+      }
+      if (num != 0 && mins.size() > (size_t)num) {
+        mins.pop_back();
+        if (has_abunds && !abunds.empty()) abunds.pop_back();
+      }
+    } else if (has_abunds) {
+      if (pos >= abunds.size()) throw_panic("index out of bounds");
+      abunds[pos] += 1;
+    }
+  }
+}
+
+void KmerMinHash::add_from(const KmerMinHash& other) {
+  for (uint64_t h : other.mins) add_hash(h);
+}
+void KmerMinHash::add_many(const uint64_t* hashes, size_t n) {
+  for (size_t i = 0; i < n; i++) add_hash(hashes[i]);
+}
+
+// reference src/lib.rs:307-403 (quirks Q5, Q6): the abundance iterators advance exactly as there
+void KmerMinHash::merge(const KmerMinHash& other) {
+  check_compatible(other);
+  std::vector<uint64_t> merged, mab;
+  merged.reserve(mins.size() + other.mins.size());
+  mab.reserve(mins.size() + other.mins.size());
+  size_t si = 0, oi = 0, sai = 0, oai = 0;
+  const bool s_has = has_abunds, o_has = other.has_abunds;
+  while (si < mins.size()) {
+    const uint64_t value = mins[si];
+    if (oi >= other.mins.size()) {
+      merged.insert(merged.end(), mins.begin() + si, mins.end());
+      si = mins.size();
+      if (s_has && sai < abunds.size()) mab.insert(mab.end(), abunds.begin() + sai, abunds.end());
+      sai = abunds.size();
+      break;
+    }
+    const uint64_t x = other.mins[oi];
+    if (x < value) {
+      merged.push_back(x); oi++;
+      if (o_has && oai < other.abunds.size()) mab.push_back(other.abunds[oai++]);
+    } else if (x == value) {
+      merged.push_back(x); oi++; si++;
+      if (o_has && oai < other.abunds.size()) {
+        uint64_t v = other.abunds[oai++];
+        if (s_has && sai < abunds.size()) mab.push_back(v + abunds[sai++]);
+      }
+    } else {
+      merged.push_back(value); si++;
+      if (s_has && sai < abunds.size()) mab.push_back(abunds[sai++]);
+    }
+  }
+  merged.insert(merged.end(), other.mins.begin() + oi, other.mins.end());
+  if (o_has && oai < other.abunds.size())
+    mab.insert(mab.end(), other.abunds.begin() + oai, other.abunds.end());
+  if (!(merged.size() < (size_t)num || num == 0)) merged.resize(num);
+  mins.swap(merged);
+  abunds.swap(mab);
+  has_abunds = true;  // Q5: Some(..) even when nothing was tracked, and never truncated
+}
+
+// ------------------------------------------------------------------------------------
+// engine: hashing a position range into candidates, reducing candidates to a delta
+
+Engine& Engine::get() {
+  static Engine* e = new Engine();
+  return *e;
+}
+
+namespace {
+
+// something whose k-mers / windows can be hashed over an index range of its position space
+struct HashSource {
+  virtual ~HashSource() = default;
+  virtual uint64_t positions() const = 0;
+  virtual void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) = 0;
+};
+
+struct DnaSource : HashSource {
+  SeqBatch b;
+  uint32_t ksize = 0;
+  uint64_t seed = 0;
+  Device* dev = nullptr;
+  uint64_t positions() const override { return b.len; }
+  void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
+    HashParams p;
+    p.ksize = ksize; p.seed = seed; p.thr = thr; p.range_lo = lo; p.range_hi = hi;
+    launch_dna_hash(b, p, sink, *dev, s);
+  }
+};
+
+struct ProteinSource : HashSource {
+  const uint8_t* res = nullptr;
+  const uint64_t* seg_off = nullptr;
+  uint32_t nseg = 0;
+  uint64_t total = 0;
+  uint32_t win = 0;
+  uint64_t seed = 0;
+  Device* dev = nullptr;
+  uint64_t positions() const override { return total; }
+  void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
+    HashParams p;
+    p.seed = seed; p.thr = thr; p.range_lo = lo; p.range_hi = hi;
+    dev->prof_begin(s);
+    launch_hash_windows(res, total, seg_off, nseg, win, p, sink, s);
+    dev->prof_end("hash_windows", s);
+  }
+};
+
+uint64_t estimate_capacity(uint64_t span, uint64_t thr) {
+  // expected number of uniform 64-bit hashes <= thr among `span`, with head-room
+  long double frac = ((long double)thr + 1.0L) / 18446744073709551616.0L;
+  long double e = (long double)span * frac;
+  uint64_t cap = (uint64_t)(e * 1.25L) + 65536;
+  return cap < span ? cap : span;
+}
+
+}  // namespace
+
+uint64_t Engine::run_chunk(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_t thr, bool want_pos,
+                           hipStream_t s) {
+  HashSource& src = *static_cast<HashSource*>(src_);
+  uint64_t cap = estimate_capacity(hi - lo, thr);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (cap >= (1ull << 31)) throw_internal("candidate set of one chunk exceeds 2^31 entries");
+    if (cap == 0) cap = 1;
+    cand_hash[0].ensure(cap * 8);
+    cand_hash[1].ensure(cap * 8);
+    if (want_pos) { cand_pos[0].ensure(cap * 8); cand_pos[1].ensure(cap * 8); }
+    counter.ensure(8);
+    HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, s));
+    CandSink sink;
+    sink.hash = cand_hash[0].as<uint64_t>();
+    sink.pos = want_pos ? cand_pos[0].as<uint64_t>() : nullptr;
+    sink.count = counter.as<unsigned long long>();
+    sink.capacity = cap;
+    src.launch(lo, hi, thr, sink, s);
+    unsigned long long n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, counter.ptr, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (n <= cap) return n;
+    cap = n;  // the counter kept counting: exact size for the re-run
+  }
+  throw_internal("candidate buffer overflow after re-run");
+}
+
+void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s,
+                          Delta* out) {
+  Device& dev = Device::get();
+  out->uniq.clear(); out->run_start.clear(); out->minpos.clear();
+  out->sorted_buf = 0; out->n = n;
+  if (n == 0) return;
+  int cur = radix_sort_u64(cand_hash[0].as<uint64_t>(), cand_hash[1].as<uint64_t>(),
+                           have_pos ? cand_pos[0].as<uint64_t>() : nullptr,
+                           have_pos ? cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s);
+  out->sorted_buf = cur;
+  uniq.ensure(n * 8);
+  starts.ensure((n + 1) * 4);
+  uint32_t nruns = run_length_encode_u64(cand_hash[cur].as<uint64_t>(), n, uniq.as<uint64_t>(),
+                                         starts.as<uint32_t>(), dev.scratch, s);
+  const uint32_t kept = (keep != 0 && nruns > keep) ? keep : nruns;
+  out->uniq.resize(kept);
+  out->run_start.resize(kept + 1);
+  HIP_CHECK(hipMemcpyAsync(out->uniq.data(), uniq.ptr, (size_t)kept * 8, hipMemcpyDeviceToHost, s));
+  // run k is [run_start[k], run_start[k+1]); the end of the last kept run is the next run's
+  // start, or n when nothing follows
+  const uint32_t fetch = kept < nruns ? kept + 1 : kept;
+  HIP_CHECK(hipMemcpyAsync(out->run_start.data(), starts.ptr, (size_t)fetch * 4, hipMemcpyDeviceToHost, s));
+  if (want_minpos && have_pos && kept) {
+    red_b.ensure((size_t)kept * 8);
+    run_reduce(starts.as<uint32_t>(), kept, kept < nruns ? 0xffffffffu : (uint32_t)n, nullptr,
+               cand_pos[cur].as<uint64_t>(), nullptr, red_b.as<uint64_t>(), s);
+    out->minpos.resize(kept);
+    HIP_CHECK(hipMemcpyAsync(out->minpos.data(), red_b.ptr, (size_t)kept * 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (fetch == kept) out->run_start[kept] = (uint32_t)n;
+}
+
+namespace {
+
+enum Mode { kScaled, kNum, kSequential };
+
+Mode mode_of(const KmerMinHash& mh) {
+  const bool ab_ok = !mh.has_abunds || mh.abunds.size() == mh.mins.size();
+  if (mh.num == 0 && mh.max_hash > 0 && ab_ok) return kScaled;
+  if (mh.num > 0 && mh.max_hash == 0 && mh.mins.size() <= (size_t)mh.num && ab_ok) return kNum;
+  return kSequential;
+}
+
+// scaled mode (num == 0, max_hash > 0): set union, counts add up (reference add_hash with
+// `hash <= max_hash` always true: insert or increment, never pop)
+void apply_scaled(KmerMinHash& mh, const Delta& d) {
+  if (d.uniq.empty()) return;
+  std::vector<uint64_t> nm, na;
+  nm.reserve(mh.mins.size() + d.uniq.size());
+  if (mh.has_abunds) na.reserve(nm.capacity());
+  size_t i = 0, j = 0;
+  auto cnt = [&](size_t k) { return (uint64_t)(d.run_start[k + 1] - d.run_start[k]); };
+  while (i < mh.mins.size() || j < d.uniq.size()) {
+    if (j >= d.uniq.size() || (i < mh.mins.size() && mh.mins[i] < d.uniq[j])) {
+      nm.push_back(mh.mins[i]);
+      if (mh.has_abunds) na.push_back(mh.abunds[i]);
+      i++;
+    } else if (i >= mh.mins.size() || d.uniq[j] < mh.mins[i]) {
+      nm.push_back(d.uniq[j]);
+      if (mh.has_abunds) na.push_back(cnt(j));
+      j++;
+    } else {
+      nm.push_back(mh.mins[i]);
+      if (mh.has_abunds) na.push_back(mh.abunds[i] + cnt(j));
+      i++; j++;
+    }
+  }
+  mh.mins.swap(nm);
+  if (mh.has_abunds) mh.abunds.swap(na);
+}
+
+// num mode (num > 0, max_hash == 0).  mins = bottom-num of the union.  Abundances follow the
+// closed form of quirk Q3: every final element gets old + new occurrences, except
+// that when the final sketch is full its LAST element only counts the occurrences up to the
+// stream position T* at which the sketch reached its final content (T* = latest first occurrence
+// over the elements that were not present before; nothing new => no occurrence counts).
+void apply_num(KmerMinHash& mh, const Delta& d, Engine& E, hipStream_t s) {
+  if (d.uniq.empty()) return;
+  const bool track = mh.has_abunds;
+  auto cnt = [&](size_t k) { return (uint64_t)(d.run_start[k + 1] - d.run_start[k]); };
+  std::vector<uint64_t> nm, na;
+  nm.reserve(mh.num);
+  if (track) na.reserve(mh.num);
+  // provenance of the last survivor
+  bool last_old = false, last_new = false;
+  size_t last_j = 0;
+  uint64_t last_old_ab = 0;
+  bool any_new = false;
+  uint64_t tstar = 0;
+  size_t i = 0, j = 0;
+  while (nm.size() < (size_t)mh.num && (i < mh.mins.size() || j < d.uniq.size())) {
+    if (j >= d.uniq.size() || (i < mh.mins.size() && mh.mins[i] < d.uniq[j])) {
+      nm.push_back(mh.mins[i]);
+      if (track) { na.push_back(mh.abunds[i]); last_old = true; last_new = false; last_old_ab = mh.abunds[i]; }
+      i++;
+    } else if (i >= mh.mins.size() || d.uniq[j] < mh.mins[i]) {
+      nm.push_back(d.uniq[j]);
+      if (track) {
+        na.push_back(cnt(j));
+        last_old = false; last_new = true; last_j = j; last_old_ab = 0;
+        any_new = true;
+        tstar = std::max(tstar, d.minpos[j]);
+      }
+      j++;
+    } else {
+      nm.push_back(mh.mins[i]);
+      if (track) {
+        na.push_back(mh.abunds[i] + cnt(j));
+        last_old = true; last_new = true; last_j = j; last_old_ab = mh.abunds[i];
+      }
+      i++; j++;
+    }
+  }
+  if (track && nm.size() == (size_t)mh.num && last_new) {
+    uint64_t c = 0;
+    if (any_new) {
+      const uint32_t lo = d.run_start[last_j], hi = d.run_start[last_j + 1];
+      std::vector<uint64_t> pos(hi - lo);
+      HIP_CHECK(hipMemcpyAsync(pos.data(), E.cand_pos[d.sorted_buf].as<uint64_t>() + lo, (size_t)(hi - lo) * 8,
+                               hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (uint64_t p : pos) c += p <= tstar;
+    }
+    na.back() = (last_old ? last_old_ab : 0) + c;
+  }
+  mh.mins.swap(nm);
+  if (track) mh.abunds.swap(na);
+}
+
+void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
+  Engine& E = Engine::get();
+  Device& dev = Device::get();
+  const uint64_t P = src.positions();
+  if (P == 0) return;
+  const Mode mode = mode_of(mh);
+
+  if (mode == kScaled) {
+    const uint64_t CH = 1ull << 30;
+    for (uint64_t lo = 0; lo < P; lo += CH) {
+      const uint64_t hi = std::min(P, lo + CH);
+      const uint64_t n = E.run_chunk(&src, lo, hi, mh.max_hash, false, s);
+      Delta d;
+      E.reduce_chunk(n, 0, false, false, s, &d);
+      apply_scaled(mh, d);
+    }
+    return;
+  }
+
+  if (mode == kNum) {
+    // The first chunk is small because every hash passes while the sketch is not full; after it
+    // the sketch's own maximum is the filter and chunks grow geometrically.
+    const bool track = mh.has_abunds;
+    uint64_t chunk = std::max<uint64_t>(1u << 16, (uint64_t)mh.num * 64);
+    for (uint64_t lo = 0; lo < P;) {
+      const uint64_t hi = std::min(P, lo + chunk);
+      const bool full = mh.mins.size() >= (size_t)mh.num;
+      const uint64_t thr = full ? mh.mins.back() : UINT64_MAX;
+      const uint64_t n = E.run_chunk(&src, lo, hi, thr, track, s);
+      Delta d;
+      E.reduce_chunk(n, mh.num, track, track, s, &d);
+      apply_num(mh, d, E, s);
+      lo = hi;
+      if (chunk < (1ull << 30)) chunk *= 8;
+    }
+    return;
+  }
+
+  // Order-dependent parameter combinations (num and max_hash both zero or both non-zero, or a
+  // sketch whose vectors were pushed out of shape through the raw ABI): hash on the device,
+  // then replay the reference's add_hash over the survivors in stream order.
+  const uint64_t thr = mh.max_hash > 0 ? mh.max_hash : UINT64_MAX;
+  const uint64_t CH = 1ull << 24;
+  std::vector<uint64_t> hs;
+  for (uint64_t lo = 0; lo < P; lo += CH) {
+    const uint64_t hi = std::min(P, lo + CH);
+    const uint64_t n = E.run_chunk(&src, lo, hi, thr, true, s);
+    if (n == 0) continue;
+    int cur = radix_sort_u64(E.cand_pos[0].as<uint64_t>(), E.cand_pos[1].as<uint64_t>(),
+                             E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(), n, dev.scratch, s);
+    hs.resize(n);
+    HIP_CHECK(hipMemcpyAsync(hs.data(), E.cand_hash[cur].ptr, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (uint64_t h : hs) mh.add_hash(h);
+  }
+}
+
+// String::from_utf8(kmer).unwrap() of reference src/lib.rs:270
+bool utf8_valid(const uint8_t* s, size_t n) {
+  size_t i = 0;
+  while (i < n) {
+    uint8_t c = s[i];
+    if (c < 0x80) { i++; continue; }
+    size_t need; uint8_t lo = 0x80, hi = 0xBF;
+    if (c >= 0xC2 && c <= 0xDF) need = 1;
+    else if (c == 0xE0) { need = 2; lo = 0xA0; }
+    else if (c >= 0xE1 && c <= 0xEC) need = 2;
+    else if (c == 0xED) { need = 2; hi = 0x9F; }
+    else if (c >= 0xEE && c <= 0xEF) need = 2;
+    else if (c == 0xF0) { need = 3; lo = 0x90; }
+    else if (c >= 0xF1 && c <= 0xF3) need = 3;
+    else if (c == 0xF4) { need = 3; hi = 0x8F; }
+    else return false;
+    if (i + need >= n) return false;
+    if (s[i + 1] < lo || s[i + 1] > hi) return false;
+    for (size_t j = 2; j <= need; j++)
+      if (s[i + j] < 0x80 || s[i + j] > 0xBF) return false;
+    i += need + 1;
+  }
+  return true;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// add_sequence front ends
+
+void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len, const uint64_t* h_offsets,
+                                       uint32_t nrec, bool force, hipStream_t stream, Error* first_error) {
+  if (nrec == 0 || total_len == 0) return;
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  Engine& E = Engine::get();
+  hipStream_t s = stream ? stream : dev.stream();
+
+  // records shorter than ksize add nothing (reference src/lib.rs:257)
+  bool any_long = false;
+  for (uint32_t r = 0; r < nrec; r++) any_long |= (h_offsets[r + 1] - h_offsets[r]) >= ksize;
+  if (!any_long) return;
+
+  const uint64_t* d_starts = nullptr;
+  if (nrec > 1) {
+    E.offbuf.ensure((size_t)(nrec + 1) * 8);
+    HIP_CHECK(hipMemcpyAsync(E.offbuf.ptr, h_offsets, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, s));
+    d_starts = E.offbuf.as<uint64_t>();
+  }
+  SeqBatch b;
+  b.seq = d_seq; b.len = total_len; b.starts = d_starts; b.nrec = nrec; b.vend0 = total_len;
+
+  bool have_error = false;
+  Error err(kNoError, "");
+
+  if (!is_protein) {
+    if (ksize == 0) throw_panic("window size must be non-zero");  // slice::windows(0)
+    std::vector<uint64_t> vends;
+    if (!force) {
+      // where each record stops being valid DNA: the windows before that byte are added, the
+      // first window holding it is the error (reference src/lib.rs:261-273, quirk Q1)
+      vends.assign(h_offsets + 1, h_offsets + nrec + 1);
+      E.vendbuf.ensure((size_t)nrec * 8);
+      HIP_CHECK(hipMemcpyAsync(E.vendbuf.ptr, vends.data(), (size_t)nrec * 8, hipMemcpyHostToDevice, s));
+      launch_first_invalid(b, E.vendbuf.as<uint64_t>(), s);
+      HIP_CHECK(hipMemcpyAsync(vends.data(), E.vendbuf.ptr, (size_t)nrec * 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (uint32_t r = 0; r < nrec && !have_error; r++) {
+        const uint64_t st = h_offsets[r], en = h_offsets[r + 1], bad = vends[r];
+        if (bad >= en || en - st < ksize) continue;
+        const uint64_t ws = bad + 1 >= st + ksize ? bad + 1 - ksize : st;  // first window holding `bad`
+        std::vector<uint8_t> kmer(ksize);
+        HIP_CHECK(hipMemcpyAsync(kmer.data(), d_seq + ws, ksize, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (auto& c : kmer) if (c >= 'a' && c <= 'z') c -= 32;
+        have_error = true;
+        if (!utf8_valid(kmer.data(), kmer.size()))
+          err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: FromUtf8Error");
+        else
+          err = Error(kInvalidDNA, "invalid DNA character in input k-mer: " +
+                                       std::string(kmer.begin(), kmer.end()));
+      }
+      // records shorter than ksize must not lose anything: they add nothing either way
+      if (nrec > 1) b.vends = E.vendbuf.as<uint64_t>();
+      else b.vend0 = vends[0];
+    }
+    DnaSource src;
+    src.b = b; src.ksize = ksize; src.seed = seed; src.dev = &dev;
+    ingest(*this, src, s);
+  } else {
+    // six-frame translation (reference src/lib.rs:277-301)
+    const uint32_t aa_k = ksize / 3;
+    const uint32_t nseg = 6 * nrec;
+    std::vector<uint64_t> seg(nseg + 1, 0);
+    for (uint32_t r = 0; r < nrec; r++) {
+      const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+      for (uint32_t f = 0; f < 6; f++) {
+        const uint32_t frame = f >> 1;
+        uint64_t nres = (len >= ksize && len >= frame) ? (len - frame) / 3 : 0;
+        seg[6 * r + f + 1] = seg[6 * r + f] + nres;
+      }
+    }
+    const uint64_t total = seg[nseg];
+    if (aa_k == 0) throw_panic("window size must be non-zero");  // aa.windows(0), quirk Q8
+    if (total == 0) return;
+    E.segbuf.ensure((size_t)(nseg + 1) * 8);
+    E.badbuf.ensure((size_t)nseg * 4);
+    E.resbuf.ensure(total);
+    HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemsetAsync(E.badbuf.ptr, 0, (size_t)nseg * 4, s));
+    launch_translate(b, E.segbuf.as<uint64_t>(), nseg, total, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);
+    std::vector<uint32_t> bad(nseg);
+    HIP_CHECK(hipMemcpyAsync(bad.data(), E.badbuf.ptr, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (uint32_t r = 0; r < nrec; r++) {
+      for (uint32_t f = 0; f < 6; f++) {
+        if (!bad[6 * r + f]) continue;
+        // from_utf8(chunk).unwrap() panics in frame f: frames before it were added, it and the
+        // rest of this record were not
+        const uint64_t lo = seg[6 * r + f], hi = seg[6 * r + 6];
+        if (hi > lo) HIP_CHECK(hipMemsetAsync(E.resbuf.as<uint8_t>() + lo, 0xFF, hi - lo, s));
+        if (!have_error) {
+          have_error = true;
+          err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: Utf8Error");
+        }
+        break;
+      }
+    }
+    ProteinSource src;
+    src.res = E.resbuf.as<uint8_t>(); src.seg_off = E.segbuf.as<uint64_t>(); src.nseg = nseg;
+    src.total = total; src.win = aa_k; src.seed = seed; src.dev = &dev;
+    ingest(*this, src, s);
+  }
+
+  if (have_error) {
+    if (first_error) *first_error = err;
+    else throw err;
+  }
+}
+
+void KmerMinHash::add_sequence(const uint8_t* seq, size_t len, bool force) {
+  if (len < ksize) return;  // reference src/lib.rs:257
+  Device& dev = Device::get();
+  Engine& E = Engine::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  E.seqbuf.ensure(len + 64);
+  HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq, len, hipMemcpyHostToDevice, dev.stream()));
+  const uint64_t off[2] = {0, (uint64_t)len};
+  add_sequences_device(E.seqbuf.as<uint8_t>(), len, off, 1, force, dev.stream(), nullptr);
+}
+
+// ------------------------------------------------------------------------------------
+// murmur64 of whole words (add_word, hash_murmur)
+
+void Engine::hash_words(const uint8_t* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed,
+                        uint64_t* out) {
+  if (n == 0) return;
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  hipStream_t s = dev.stream();
+  const uint64_t total = offsets[n];
+  misc.ensure(total + 64 + (size_t)(n + 1) * 8 + (size_t)n * 8);
+  uint8_t* d_bytes = misc.as<uint8_t>();
+  const size_t off_at = (total + 63) & ~(size_t)63;
+  uint64_t* d_off = reinterpret_cast<uint64_t*>(d_bytes + off_at);
+  uint64_t* d_out = d_off + (n + 1);
+  if (total) HIP_CHECK(hipMemcpyAsync(d_bytes, bytes, total, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(d_off, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+  launch_hash_segments(d_bytes, d_off, n, seed, d_out, s);
+  HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void KmerMinHash::add_word(const uint8_t* w, size_t len) {
+  const uint64_t off[2] = {0, (uint64_t)len};
+  uint64_t h = 0;
+  Engine::get().hash_words(w, off, 1, seed, &h);
+  add_hash(h);
+}
+
+// ------------------------------------------------------------------------------------
+// comparisons of host-resident sketches
+
+void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std::vector<const KmerMinHash*>& cols,
+                          const uint32_t* row_nums_host, uint32_t num, uint64_t* common, uint64_t* size,
+                          double* jaccard, uint64_t* count_common, double* containment) {
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  hipStream_t s = dev.stream();
+  auto pack = [&](const std::vector<const KmerMinHash*>& v, DeviceBuffer& data, DeviceBuffer& offs,
+                  SketchSet* out, uint32_t* maxlen) {
+    std::vector<uint64_t> off(v.size() + 1, 0);
+    *maxlen = 0;
+    for (size_t i = 0; i < v.size(); i++) {
+      off[i + 1] = off[i] + v[i]->mins.size();
+      *maxlen = std::max<uint32_t>(*maxlen, (uint32_t)v[i]->mins.size());
+    }
+    data.ensure(off.back() * 8 + 8);
+    offs.ensure(off.size() * 8);
+    for (size_t i = 0; i < v.size(); i++)
+      if (!v[i]->mins.empty())
+        HIP_CHECK(hipMemcpyAsync(data.as<uint64_t>() + off[i], v[i]->mins.data(), v[i]->mins.size() * 8,
+                                 hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(offs.ptr, off.data(), off.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));  // `off` is a stack-lifetime staging buffer
+    out->hashes = data.as<uint64_t>();
+    out->offsets = offs.as<uint64_t>();
+    out->n = (uint32_t)v.size();
+  };
+  SketchSet R, C;
+  uint32_t mr = 0, mc = 0;
+  pack(rows, cmp_a, cmp_oa, &R, &mr);
+  pack(cols, cmp_b, cmp_ob, &C, &mc);
+  const size_t np = rows.size() * cols.size();
+  if (np == 0) return;
+  cmp_out.ensure(np * 8 * 5 + rows.size() * 4 + 64);
+  uint64_t* d_common = cmp_out.as<uint64_t>();
+  uint64_t* d_size = d_common + np;
+  double* d_jac = reinterpret_cast<double*>(d_size + np);
+  uint64_t* d_cc = reinterpret_cast<uint64_t*>(d_jac + np);
+  double* d_cont = reinterpret_cast<double*>(d_cc + np);
+  uint32_t* d_rownum = reinterpret_cast<uint32_t*>(d_cont + np);
+  if (row_nums_host)
+    HIP_CHECK(hipMemcpyAsync(d_rownum, row_nums_host, rows.size() * 4, hipMemcpyHostToDevice, s));
+  CompareOut o;
+  o.common = d_common; o.size = d_size; o.jaccard = d_jac; o.count_common = d_cc; o.containment = d_cont;
+  launch_compare_block(R, C, num, row_nums_host ? d_rownum : nullptr, o, dev, s, mr, mc);
+  if (common) HIP_CHECK(hipMemcpyAsync(common, d_common, np * 8, hipMemcpyDeviceToHost, s));
+  if (size) HIP_CHECK(hipMemcpyAsync(size, d_size, np * 8, hipMemcpyDeviceToHost, s));
+  if (jaccard) HIP_CHECK(hipMemcpyAsync(jaccard, d_jac, np * 8, hipMemcpyDeviceToHost, s));
+  if (count_common) HIP_CHECK(hipMemcpyAsync(count_common, d_cc, np * 8, hipMemcpyDeviceToHost, s));
+  if (containment) HIP_CHECK(hipMemcpyAsync(containment, d_cont, np * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+
+uint64_t KmerMinHash::count_common(const KmerMinHash& other) const {
+  check_compatible(other);
+  uint64_t cc = 0;
+  Engine::get().compare_host({this}, {&other}, nullptr, num, nullptr, nullptr, nullptr, &cc, nullptr);
+  return cc;
+}
+
+void KmerMinHash::intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const {
+  check_compatible(other);
+  Engine::get().compare_host({this}, {&other}, nullptr, num, common, size, nullptr, nullptr, nullptr);
+}
+
+double KmerMinHash::compare(const KmerMinHash& other) const {
+  check_compatible(other);
+  double j = 0.0;
+  Engine::get().compare_host({this}, {&other}, nullptr, num, nullptr, nullptr, &j, nullptr, nullptr);
+  return j;
+}
+
+}  // namespace smh

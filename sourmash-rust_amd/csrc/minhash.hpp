@@ -1,0 +1,90 @@
+// minhash.hpp -- host-side KmerMinHash and the sketching engine that drives the HIP kernels.
+//
+// Mirrors the reference's `pub struct KmerMinHash` (src/lib.rs:37-46) field for field and its
+// methods (src/lib.rs:141-513).  Scalar methods (add_hash, merge, check_compatible) are plain
+// host code like the reference's; everything that touches sequence bytes or compares sketches
+// runs on the GPU and throws Error(kInternal) when no device is usable -- there is no CPU
+// fallback for those.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace smh {
+
+// result of hashing one chunk on the device: what must be merged into a sketch
+struct Delta {
+  std::vector<uint64_t> uniq;       // ascending distinct hashes that passed the filter (kept prefix)
+  std::vector<uint32_t> run_start;  // uniq.size()+1 entries: run k is [run_start[k], run_start[k+1])
+  std::vector<uint64_t> minpos;     // first stream position of each (empty when not requested)
+  int sorted_buf = 0;               // which candidate ping-pong half holds the sorted chunk
+  uint64_t n = 0;                   // candidates in the chunk
+};
+
+struct KmerMinHash {
+  uint32_t num = 1000;
+  uint32_t ksize = 21;
+  bool is_protein = false;
+  uint64_t seed = 42;
+  uint64_t max_hash = 0;
+  std::vector<uint64_t> mins;
+  bool has_abunds = false;         // Option<Vec<u64>>::is_some()
+  std::vector<uint64_t> abunds;
+
+  KmerMinHash() { mins.reserve(1000); }  // Default, src/lib.rs:48-60
+  KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track);  // 142-174
+
+  void check_compatible(const KmerMinHash& other) const;                 // 176-190
+  void add_hash(uint64_t h);                                             // 192-245
+  void add_word(const uint8_t* w, size_t len);                           // 247-250 (hash on device)
+  void add_sequence(const uint8_t* seq, size_t len, bool force);         // 252-305 (host bytes)
+  void merge(const KmerMinHash& other);                                  // 307-403
+  void add_from(const KmerMinHash& other);                               // 405-410
+  void add_many(const uint64_t* hashes, size_t n);                       // 412-417
+  uint64_t count_common(const KmerMinHash& other) const;                 // 428-436 (device)
+  void intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const;  // 470-499
+  double compare(const KmerMinHash& other) const;                        // 501-508 (device)
+  size_t size() const { return mins.size(); }
+
+  // --- batch entry points (additive C ABI) ---
+  // Records live in ONE device buffer; h_offsets has nrec+1 host entries.  Semantics: as if
+  // add_sequence were called on every record in order; the first record that would have
+  // returned Err is reported through *first_error (nullable) after all records were processed.
+  void add_sequences_device(const uint8_t* d_seq, uint64_t total_len, const uint64_t* h_offsets,
+                            uint32_t nrec, bool force, hipStream_t stream, Error* first_error);
+};
+
+// One process-wide workspace: candidate buffers, sort ping-pong, small staging areas.
+// Entry points take the Device mutex (recursive).
+using HashSourceRef = void*;  // HashSource* of minhash.cpp
+class Engine {
+ public:
+  static Engine& get();
+
+  // hash positions [lo, hi) of a source, keep hashes <= thr: candidates land in cand_hash[0]
+  // (and cand_pos[0]); returns how many.  Re-runs once with an exact buffer on overflow.
+  uint64_t run_chunk(HashSourceRef src, uint64_t lo, uint64_t hi, uint64_t thr, bool want_pos, hipStream_t s);
+  // sort the chunk by hash, collapse runs, keep the first `keep` runs (0 = all), fetch them
+  void reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s, Delta* out);
+
+  // murmur64 of whole byte strings on the device (host pointers in, host pointer out)
+  void hash_words(const uint8_t* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out);
+
+  // block compare of host-resident sketches (uploads them); outputs are row-major rows x cols
+  void compare_host(const std::vector<const KmerMinHash*>& rows, const std::vector<const KmerMinHash*>& cols,
+                    const uint32_t* row_nums_host, uint32_t num, uint64_t* common, uint64_t* size,
+                    double* jaccard, uint64_t* count_common, double* containment);
+
+  DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, starts, red_b, misc, seqbuf, offbuf, vendbuf;
+  DeviceBuffer resbuf, segbuf, badbuf, cmp_a, cmp_b, cmp_oa, cmp_ob, cmp_out;
+
+ private:
+  Engine() = default;
+};
+
+}  // namespace smh

@@ -1,0 +1,512 @@
+// sketch_kernels.hip -- gfx950 kernels for KmerMinHash::add_sequence
+// (reference src/lib.rs:252-305) and its helpers:
+//
+//   k_dna_rolling<K>   DNA arm, ksize <= 32.  One lane owns a run of R consecutive k-mer start
+//                      positions; the tile is read from HBM once with coalesced 16-byte loads
+//                      and staged in LDS; each lane rolls two 2-bit packed windows (forward in
+//                      big- and little-endian digit order; the reverse complement is their
+//                      bitwise complement), picks the canonical strand with one 64-bit compare,
+//                      expands it to the ASCII bytes murmur needs through a bank-replicated LDS
+//                      table and runs MurmurHash3 x64_128 (first word) in registers.
+//                      replaces: src/lib.rs:260-267 (+ revcomp 677-689, _checkdna 795-804,
+//                      _hash_murmur 33-35) and the `hash <= max_hash` filter of add_hash 198.
+//   k_dna_generic      same contract for any ksize, one lane per k-mer, byte-wise.
+//   k_first_invalid    first byte outside [ACGTacgt] per record (force=false, lib.rs:268-273).
+//   k_translate        six-frame translation, unknown codons marked (lib.rs:277-301, 779-793).
+//   k_hash_windows     every window of `win` residues, skipping dropped codons (lib.rs:289-300).
+//   k_hash_segments    murmur64 of whole byte strings (add_word lib.rs:247-250, ffi.rs:15-24).
+//   k_synth_dna        benchmark input generator.
+//
+// All arithmetic is 64-bit integer; results are bit-exact with the reference by construction
+// and checked against oracle/ in tests/.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace smh {
+namespace {
+
+// ---------------------------------------------------------------------------------
+// MurmurHash3 x64_128 pieces (crate murmurhash3 ~0.0.5 as called at reference src/lib.rs:33-35)
+constexpr uint64_t kC1 = 0x87c37b91114253d5ULL;
+constexpr uint64_t kC2 = 0x4cf5ad432745937fULL;
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+__device__ __forceinline__ uint64_t mix_k1(uint64_t k1) { k1 *= kC1; k1 = rotl64(k1, 31); k1 *= kC2; return k1; }
+__device__ __forceinline__ uint64_t mix_k2(uint64_t k2) { k2 *= kC2; k2 = rotl64(k2, 33); k2 *= kC1; return k2; }
+__device__ __forceinline__ void mm3_block(uint64_t& h1, uint64_t& h2, uint64_t k1, uint64_t k2) {
+  h1 ^= mix_k1(k1);
+  h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+  h2 ^= mix_k2(k2);
+  h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+}
+__device__ __forceinline__ uint64_t mm3_finish(uint64_t h1, uint64_t h2, uint64_t len) {
+  h1 ^= len; h2 ^= len;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return h1 + h2;  // first word of the digest
+}
+
+// byte-at-a-time front end for strings of any length
+struct Mm3Stream {
+  uint64_t h1, h2, k1, k2;
+  uint32_t n;
+  __device__ __forceinline__ explicit Mm3Stream(uint64_t seed) : h1(seed), h2(seed), k1(0), k2(0), n(0) {}
+  __device__ __forceinline__ void push(uint32_t b) {
+    uint32_t r = n & 15u;
+    if (r < 8) k1 |= (uint64_t)b << (8 * r);
+    else k2 |= (uint64_t)b << (8 * (r - 8));
+    n++;
+    if ((n & 15u) == 0) { mm3_block(h1, h2, k1, k2); k1 = 0; k2 = 0; }
+  }
+  __device__ __forceinline__ uint64_t finish() {
+    uint32_t rem = n & 15u;
+    if (rem > 8) h2 ^= mix_k2(k2);
+    if (rem > 0) h1 ^= mix_k1(k1);
+    return mm3_finish(h1, h2, n);
+  }
+};
+
+__device__ __forceinline__ void emit(const CandSink& sink, uint64_t h, uint64_t pos) {
+  unsigned long long idx = atomicAdd(sink.count, 1ull);  // hipcc aggregates this per wave
+  if (idx < sink.capacity) {
+    sink.hash[idx] = h;
+    if (sink.pos) sink.pos[idx] = pos;
+  }
+}
+
+// last record whose start is <= p   (starts has nrec+1 entries, starts[nrec] = total length)
+__device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ starts, uint32_t nrec,
+                                                uint64_t p) {
+  uint32_t lo = 0, hi = nrec;  // answer in [lo, hi)
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (starts[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+
+// ---------------------------------------------------------------------------------
+// DNA arm, rolling 2-bit windows, ksize <= 32
+constexpr int kDnaThreads = 256;
+constexpr int kLutReplicas = 16;                 // lane l uses replica l & 15: at most 2-way conflicts
+constexpr int kLutDwords = 256 * kLutReplicas;   // 16 KiB
+
+// KT > 0: ksize fixed at compile time; KT == 0: any ksize in 1..32 at run time.
+template <int KT>
+__global__ __launch_bounds__(kDnaThreads) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
+                                                             int logR) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* lut = smem;
+  uint32_t* tile = smem + kLutDwords;
+
+  const int K = KT ? KT : (int)hp.ksize;
+  const int tid = threadIdx.x;
+  const uint32_t R = 1u << logR;
+  const uint64_t TILE = (uint64_t)kDnaThreads << logR;
+  const uint64_t MASK = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
+  const int top_shift = 2 * K - 2;
+  const bool multi = b.starts != nullptr;
+
+  // 4 two-bit digits -> 4 ASCII bytes, digit d -> "ACGT"[d], first digit in the low byte
+  for (int e = tid; e < kLutDwords; e += kDnaThreads) {
+    uint32_t idx = (uint32_t)e >> 4, v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
+    lut[e] = v;
+  }
+  const uint32_t lut_lane = (uint32_t)(tid & (kLutReplicas - 1)) << 2;  // byte offset of my replica
+
+  const uint64_t span = hp.range_hi - hp.range_lo;
+  const uint64_t ntiles = (span + TILE - 1) / TILE;
+  const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
+  const uint32_t nsteps = (R + (uint32_t)K - 1 + 3) & ~3u;  // bases walked per lane, multiple of 4
+
+  for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const uint64_t T0 = hp.range_lo + tix * TILE;
+    const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+
+    // ---- stage [T0, T0 + TILE + K - 1) in LDS: aligned 16-byte loads, one pad dword per R bytes
+    const uintptr_t g0 = (uintptr_t)(b.seq + T0);
+    const uintptr_t ga = g0 & ~(uintptr_t)15;
+    const uint32_t m = (uint32_t)(g0 - ga);
+    const uint32_t nchunks = (m + (uint32_t)TILE + 40 + 15) >> 4;  // K <= 32: last lane reads < m+TILE+38
+    __syncthreads();  // LUT ready / previous tile fully consumed
+    for (uint32_t c = tid; c < nchunks; c += kDnaThreads) {
+      uintptr_t addr = ga + ((uintptr_t)c << 4);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (addr < gend) v = *reinterpret_cast<const uint4*>(addr);
+      uint32_t x = c << 4;
+      uint32_t o = (x >> 2) + (x >> logR);
+      tile[o] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+    }
+    __syncthreads();
+
+    const uint64_t p0 = T0 + ((uint64_t)tid << logR);  // my first k-mer start position
+    if (p0 >= hp.range_hi) continue;                   // no barrier below this point in the tile
+    const uint32_t nk = (hp.range_hi - p0) < R ? (uint32_t)(hp.range_hi - p0) : R;
+
+    // record bookkeeping: `lim` = index of the first base of my run that is not inside the
+    // current record's valid part; the per-base test is one compare.
+    uint32_t rec = 0;
+    uint64_t cur_end = b.vend0;
+    if (multi) {
+      rec = find_record(b.starts, b.nrec, p0);
+      cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+    }
+    uint32_t lim = 0;
+    if (cur_end > p0) lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
+
+    uint32_t x = (m & ~3u) + ((uint32_t)tid << logR);
+    const uint32_t sh = m & 3u;
+    uint32_t cur = tile[(x >> 2) + (x >> logR)];
+    uint64_t fbe = 0, fle = 0;  // forward k-mer, first base most / least significant
+    uint32_t vrun = 0;          // consecutive valid bases ending here
+
+    for (uint32_t i0 = 0; i0 < nsteps; i0 += 4) {
+      x += 4;
+      const uint32_t nxt = tile[(x >> 2) + (x >> logR)];
+      const uint32_t d = __builtin_amdgcn_alignbyte(nxt, cur, sh);
+      cur = nxt;
+      // four bases at once: upper-case, 2-bit code (A0 C1 G2 T3), validity by re-encoding
+      const uint32_t u4 = d & 0xDFDFDFDFu;
+      const uint32_t c2 = (u4 >> 1) & 0x03030303u;
+      const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
+      const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
+      const uint32_t diff4 = u4 ^ exp4;
+#pragma unroll
+      for (int bb = 0; bb < 4; bb++) {
+        const uint32_t i = i0 + bb;
+        const uint32_t code = (code4 >> (8 * bb)) & 3u;
+        uint32_t bad = (diff4 >> (8 * bb)) & 0xffu;
+        if (i >= lim) {
+          // at or past the end of the record's valid part: find where base p0+i belongs
+          const uint64_t q = p0 + i;
+          if (multi) {
+            while (rec + 1 < b.nrec && q >= b.starts[rec + 1]) { rec++; vrun = 0; }
+            cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+          }
+          if (q >= cur_end) { bad = 1; lim = i + 1; }
+          else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
+        }
+        vrun = bad ? 0u : vrun + 1u;
+        fbe = ((fbe << 2) | code) & MASK;
+        fle = (fle >> 2) | ((uint64_t)code << top_shift);
+        if (i + 1 >= (uint32_t)K) {
+          const uint32_t s = i + 1 - (uint32_t)K;  // k-mer start index inside my run
+          if (vrun >= (uint32_t)K && s < nk) {
+            // canonical strand: reverse complement, first base most significant, is ~fle
+            const uint64_t rbe = ~fle & MASK;
+            const uint64_t X = fbe < rbe ? fle : ~fbe;  // chosen strand, first base in the low bits
+            uint32_t D[8];
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+              if (4 * g < K) {
+                uint32_t idx = (uint32_t)(X >> (8 * g)) & 0xffu;
+                uint32_t w = *reinterpret_cast<const uint32_t*>(
+                    reinterpret_cast<const char*>(lut) + ((idx << 6) | lut_lane));
+                int nb = K - 4 * g;  // bytes of this dword that belong to the k-mer
+                if (nb < 4) w &= (1u << (8 * nb)) - 1u;
+                D[g] = w;
+              } else {
+                D[g] = 0;
+              }
+            }
+            const uint64_t w0 = D[0] | ((uint64_t)D[1] << 32), w1 = D[2] | ((uint64_t)D[3] << 32);
+            const uint64_t w2 = D[4] | ((uint64_t)D[5] << 32), w3 = D[6] | ((uint64_t)D[7] << 32);
+            uint64_t h1 = hp.seed, h2 = hp.seed;
+            if (K >= 16) {
+              mm3_block(h1, h2, w0, w1);
+              if (K == 32) mm3_block(h1, h2, w2, w3);
+              else {
+                if (K > 24) h2 ^= mix_k2(w3);
+                if (K > 16) h1 ^= mix_k1(w2);
+              }
+            } else {
+              if (K > 8) h2 ^= mix_k2(w1);
+              h1 ^= mix_k1(w0);
+            }
+            const uint64_t h = mm3_finish(h1, h2, (uint64_t)K);
+            if (h <= thr) emit(sink, h, hp.pos_base + p0 + s);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// DNA arm, any ksize: one lane per k-mer start position
+__global__ __launch_bounds__(256) void k_dna_generic(SeqBatch b, HashParams hp, CandSink sink) {
+  const uint64_t K = hp.ksize;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+  for (uint64_t p = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < hp.range_hi;
+       p += stride) {
+    uint64_t end = b.vend0;
+    if (b.starts) {
+      uint32_t r = find_record(b.starts, b.nrec, p);
+      end = b.vends ? b.vends[r] : b.starts[r + 1];
+    }
+    if (p + K > end || p + K < p) continue;
+    const uint8_t* s = b.seq + p;
+    bool ok = true, decided = false, fwd = true;
+    for (uint64_t i = 0; i < K; i++) {
+      uint32_t f = upper(s[i]);
+      if (!(f == 'A' || f == 'C' || f == 'G' || f == 'T')) { ok = false; break; }
+      if (!decided) {
+        uint32_t t = upper(s[K - 1 - i]);
+        uint32_t rc = t == 'A' ? 'T' : t == 'T' ? 'A' : t == 'C' ? 'G' : t == 'G' ? 'C' : t;
+        if (f != rc) { fwd = f < rc; decided = true; }
+      }
+    }
+    if (!ok) continue;
+    Mm3Stream st(hp.seed);
+    for (uint64_t i = 0; i < K; i++) {
+      uint32_t c;
+      if (fwd) c = upper(s[i]);
+      else {
+        uint32_t t = upper(s[K - 1 - i]);
+        c = t == 'A' ? 'T' : t == 'T' ? 'A' : t == 'C' ? 'G' : 'C';
+      }
+      st.push(c);
+    }
+    uint64_t h = st.finish();
+    if (h <= thr) emit(sink, h, hp.pos_base + p);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_first_invalid(SeqBatch b, uint64_t* __restrict__ vends) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+  for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; base < b.len;
+       base += stride) {
+    uint64_t hi = base + 16 < b.len ? base + 16 : b.len;
+    for (uint64_t q = base; q < hi; q++) {
+      uint32_t u = b.seq[q] & 0xDFu;
+      if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) {
+        uint32_t r = b.starts ? find_record(b.starts, b.nrec, q) : 0;
+        atomicMin((unsigned long long*)&vends[r], (unsigned long long)q);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// protein arm, phase 1: translate.  Residue buffer layout: for record r, segments
+// 6r+0..6r+5 = (frame 0 fwd, frame 0 rc, frame 1 fwd, frame 1 rc, frame 2 fwd, frame 2 rc),
+// the order the reference walks them; an unknown codon becomes kDropped.
+constexpr uint32_t kDropped = 0xFFu;
+__constant__ char kCodonAA[65] =
+    "FFLLSSSSYY**CC*W" "LLLLPPPPHHQQRRRR" "IIIMTTTTNNKKSSRR" "VVVVAAAADDEEGGGG";  // T,C,A,G order
+
+__device__ __forceinline__ int tcag(uint32_t c) {
+  return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : -1;
+}
+__device__ __forceinline__ uint32_t comp_upper(uint32_t c) {
+  return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+}
+// str::from_utf8 on a 3-byte chunk (reference src/lib.rs:787 unwraps it)
+__device__ __forceinline__ bool utf8_ok3(uint32_t a, uint32_t c, uint32_t d) {
+  auto cont = [](uint32_t v) { return v >= 0x80 && v <= 0xBF; };
+  auto lead2 = [](uint32_t v) { return v >= 0xC2 && v <= 0xDF; };
+  if (a < 0x80) {
+    if (c < 0x80) return d < 0x80;
+    return lead2(c) && cont(d);
+  }
+  if (lead2(a)) return cont(c) && d < 0x80;
+  if (a == 0xE0) return c >= 0xA0 && c <= 0xBF && cont(d);
+  if (a == 0xED) return c >= 0x80 && c <= 0x9F && cont(d);
+  if (a >= 0xE1 && a <= 0xEF) return cont(c) && cont(d);
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_translate(SeqBatch b, const uint64_t* __restrict__ seg_off,
+                                                   uint32_t nseg, uint8_t* __restrict__ res,
+                                                   uint32_t* __restrict__ bad_utf8) {
+  const uint64_t total = seg_off[nseg];
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    uint32_t seg = find_record(seg_off, nseg, g);
+    uint32_t r = seg / 6, f = seg % 6, frame = f >> 1;
+    uint64_t j = g - seg_off[seg];
+    uint64_t rs = b.starts ? b.starts[r] : 0;
+    uint64_t rl = (b.starts ? b.starts[r + 1] : b.len) - rs;
+    uint32_t c0, c1, c2;
+    if ((f & 1) == 0) {
+      const uint8_t* s = b.seq + rs + frame + 3 * j;
+      c0 = upper(s[0]); c1 = upper(s[1]); c2 = upper(s[2]);
+    } else {
+      const uint8_t* s = b.seq + rs + (rl - 1 - frame - 3 * j);
+      c0 = comp_upper(upper(s[0])); c1 = comp_upper(upper(*(s - 1))); c2 = comp_upper(upper(*(s - 2)));
+    }
+    if ((c0 | c1 | c2) & 0x80u) {
+      if (!utf8_ok3(c0, c1, c2)) atomicOr(&bad_utf8[seg], 1u);
+    }
+    int i0 = tcag(c0), i1 = tcag(c1), i2 = tcag(c2);
+    res[g] = (i0 < 0 || i1 < 0 || i2 < 0) ? (uint8_t)kDropped : (uint8_t)kCodonAA[16 * i0 + 4 * i1 + i2];
+  }
+}
+
+// protein arm, phase 2: a window starts at every kept residue and takes the next `win` kept
+// residues of the same segment (dropped codons are spliced out, quirk Q8).
+__global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict__ res,
+                                                      const uint64_t* __restrict__ seg_off,
+                                                      uint32_t nseg, uint32_t win, HashParams hp,
+                                                      CandSink sink) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+  for (uint64_t g = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < hp.range_hi;
+       g += stride) {
+    if (res[g] == kDropped) continue;
+    uint32_t seg = find_record(seg_off, nseg, g);
+    const uint64_t end = seg_off[seg + 1];
+    Mm3Stream st(hp.seed);
+    uint32_t got = 0;
+    for (uint64_t q = g; q < end && got < win; q++) {
+      uint32_t c = res[q];
+      if (c != kDropped) { st.push(c); got++; }
+    }
+    if (got < win) continue;
+    uint64_t h = st.finish();
+    if (h <= thr) emit(sink, h, hp.pos_base + g);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hash_segments(const uint8_t* __restrict__ bytes,
+                                                       const uint64_t* __restrict__ off, uint32_t nseg,
+                                                       uint64_t seed, uint64_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg) return;
+  Mm3Stream st(seed);
+  for (uint64_t q = off[i]; q < off[i + 1]; q++) st.push(bytes[q]);
+  out[i] = st.finish();
+}
+
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t index) {
+  uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// one lane per 64-bit generator word = 32 bases; `start` is a multiple of 32
+__global__ __launch_bounds__(256) void k_synth_dna(uint8_t* __restrict__ out, uint64_t start, uint64_t len,
+                                                   uint64_t seed, uint64_t n_every) {
+  const uint64_t nwords = (len + 31) / 32;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    uint64_t bits = splitmix64(seed, (start >> 5) + w);
+    uint64_t p = start + 32 * w;
+    uint64_t nrem = n_every ? p % n_every : 0;
+    uint64_t o = 32 * w;
+    for (int j = 0; j < 32 && o + j < len; j++) {
+      uint32_t c = (0x54474341u >> (8 * ((bits >> (2 * j)) & 3))) & 0xffu;
+      if (n_every) {
+        if (nrem == n_every - 1) c = 'N';
+        nrem = nrem + 1 == n_every ? 0 : nrem + 1;
+      }
+      out[o + j] = (uint8_t)c;
+    }
+  }
+}
+
+inline int grid_for(uint64_t items, int per_block, int cap) {
+  uint64_t g = (items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (uint64_t)cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// launchers
+
+void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sink, Device& dev,
+                     hipStream_t s, bool force_generic) {
+  if (p.range_hi <= p.range_lo) return;
+  const uint64_t span = p.range_hi - p.range_lo;
+  dev.prof_begin(s);
+  if (p.ksize >= 1 && p.ksize <= 32 && !force_generic) {
+    // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
+    // runs so that the launch still covers the chip
+    int logR = 7;
+    while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * kDnaThreads * 2) logR--;
+    const uint64_t tile = (uint64_t)kDnaThreads << logR;
+    const uint64_t ntiles = (span + tile - 1) / tile;
+    int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
+    const uint32_t x_bytes = (uint32_t)tile + 96;
+    const size_t lds = (size_t)kLutDwords * 4 + x_bytes + 4 * ((x_bytes >> logR) + 2);
+    if (p.ksize == 31)
+      hipLaunchKernelGGL(k_dna_rolling<31>, dim3(grid), dim3(kDnaThreads), lds, s, b, p, sink, logR);
+    else if (p.ksize == 21)
+      hipLaunchKernelGGL(k_dna_rolling<21>, dim3(grid), dim3(kDnaThreads), lds, s, b, p, sink, logR);
+    else
+      hipLaunchKernelGGL(k_dna_rolling<0>, dim3(grid), dim3(kDnaThreads), lds, s, b, p, sink, logR);
+    HIP_CHECK(hipGetLastError());
+    dev.prof_end("dna_rolling", s);
+  } else {
+    hipLaunchKernelGGL(k_dna_generic, dim3(grid_for(span, 256, dev.cu_count() * 16)), dim3(256), 0, s,
+                       b, p, sink);
+    HIP_CHECK(hipGetLastError());
+    dev.prof_end("dna_generic", s);
+  }
+}
+
+void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s) {
+  if (b.len == 0) return;
+  hipLaunchKernelGGL(k_first_invalid, dim3(grid_for(b.len, 256 * 16, 4096)), dim3(256), 0, s, b,
+                     vends_out);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_translate(const SeqBatch& b, const uint64_t* seg_off, uint32_t nseg, uint64_t total,
+                      uint8_t* residues, uint32_t* bad_utf8, hipStream_t s) {
+  if (total == 0) return;
+  hipLaunchKernelGGL(k_translate, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, b, seg_off, nseg,
+                     residues, bad_utf8);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* seg_offsets,
+                         uint32_t nseg, uint32_t win, const HashParams& p, const CandSink& sink,
+                         hipStream_t s) {
+  (void)total;
+  if (p.range_hi <= p.range_lo) return;
+  hipLaunchKernelGGL(k_hash_windows, dim3(grid_for(p.range_hi - p.range_lo, 256, 8192)), dim3(256), 0,
+                     s, bytes, seg_offsets, nseg, win, p, sink);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_hash_segments(const uint8_t* bytes, const uint64_t* seg_offsets, uint32_t nseg,
+                          uint64_t seed, uint64_t* out, hipStream_t s) {
+  if (nseg == 0) return;
+  hipLaunchKernelGGL(k_hash_segments, dim3((nseg + 255) / 256), dim3(256), 0, s, bytes, seg_offsets,
+                     nseg, seed, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
+                      hipStream_t s) {
+  if (len == 0) return;
+  if (start & 31) throw_internal("synth_dna: start must be a multiple of 32");
+  hipLaunchKernelGGL(k_synth_dna, dim3(grid_for((len + 31) / 32, 256, 8192)), dim3(256), 0, s, out,
+                     start, len, seed, n_every);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace smh

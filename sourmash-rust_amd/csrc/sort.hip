@@ -1,0 +1,322 @@
+// sort.hip -- hand-written gfx950 primitives behind the sketch "fold" step:
+//   * LSD radix sort of u64 keys (optional u64 payload), 8-bit digits, wave64 ballot ranking
+//   * run-length encoding of a sorted key array (unique keys + run starts)
+//   * segmented reductions over runs (sum of weights, min position, capped count)
+//   * single-workgroup exclusive scan used by both
+//
+// Where this sits in the reference: it is the device-side replacement for the sorted
+// Vec<u64> + binary_search + Vec::insert maintenance of KmerMinHash::add_hash
+// (reference src/lib.rs:192-245) when hashes arrive in bulk: sort + unique + count gives
+// the same `mins` / `abunds` as inserting one by one (DESIGN.md "fold").
+//
+// Wave = 64 lanes everywhere; masks are 64-bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace smh {
+
+namespace {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 16;                       // keys per thread per tile
+constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 keys per workgroup
+constexpr int kWaves = kSortThreads / 64;
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+  uint32_t lane = __lane_id();
+  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// ---------------------------------------------------------------------------------
+// all eight digit histograms in one read of the keys (decides which passes can be skipped)
+__global__ __launch_bounds__(256) void k_hist_all(const uint64_t* __restrict__ keys, size_t n,
+                                                  unsigned long long* __restrict__ ghist) {
+  __shared__ uint32_t h[8 * 256];
+  for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t k = keys[i];
+#pragma unroll
+    for (int p = 0; p < 8; p++) atomicAdd(&h[p * 256 + ((k >> (8 * p)) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x)
+    if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+}
+
+// per-workgroup histogram of one digit; layout digit-major so one scan orders everything
+__global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint64_t* __restrict__ keys,
+                                                              size_t n, int shift,
+                                                              uint32_t* __restrict__ blockhist,
+                                                              uint32_t nblocks) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int i = 0; i < kSortItems; i++) {
+    size_t idx = base + (size_t)i * kSortThreads + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255], 1u);
+  }
+  __syncthreads();
+  blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of a u32 array by ONE workgroup of 1024 threads (arrays of a few million
+// entries at most: 256 * tiles).  total (inclusive sum) goes to *total_out if given.
+__global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t* __restrict__ data, size_t m,
+                                                         uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  size_t per = (m + 1023) / 1024;
+  size_t lo = (size_t)t * per, hi = lo + per < m ? lo + per : m;
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; i++) s += data[i];
+  part[t] = s;
+  __syncthreads();
+  // Hillis-Steele over 1024 partial sums
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (size_t i = lo; i < hi; i++) {
+    uint32_t v = data[i];
+    data[i] = run;
+    run += v;
+  }
+  if (total_out && t == 1023) *total_out = part[1023];
+}
+
+// stable scatter of one digit.  Wave w of the workgroup owns the contiguous sub-tile
+// [w*1024, (w+1)*1024) of the tile and walks it 64 keys per round, so (wave, round, lane)
+// order is index order and equal digits keep their relative order.
+template <bool HasVals>
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
+    const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout, const uint64_t* __restrict__ vin,
+    uint64_t* __restrict__ vout, size_t n, int shift, const uint32_t* __restrict__ scanned,
+    uint32_t nblocks) {
+  __shared__ uint32_t wcount[kWaves][256];
+  __shared__ uint32_t woff[kWaves][256];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  for (int i = t; i < kWaves * 256; i += kSortThreads) (&wcount[0][0])[i] = 0;
+  __syncthreads();
+
+  const size_t wbase = (size_t)blockIdx.x * kSortTile + (size_t)w * (kSortItems * 64);
+  uint64_t key[kSortItems];
+  uint32_t meta[kSortItems];  // digit << 16 | rank within the wave's sub-tile
+  const uint64_t lt = lanemask_lt();
+#pragma unroll
+  for (int i = 0; i < kSortItems; i++) {
+    size_t idx = wbase + (size_t)i * 64 + lane;
+    bool active = idx < n;
+    uint64_t k = active ? kin[idx] : 0;
+    uint32_t d = (uint32_t)(k >> shift) & 255u;
+    key[i] = k;
+    // lanes holding the same digit: AND of eight ballots
+    uint64_t m = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      uint64_t bal = __ballot(active && ((d >> b) & 1));
+      m &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    uint32_t prior = wcount[w][d];
+    uint32_t below = __popcll(m & lt);
+    meta[i] = (d << 16) | (prior + below);
+    if (active && below == 0) wcount[w][d] = prior + (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  {
+    // thread d resolves digit d: base of this workgroup + counts of earlier waves
+    uint32_t run = scanned[(size_t)t * nblocks + blockIdx.x];
+#pragma unroll
+    for (int ww = 0; ww < kWaves; ww++) {
+      woff[ww][t] = run;
+      run += wcount[ww][t];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kSortItems; i++) {
+    size_t idx = wbase + (size_t)i * 64 + lane;
+    if (idx < n) {
+      uint32_t d = meta[i] >> 16, r = meta[i] & 0xFFFFu;
+      size_t o = (size_t)woff[w][d] + r;
+      kout[o] = key[i];
+      if (HasVals) vout[o] = vin[idx];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// run-length encoding of sorted keys
+constexpr int kRleThreads = 256;
+constexpr int kRleItems = 8;
+constexpr int kRleTile = kRleThreads * kRleItems;
+
+__device__ __forceinline__ bool is_head(const uint64_t* keys, size_t i) {
+  return i == 0 || keys[i] != keys[i - 1];
+}
+
+__global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __restrict__ keys,
+                                                           size_t n, uint32_t* __restrict__ bc) {
+  __shared__ uint32_t wsum[kRleThreads / 64];
+  size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < kRleItems; i++)
+    if (base + i < n && is_head(keys, base + i)) c++;
+  for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+    for (int i = 0; i < kRleThreads / 64; i++) s += wsum[i];
+    bc[blockIdx.x] = s;
+  }
+}
+
+// thread owns kRleItems consecutive keys; exclusive position of its first head inside the
+// workgroup comes from a wave scan + per-wave offsets.
+__global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __restrict__ keys,
+                                                           size_t n,
+                                                           const uint32_t* __restrict__ bscan,
+                                                           uint64_t* __restrict__ uniq,
+                                                           uint32_t* __restrict__ starts) {
+  __shared__ uint32_t wsum[kRleThreads / 64];
+  size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
+  uint32_t flags = 0, c = 0;
+#pragma unroll
+  for (int i = 0; i < kRleItems; i++)
+    if (base + i < n && is_head(keys, base + i)) { flags |= 1u << i; c++; }
+  uint32_t incl = c;
+  const int lane = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t woffs = 0;
+  for (int i = 0; i < (int)(threadIdx.x >> 6); i++) woffs += wsum[i];
+  uint32_t o = bscan[blockIdx.x] + woffs + incl - c;
+#pragma unroll
+  for (int i = 0; i < kRleItems; i++)
+    if (flags & (1u << i)) {
+      uniq[o] = keys[base + i];
+      starts[o] = (uint32_t)(base + i);
+      o++;
+    }
+}
+
+__global__ void k_set_u32(uint32_t* p, size_t idx, uint32_t v) { p[idx] = v; }
+
+// one thread per run: count, optional weight sum, optional min of the payload
+__global__ __launch_bounds__(256) void k_run_reduce(const uint32_t* __restrict__ starts,
+                                                    uint32_t nruns, uint32_t n,
+                                                    const uint64_t* __restrict__ weights,
+                                                    const uint64_t* __restrict__ pos,
+                                                    uint64_t* __restrict__ out_sum,
+                                                    uint64_t* __restrict__ out_minpos) {
+  uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nruns) return;
+  uint32_t lo = starts[u], hi = (u + 1 < nruns) ? starts[u + 1] : n;
+  if (out_sum) {
+    uint64_t s = 0;
+    if (weights) for (uint32_t i = lo; i < hi; i++) s += weights[i];
+    else s = hi - lo;
+    out_sum[u] = s;
+  }
+  if (out_minpos) {
+    uint64_t m = ~0ull;
+    for (uint32_t i = lo; i < hi; i++) m = pos[i] < m ? pos[i] : m;
+    out_minpos[u] = m;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// host drivers
+
+static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, d, m, total);
+  HIP_CHECK(hipGetLastError());
+}
+
+int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
+                   DeviceBuffer& scratch, hipStream_t s) {
+  if (n < 2) return 0;
+  if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
+  const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
+  const size_t hist_bytes = 8 * 256 * sizeof(unsigned long long);
+  const size_t bh_bytes = (size_t)256 * nblocks * sizeof(uint32_t);
+  scratch.ensure(hist_bytes + bh_bytes);
+  auto* ghist = (unsigned long long*)scratch.ptr;
+  auto* blockhist = (uint32_t*)((char*)scratch.ptr + hist_bytes);
+
+  HIP_CHECK(hipMemsetAsync(ghist, 0, hist_bytes, s));
+  int hb = (int)((n + 255) / 256);
+  if (hb > 2048) hb = 2048;
+  hipLaunchKernelGGL(k_hist_all, dim3(hb), dim3(256), 0, s, k0, n, ghist);
+  HIP_CHECK(hipGetLastError());
+  unsigned long long hh[8 * 256];
+  HIP_CHECK(hipMemcpyAsync(hh, ghist, hist_bytes, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+
+  int cur = 0;
+  uint64_t* kk[2] = {k0, k1};
+  uint64_t* vv[2] = {v0, v1};
+  for (int p = 0; p < 8; p++) {
+    bool trivial = false;
+    for (int d = 0; d < 256; d++)
+      if (hh[p * 256 + d] == n) { trivial = true; break; }
+    if (trivial) continue;  // every key has the same digit: the pass is the identity
+    hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
+                       blockhist, nblocks);
+    exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, s);
+    if (v0)
+      hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks);
+    else
+      hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
+                         kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks);
+    HIP_CHECK(hipGetLastError());
+    cur ^= 1;
+  }
+  return cur;
+}
+
+uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
+                               DeviceBuffer& scratch, hipStream_t s) {
+  if (n == 0) return 0;
+  if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
+  const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
+  scratch.ensure((size_t)(nblocks + 1) * sizeof(uint32_t));
+  auto* bc = (uint32_t*)scratch.ptr;
+  hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, n, bc);
+  exclusive_scan_u32(bc, nblocks, bc + nblocks, s);
+  hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, n, bc, uniq,
+                     starts);
+  HIP_CHECK(hipGetLastError());
+  uint32_t nruns = 0;
+  HIP_CHECK(hipMemcpyAsync(&nruns, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  return nruns;
+}
+
+void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t n, const uint64_t* weights,
+                const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos, hipStream_t s) {
+  if (nruns == 0) return;
+  hipLaunchKernelGGL(k_run_reduce, dim3((nruns + 255) / 256), dim3(256), 0, s, starts, nruns, n,
+                     weights, pos, out_sum, out_minpos);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace smh

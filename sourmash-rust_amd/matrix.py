@@ -1,0 +1,64 @@
+"""All-vs-all comparison (the N x N matrix the north star names): the reference has no matrix
+entry point -- it is N^2 independent calls of KmerMinHash::compare (src/lib.rs:501-508), see
+SURVEY.md 3.4.  Here: one device launch per block through the additive C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import f64p, lib, u64p
+from .errors import call
+
+
+def compare_block(rows, cols, want=("jaccard",)):
+    """rows/cols: lists of KmerMinHash.  Returns dict name -> (len(rows), len(cols)) array.
+    names: jaccard, common, size, count_common, containment."""
+    n, m = len(rows), len(cols)
+    out = {}
+    bufs = {"jaccard": np.float64, "common": np.uint64, "size": np.uint64, "count_common": np.uint64,
+            "containment": np.float64}
+    for k in want:
+        out[k] = np.zeros((n, m), dtype=bufs[k])
+
+    def ptr(name):
+        if name not in out:
+            return None
+        return out[name].ctypes.data_as(f64p if out[name].dtype == np.float64 else u64p)
+
+    R = (C.c_void_p * max(n, 1))(*[r._p for r in rows])
+    Cc = (C.c_void_p * max(m, 1))(*[c._p for c in cols])
+    call(lib().smh_compare_block, R, n, Cc, m, ptr("jaccard"), ptr("common"), ptr("size"), ptr("count_common"),
+         ptr("containment"))
+    return out
+
+
+def csr_from_sketches(sketches):
+    """list of ascending uint64 arrays -> (flat uint64 array, uint64 offsets)."""
+    off = np.zeros(len(sketches) + 1, dtype=np.uint64)
+    for i, s in enumerate(sketches):
+        off[i + 1] = off[i] + len(s)
+    flat = np.concatenate([np.asarray(s, dtype=np.uint64) for s in sketches]) if sketches else np.zeros(0, np.uint64)
+    return np.ascontiguousarray(flat), off
+
+
+def compare_block_dev(row_hashes, row_offsets, col_hashes, col_offsets, num, want=("jaccard",), stream=None):
+    """Device-resident CSR sketches (torch uint64/int64 CUDA tensors) -> dict of CUDA tensors.
+    torch is only the allocator here; the work is the library's HIP kernel."""
+    import torch
+    n, m = len(row_offsets) - 1, len(col_offsets) - 1
+    dev = row_hashes.device
+    outs = {}
+    for k in want:
+        dt = torch.float64 if k in ("jaccard", "containment") else torch.int64
+        outs[k] = torch.empty((n, m), dtype=dt, device=dev)
+
+    def p(name):
+        return C.c_void_p(outs[name].data_ptr()) if name in outs else C.c_void_p(0)
+
+    ro = np.ascontiguousarray(row_offsets, dtype=np.uint64)
+    co = np.ascontiguousarray(col_offsets, dtype=np.uint64)
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    call(lib().smh_compare_block_dev, C.c_void_p(row_hashes.data_ptr()), ro.ctypes.data_as(u64p), n,
+         C.c_void_p(col_hashes.data_ptr()), co.ctypes.data_as(u64p), m, num,
+         p("jaccard"), p("common"), p("size"), p("count_common"), p("containment"), C.c_void_p(stream))
+    return outs

@@ -1,0 +1,73 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    names = set()
+    for hdr in ("sourmash.h", "sourmash_amd.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(", text):
+            n = m.group(1)
+            if n.startswith(("kmerminhash_", "signature", "sourmash_", "smh_", "hash_murmur")):
+                names.add(n)
+    return names
+
+
+def test_reference_abi_is_complete():
+    # the 48 symbols of the reference header
+    ref = [n for n in declared_symbols() if not n.startswith("smh_")]
+    assert len(ref) == 48
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.SO_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = declared_symbols() - exported
+    assert not missing, missing
+    assert declared_symbols() == set(pkg.exported_symbols())
+
+
+def test_loads_and_scalar_calls_work_without_gpu(pkg):
+    L = pkg.lib()
+    mh = pkg.KmerMinHash(3, 21, False, 42, 0, True)
+    for h in (5, 3, 9, 3, 1):
+        mh.add_hash(h)
+    assert mh.mins == [1, 3, 5] and mh.abunds == [1, 2, 1]
+    assert (mh.num, mh.ksize, mh.is_protein, mh.seed, mh.max_hash, mh.track_abundance) == (3, 21, False, 42, 0, True)
+    assert L.sourmash_err_get_last_code() == 0
+
+
+def test_compute_fails_loudly_without_gpu(pkg):
+    if pkg.device_available():
+        pytest.skip("a GPU is present")
+    mh = pkg.KmerMinHash(20, 10)
+    with pytest.raises(pkg.SourmashError) as ei:
+        mh.add_sequence(b"TGCCGCCCAGCA")
+    assert ei.value.code == 2 and "no HIP device" in ei.value.message
+    assert len(mh) == 0
+    with pytest.raises(pkg.SourmashError):
+        pkg.hash_murmur(b"ACG")
+    with pytest.raises(pkg.SourmashError):
+        mh.compare(pkg.KmerMinHash(20, 10))
+
+
+def test_product_does_not_reference_the_oracle():
+    # the product path may not import, include, link or execute anything under oracle/
+    pkgdir = os.path.join(ROOT, "sourmash-rust_amd")
+    bad = re.compile(r"(import\s+(coracle|pyoracle)|from\s+oracle|#include\s+[\"<][^\">]*oracle|liboracle|"
+                     r"oracle/(_build|_ref)|sourmash_oracle|omh_[a-z_]+\()")
+    for dirpath, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not bad.search(text), os.path.join(dirpath, f)
+    out = subprocess.check_output(["ldd", os.path.join(pkgdir, "lib", "libsourmash_amd.so")], text=True)
+    assert "oracle" not in out

@@ -1,0 +1,102 @@
+"""GPU parity: compare / intersection_size / count_common / containment through the C ABI vs the
+oracle and the committed golden matrices, bit-exact (the f64 results are quotients of exactly
+representable integers: equality, not tolerance)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def mh_from_sketch(M, sk):
+    mh = M(0 if sk["max_hash"] else sk["num"], sk["ksize"], sk["molecule"] == "protein", sk["seed"],
+           sk["max_hash"], "abundances" in sk)
+    for m in sk["mins"]:
+        mh.mins_push(m)
+    for a in sk.get("abundances", []):
+        mh.abunds_push(a)
+    return mh
+
+
+def test_sbt_v5_hit_counts(pkg, sbt_v5_leaves):
+    # reference src/index/sbt.rs:543-589 through kmerminhash_compare / containment
+    mhs = {pos: mh_from_sketch(pkg.KmerMinHash, sk) for pos, sk in sbt_v5_leaves.items()}
+    q = mhs[7]
+    sims = [mh.compare(q) for mh in mhs.values()]
+    cont = [mh.containment(q) for mh in mhs.values()]
+    assert sum(v > 0.5 for v in sims) == 1 and sum(v > 0.1 for v in sims) == 2
+    assert sum(v > 0.5 for v in cont) == 2 and sum(v > 0.1 for v in cont) == 4
+
+
+@pytest.mark.parametrize("tag", ["v5", "subset"])
+def test_golden_matrices(tag, pkg, sbt_v5_leaves, sbt_subset_sketches):
+    mats = np.load(os.path.join(GOLDEN, "golden_matrices.npz"))
+    sks = [sbt_v5_leaves[k] for k in sorted(sbt_v5_leaves)] if tag == "v5" else sbt_subset_sketches
+    mhs = [mh_from_sketch(pkg.KmerMinHash, s) for s in sks]
+    out = pkg.matrix.compare_block(mhs, mhs, want=("jaccard", "common", "size", "count_common", "containment"))
+    assert (out["common"] == mats[tag + "_common"]).all()
+    assert (out["size"] == mats[tag + "_size"]).all()
+    assert (out["jaccard"] == mats[tag + "_jaccard"]).all()
+    assert (out["count_common"] == mats[tag + "_count_common"]).all()
+    lens = np.array([len(s["mins"]) for s in sks], dtype=np.float64)
+    assert (out["containment"] == mats[tag + "_count_common"].astype(np.float64) / lens[:, None]).all()
+
+
+def test_random_pairs_all_modes(pkg, coracle):
+    rng = random.Random(21)
+    for trial in range(60):
+        num_a = rng.choice([0, 1, 5, 20, 50, 2000])
+        num_b = num_a if rng.random() < 0.6 or num_a == 0 else rng.choice([1, 7, 30])  # H6: nums may differ
+        mx = 0 if num_a else 1 << 62
+        universe = [rng.getrandbits(62) for _ in range(rng.choice([10, 80, 5000]))]
+        ga, oa = pkg.KmerMinHash(num_a, 21, False, 42, mx), coracle.MinHash(num_a, 21, False, 42, mx)
+        gb, ob = pkg.KmerMinHash(num_b, 21, False, 42, mx), coracle.MinHash(num_b, 21, False, 42, mx)
+        for h in rng.choices(universe, k=rng.choice([0, 1, 30, 3000])):
+            ga.add_hash(h); oa.add_hash(h)
+        for h in rng.choices(universe, k=rng.choice([0, 1, 30, 3000])):
+            gb.add_hash(h); ob.add_hash(h)
+        assert ga.count_common(gb) == oa.count_common(ob)
+        assert ga.intersection_size(gb) == oa.intersection_size(ob)
+        assert gb.intersection_size(ga) == ob.intersection_size(oa)
+        assert ga.compare(gb) == oa.compare(ob) and gb.compare(ga) == ob.compare(oa)
+        assert ga.intersection(gb) == oa.intersection_size(ob)[1]
+        c = ga.containment(gb)
+        if len(oa.mins):
+            assert c == oa.containment(ob)
+        else:
+            assert c != c  # 0/0 = NaN like the reference
+
+
+def test_large_sketches_not_in_lds(pkg, coracle):
+    rng = np.random.RandomState(3)
+    pool = np.unique(rng.randint(0, 1 << 62, size=60000, dtype=np.int64).astype(np.uint64))
+    a = np.sort(rng.choice(pool, 20000, replace=False))
+    b = np.sort(rng.choice(pool, 25000, replace=False))
+    ga, gb = pkg.KmerMinHash(0, 21, False, 42, 1 << 62), pkg.KmerMinHash(0, 21, False, 42, 1 << 62)
+    ga.add_many(a); gb.add_many(b)
+    exp = len(np.intersect1d(a, b))
+    assert ga.count_common(gb) == exp
+    assert ga.intersection_size(gb) == (exp, len(a) + len(b) - exp)
+
+
+def test_device_csr_block(pkg, coracle):
+    import torch
+    rng = np.random.RandomState(5)
+    pool = np.unique(rng.randint(0, 1 << 62, size=3000, dtype=np.int64).astype(np.uint64))
+    rows = [np.sort(rng.choice(pool, rng.choice([0, 10, 500, 500, 500]), replace=False)) for _ in range(37)]
+    cols = [np.sort(rng.choice(pool, rng.choice([1, 500, 500, 700]), replace=False)) for _ in range(53)]
+    for num in (0, 500, 64):
+        common, size, jac = coracle.compare_matrix(rows, cols, num, 31, 0 if num else 1 << 62)
+        rf, ro = pkg.matrix.csr_from_sketches(rows)
+        cf, co = pkg.matrix.csr_from_sketches(cols)
+        rt = torch.from_numpy(rf.view(np.int64)).cuda()
+        ct = torch.from_numpy(cf.view(np.int64)).cuda()
+        out = pkg.matrix.compare_block_dev(rt, ro, ct, co, num, want=("jaccard", "common", "size", "count_common"))
+        torch.cuda.synchronize()
+        assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
+        assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
+        assert (out["jaccard"].cpu().numpy() == jac).all()

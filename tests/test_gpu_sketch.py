@@ -1,0 +1,286 @@
+"""GPU parity: KmerMinHash::add_sequence through the C ABI vs the oracle, bit-exact.
+
+Covers the reference's own KATs, the committed golden vectors, and seeded random inputs over the
+edge cases the reference handles: lowercase, invalid bytes with force on/off (partial state +
+error k-mer), length < k / == k, every sketch mode (num, scaled, both, neither), abundance quirk
+Q3, multi-call accumulation, k <= 32 (rolling kernel) and k > 32 (byte-wise kernel), the protein
+arm with dropped codons, many records per launch, and device-resident input."""
+import gzip
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+MERGE_MINS = [
+    2996412506971915891, 4448613756639084635, 8373222269469409550, 9390240264282449587,
+    11085758717695534616, 11668188995231815419, 11760449009842383350, 14682565545778736889,
+]
+
+
+def same_state(g, o):
+    assert g.mins == o.mins
+    assert g.abunds == o.abunds
+
+
+def test_reference_kats(pkg):
+    assert pkg.hash_murmur(b"ACG", 42) == 1731421407650554201          # tests/test.rs:5
+    mh = pkg.KmerMinHash(1, 4)
+    with pytest.raises(pkg.SourmashError) as ei:                          # tests/minhash.rs:5-17
+        mh.add_sequence(b"ATGR", False)
+    assert ei.value.code == 1101 and ei.value.message == "invalid DNA character in input k-mer: ATGR"
+    a, b = pkg.KmerMinHash(20, 10), pkg.KmerMinHash(20, 10)              # tests/minhash.rs:19-52
+    a.add_sequence(b"TGCCGCCCAGCA"); b.add_sequence(b"TGCCGCCCAGCA")
+    a.add_sequence(b"GTCCGCCCAGTGA"); b.add_sequence(b"GTCCGCCCAGTGG")
+    a.merge(b)
+    assert a.mins == MERGE_MINS
+    s1 = b"TGCCGCCCAGCACCGGGTGACTAGGTTGAGCCATGATTAACCTGCAATGA"           # tests/minhash.rs:54-83
+    s2 = b"GATTGGTGCACACTTAACTGGGTGCCGCGCTGGTGCTGATCCATGAAGTT"
+    a, b = pkg.KmerMinHash(20, 10), pkg.KmerMinHash(20, 10)
+    a.add_sequence(s1); b.add_sequence(s1)
+    assert a.compare(b) == 1.0 and b.compare(a) == 1.0
+    b.add_sequence(s1)
+    assert a.compare(b) == 1.0 and b.compare(a) == 1.0
+    b.add_sequence(s2)
+    assert a.compare(b) >= 0.3 and b.compare(a) >= 0.3
+
+
+def test_hash_words(pkg, coracle):
+    rng = random.Random(1)
+    words = [bytes(rng.getrandbits(8) | 1 for _ in range(n)) for n in list(range(0, 40)) + [63, 64, 65, 200]]
+    got = pkg.hash_words(words, 42)
+    assert [int(x) for x in got] == [coracle.hash_murmur(w, 42) for w in words]
+    big_seed = (1 << 40) + 12345
+    assert int(pkg.hash_words([b"ACGTACGT"], big_seed)[0]) == coracle.hash_murmur(b"ACGTACGT", big_seed)
+    mh, o = pkg.KmerMinHash(5, 3), coracle.MinHash(5, 3)
+    for w in (b"AAA", b"ACG", b"TTT", b"whatever"):
+        mh.add_word(w); o.add_word(w)
+    same_state(mh, o)
+
+
+def golden():
+    with gzip.open(os.path.join(GOLDEN, "golden_vectors.json.gz"), "rt") as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("name", sorted(golden()["sketch"]))
+def test_golden_vectors(name, pkg, coracle):
+    g = golden()["sketch"][name]
+    mh = pkg.KmerMinHash(*g["params"])
+    mh.add_sequence(bytes(coracle.synth_dna(*g["synth"])), g["force"])
+    assert mh.mins == g["mins"] and mh.abunds == g["abunds"]
+
+
+ALPH = b"ACGTacgtNnRXY*-"
+
+
+def rand_seq(rng, n, bad=0.02):
+    out = bytearray()
+    for _ in range(n):
+        if rng.random() < bad:
+            out.append(rng.choice(ALPH))
+        else:
+            out.append(rng.choice(b"ACGT" if rng.random() < 0.9 else b"acgt"))
+    return bytes(out)
+
+
+CASES = [
+    # num, ksize, prot, seed, max_hash, track
+    (20, 10, False, 42, 0, False),
+    (20, 10, False, 42, 0, True),
+    (5, 4, False, 42, 0, True),
+    (0, 7, False, 42, 1 << 61, True),
+    (0, 21, False, 42, 1 << 58, False),
+    (8, 5, False, 7, 1 << 62, True),           # Q4: num and max_hash both set (order-dependent)
+    (0, 6, False, 42, 0, True),                # neither set (order-dependent)
+    (500, 31, False, 42, 0, False),
+    (100, 31, False, 42, 0, True),
+    (50, 32, False, 42, 0, True),
+    (50, 1, False, 42, 0, True),
+    (64, 16, False, 42, 0, True),
+    (64, 17, False, 9, 0, False),
+    (30, 33, False, 42, 0, True),              # byte-wise kernel
+    (30, 51, False, 42, 0, True),
+    (0, 51, False, 42, 1 << 60, True),
+    (50, 9, True, 42, 0, True),
+    (0, 27, True, 42, 1 << 60, True),
+    (30, 12, True, (1 << 40) + 5, 0, False),
+    (40, 21, False, (1 << 40) + 5, 0, False),  # seed >= 2^32 (Q10)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_add_sequence_random(case, pkg, coracle):
+    rng = random.Random(hash(case) & 0xFFFF)
+    k = case[1]
+    for trial in range(5):
+        g = pkg.KmerMinHash(*case)
+        o = coracle.MinHash(*case)
+        for _ in range(rng.randint(1, 3)):
+            n = rng.choice([0, 1, k - 1, k, k + 1, 40, 200, 3000, 20000])
+            seq = rand_seq(rng, max(0, n), bad=rng.choice([0.0, 0.0, 0.01]))
+            force = rng.random() < 0.5
+            eg = eo = None
+            try:
+                g.add_sequence(seq, force)
+            except pkg.SourmashError as e:
+                eg = (e.code, e.message.split(": ")[-1] if e.code == 1101 else "")
+            try:
+                o.add_sequence(seq, force)
+            except coracle.OracleError as e:
+                eo = (e.code, e.message if e.code == 1101 else "")
+            assert eg == eo
+            same_state(g, o)
+
+
+def test_few_distinct_kmers_abundance(pkg, coracle):
+    # heavy repetition: the abundance closed form (Q3) against one-by-one insertion
+    rng = random.Random(5)
+    for num, mx in [(3, 0), (6, 0), (40, 0), (0, 1 << 63), (4, 1 << 63)]:
+        g = pkg.KmerMinHash(num, 3, False, 42, mx, True)
+        o = coracle.MinHash(num, 3, False, 42, mx, True)
+        for _ in range(12):
+            seq = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([3, 10, 30, 500, 70000])))
+            g.add_sequence(seq, True); o.add_sequence(seq, True)
+            same_state(g, o)
+
+
+def test_num_mode_multi_chunk_abundance(pkg, coracle):
+    # longer than the first num-mode chunk, so thresholds and T* cross chunk boundaries
+    for num, k, track in [(50, 12, True), (500, 31, True), (2000, 21, False)]:
+        seq = bytes(coracle.synth_dna(0, 400000, 11 + num, 0))
+        seq = seq[:150000] + seq[:100000] + seq[150000:]   # repeats across chunks
+        g = pkg.KmerMinHash(num, k, False, 42, 0, track)
+        o = coracle.MinHash(num, k, False, 42, 0, track)
+        g.add_sequence(seq, True); o.add_sequence(seq, True)
+        same_state(g, o)
+        g.add_sequence(seq[1000:90000], True); o.add_sequence(seq[1000:90000], True)
+        same_state(g, o)
+
+
+def test_c1_config_sketch_and_self_compare(pkg, coracle):
+    # BASELINE config 0: 1 MB DNA, k=31, num=500, compare to itself -> 1.0
+    seq = bytes(coracle.synth_dna(0, 1000000, 1, 0))
+    g = pkg.KmerMinHash(500, 31)
+    o = coracle.MinHash(500, 31)
+    g.add_sequence(seq); o.add_sequence(seq)
+    same_state(g, o)
+    assert g.compare(g) == 1.0 and g.count_common(g) == 500
+
+
+def test_nul_bytes_and_high_bytes(pkg, coracle):
+    seq = b"ACGTACGTAC\x00ACGTTTGACA\xffGGGATCCAT\xc3\xa9ACGATCGATTTTACG"
+    for force in (True, False):
+        for case in [(10, 5, False, 42, 0, True), (10, 6, True, 42, 0, True)]:
+            g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+            eg = eo = None
+            try:
+                g.add_sequence(seq, force)
+            except pkg.SourmashError as e:
+                eg = e.code
+            try:
+                o.add_sequence(seq, force)
+            except coracle.OracleError as e:
+                eo = e.code
+            assert eg == eo
+            same_state(g, o)
+
+
+def test_protein_dropped_codons(pkg, coracle):
+    rng = random.Random(8)
+    for trial in range(6):
+        seq = bytearray(rand_seq(rng, rng.choice([30, 100, 1000, 30000]), bad=0.0))
+        for _ in range(rng.randint(0, 6)):     # runs of N splice residues together (Q8)
+            p = rng.randrange(len(seq))
+            seq[p:p + rng.randint(1, 12)] = b"N" * rng.randint(1, 12)
+        for case in [(40, 21, True, 42, 0, True), (0, 30, True, 42, 1 << 61, True), (30, 3, True, 42, 0, False)]:
+            g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+            g.add_sequence(bytes(seq), True); o.add_sequence(bytes(seq), True)
+            same_state(g, o)
+
+
+def test_many_records_per_launch(pkg, coracle):
+    rng = random.Random(13)
+    recs = [rand_seq(rng, rng.choice([0, 5, 30, 31, 32, 100, 151, 151, 151, 2000]), bad=rng.choice([0, 0, 0.01]))
+            for _ in range(300)]
+    for case in [(500, 31, False, 42, 0, True), (0, 21, False, 42, 1 << 59, True), (60, 15, True, 42, 0, True),
+                 (0, 40, False, 42, 1 << 60, False)]:
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        g.add_sequences(recs, True)
+        for r in recs:
+            o.add_sequence(r, True)
+        same_state(g, o)
+    # force=False: every record is processed up to its first bad window, the first error is reported
+    g, o = pkg.KmerMinHash(100, 21, False, 42, 0, True), coracle.MinHash(100, 21, False, 42, 0, True)
+    first = None
+    for r in recs:
+        try:
+            o.add_sequence(r, False)
+        except coracle.OracleError as e:
+            first = first or e.message
+    with pytest.raises(pkg.SourmashError) as ei:
+        g.add_sequences(recs, False)
+    assert ei.value.code == 1101 and ei.value.message.endswith(first)
+    same_state(g, o)
+
+
+def test_device_resident_input_and_generator(pkg, coracle):
+    import ctypes as C
+    import torch
+    n = 3_000_000
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    pkg.lib().smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 64, n, 2, 100000, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    host = bytes(coracle.synth_dna(64, n, 2, 100000))
+    assert bytes(buf.cpu().numpy()) == host
+    offs = [0, 1_000_000, 1_000_000, 2_500_000, n]
+    for case in [(0, 31, False, 42, 18446744073709552, True), (500, 31, False, 42, 0, False)]:
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        g.add_sequences_dev(buf.data_ptr(), n, offs, True, torch.cuda.current_stream().cuda_stream)
+        for a, b in zip(offs[:-1], offs[1:]):
+            o.add_sequence(host[a:b], True)
+        same_state(g, o)
+    # an unaligned device pointer (slice) must work too
+    g, o = pkg.KmerMinHash(0, 31, False, 42, 18446744073709552, True), coracle.MinHash(0, 31, False, 42, 18446744073709552, True)
+    g.add_sequences_dev(buf.data_ptr() + 7, 500_001, [0, 500_001], True)
+    o.add_sequence(host[7:500_008], True)
+    same_state(g, o)
+
+
+def test_full_size_properties(pkg, coracle):
+    """Size-independent checks at a size the oracle cannot finish quickly (256 MB): chunking is
+    exact (sketching two halves with k-1 overlap and merging == sketching the whole) and the
+    abundance total equals the number of retained k-mer occurrences."""
+    import ctypes as C
+    import torch
+    n = 256 * 1024 * 1024
+    mx = 18446744073709552
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    pkg.lib().smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, n, 2, 0, C.c_void_p(0))
+    torch.cuda.synchronize()
+    whole = pkg.KmerMinHash(0, 31, False, 42, mx, True)
+    whole.add_sequences_dev(buf.data_ptr(), n, [0, n], True)
+    half = n // 2
+    a = pkg.KmerMinHash(0, 31, False, 42, mx, True)
+    b = pkg.KmerMinHash(0, 31, False, 42, mx, True)
+    a.add_sequences_dev(buf.data_ptr(), half + 30, [0, half + 30], True)
+    b.add_sequences_dev(buf.data_ptr() + half, n - half, [0, n - half], True)
+    a.merge(b)
+    assert (a.mins_np() == whole.mins_np()).all() and (a.abunds_np() == whole.abunds_np()).all()
+    m = whole.mins_np()
+    assert (m[1:] > m[:-1]).all() and m[-1] <= mx
+    # expected retained fraction 1/1000 of n-30 windows (binomial, 6 sigma)
+    tot = int(whole.abunds_np().sum())
+    exp = (n - 30) / 1000.0
+    assert abs(tot - exp) < 6 * exp ** 0.5
+    # the first 2 MB agree with the oracle exactly
+    o = coracle.MinHash(0, 31, False, 42, mx, True)
+    o.add_sequence(bytes(coracle.synth_dna(0, 2_000_000, 2, 0)), True)
+    g = pkg.KmerMinHash(0, 31, False, 42, mx, True)
+    g.add_sequences_dev(buf.data_ptr(), 2_000_000, [0, 2_000_000], True)
+    same_state(g, o)
