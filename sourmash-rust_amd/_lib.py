@@ -96,6 +96,25 @@ _SIGS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process do not coexist, so when torch is installed its copy is mapped first
+    and libsourmash_amd.so's NEEDED libamdhip64.so.7 resolves to it; a later `import torch`
+    then finds the same object.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    if os.environ.get("SOURMASH_AMD_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -103,6 +122,7 @@ def lib():
             raise ImportError(
                 "libsourmash_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C sourmash-rust_amd/csrc`; there is no pure-Python or CPU fallback." % SO_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)  # AttributeError here = the library does not export the ABI

@@ -77,8 +77,10 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
                                DeviceBuffer& scratch, hipStream_t s);
-void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t n, const uint64_t* weights,
-                const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos, hipStream_t s);
+// reduces the first `nruns` of `total_runs` runs (run u ends at starts[u+1], the last one at n)
+void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t total_runs, uint32_t n,
+                const uint64_t* weights, const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos,
+                hipStream_t s);
 
 // --- compare_kernels.hip ---------------------------------------------------------------
 // Sketches as CSR: hashes[offsets[i] .. offsets[i+1]) ascending and unique.

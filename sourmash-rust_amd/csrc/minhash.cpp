@@ -218,8 +218,8 @@ void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_mi
   HIP_CHECK(hipMemcpyAsync(out->run_start.data(), starts.ptr, (size_t)fetch * 4, hipMemcpyDeviceToHost, s));
   if (want_minpos && have_pos && kept) {
     red_b.ensure((size_t)kept * 8);
-    run_reduce(starts.as<uint32_t>(), kept, kept < nruns ? 0xffffffffu : (uint32_t)n, nullptr,
-               cand_pos[cur].as<uint64_t>(), nullptr, red_b.as<uint64_t>(), s);
+    run_reduce(starts.as<uint32_t>(), kept, nruns, (uint32_t)n, nullptr, cand_pos[cur].as<uint64_t>(), nullptr,
+               red_b.as<uint64_t>(), s);
     out->minpos.resize(kept);
     HIP_CHECK(hipMemcpyAsync(out->minpos.data(), red_b.ptr, (size_t)kept * 8, hipMemcpyDeviceToHost, s));
   }

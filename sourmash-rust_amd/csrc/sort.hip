@@ -219,14 +219,14 @@ __global__ void k_set_u32(uint32_t* p, size_t idx, uint32_t v) { p[idx] = v; }
 
 // one thread per run: count, optional weight sum, optional min of the payload
 __global__ __launch_bounds__(256) void k_run_reduce(const uint32_t* __restrict__ starts,
-                                                    uint32_t nruns, uint32_t n,
+                                                    uint32_t nruns, uint32_t total_runs, uint32_t n,
                                                     const uint64_t* __restrict__ weights,
                                                     const uint64_t* __restrict__ pos,
                                                     uint64_t* __restrict__ out_sum,
                                                     uint64_t* __restrict__ out_minpos) {
   uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= nruns) return;
-  uint32_t lo = starts[u], hi = (u + 1 < nruns) ? starts[u + 1] : n;
+  uint32_t lo = starts[u], hi = (u + 1 < total_runs) ? starts[u + 1] : n;
   if (out_sum) {
     uint64_t s = 0;
     if (weights) for (uint32_t i = lo; i < hi; i++) s += weights[i];
@@ -311,11 +311,12 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   return nruns;
 }
 
-void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t n, const uint64_t* weights,
-                const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos, hipStream_t s) {
+void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t total_runs, uint32_t n,
+                const uint64_t* weights, const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos,
+                hipStream_t s) {
   if (nruns == 0) return;
-  hipLaunchKernelGGL(k_run_reduce, dim3((nruns + 255) / 256), dim3(256), 0, s, starts, nruns, n,
-                     weights, pos, out_sum, out_minpos);
+  hipLaunchKernelGGL(k_run_reduce, dim3((nruns + 255) / 256), dim3(256), 0, s, starts, nruns, total_runs,
+                     n, weights, pos, out_sum, out_minpos);
   HIP_CHECK(hipGetLastError());
 }
 

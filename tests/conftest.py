@@ -55,7 +55,19 @@ def sbt_subset_sketches():
     """First sketch of each of the 100 leaf signatures of tests/data/.sbt.subset (k=21, scaled, abund)."""
     with gzip.open(os.path.join(GOLDEN, "sbt_subset_sigs.json.gz"), "rt") as fh:
         d = json.load(fh)
-    return [d[k][0]["signatures"][0] for k in sorted(d)]
+    return [sorted_sketch(d[k][0]["signatures"][0]) for k in sorted(d)]
+
+
+def sorted_sketch(sk):
+    """The .sbt.subset fixture files store `mins` in arbitrary order (written by an old Python
+    sourmash); KmerMinHash's invariant is ascending mins, which is what every
+    comparison assumes, so the fixture is put in that order (abundances permuted alike)."""
+    order = sorted(range(len(sk["mins"])), key=lambda i: sk["mins"][i])
+    out = dict(sk)
+    out["mins"] = [sk["mins"][i] for i in order]
+    if "abundances" in sk:
+        out["abundances"] = [sk["abundances"][i] for i in order]
+    return out
 
 
 @pytest.fixture(scope="session")
