@@ -240,8 +240,16 @@ Mode mode_of(const KmerMinHash& mh) {
 
 // scaled mode (num == 0, max_hash > 0): set union, counts add up (reference add_hash with
 // `hash <= max_hash` always true: insert or increment, never pop)
-void apply_scaled(KmerMinHash& mh, const Delta& d) {
+void apply_scaled(KmerMinHash& mh, Delta& d) {
   if (d.uniq.empty()) return;
+  if (mh.mins.empty()) {
+    mh.mins.swap(d.uniq);
+    if (mh.has_abunds) {
+      mh.abunds.resize(mh.mins.size());
+      for (size_t k = 0; k < mh.mins.size(); k++) mh.abunds[k] = d.run_start[k + 1] - d.run_start[k];
+    }
+    return;
+  }
   std::vector<uint64_t> nm, na;
   nm.reserve(mh.mins.size() + d.uniq.size());
   if (mh.has_abunds) na.reserve(nm.capacity());
@@ -332,7 +340,11 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
   const Mode mode = mode_of(mh);
 
   if (mode == kScaled) {
-    const uint64_t CH = 1ull << 30;
+    // one launch over as many positions as keep the expected candidate count under 2^30: the
+    // whole 10 GB benchmark batch is a single launch + a single sort + a single merge
+    long double frac = ((long double)mh.max_hash + 1.0L) / 18446744073709551616.0L;
+    long double span_ld = (long double)(1ull << 30) / frac;
+    const uint64_t CH = span_ld > 4.0e12L ? (uint64_t)4e12 : (span_ld < 16777216.0L ? (1ull << 24) : (uint64_t)span_ld);
     for (uint64_t lo = 0; lo < P; lo += CH) {
       const uint64_t hi = std::min(P, lo + CH);
       const uint64_t n = E.run_chunk(&src, lo, hi, mh.max_hash, false, s);

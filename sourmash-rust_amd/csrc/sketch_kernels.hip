@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "device.hpp"
 #include "kernels.hpp"
 
@@ -100,34 +103,61 @@ __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <=
 
 // ---------------------------------------------------------------------------------
 // DNA arm, rolling 2-bit windows, ksize <= 32
-constexpr int kDnaThreads = 256;
 constexpr int kLutReplicas = 16;                 // lane l uses replica l & 15: at most 2-way conflicts
 constexpr int kLutDwords = 256 * kLutReplicas;   // 16 KiB
 
-// KT > 0: ksize fixed at compile time; KT == 0: any ksize in 1..32 at run time.
+// murmur64 of a k-mer given as eight little-endian dwords (bytes beyond K are zero)
 template <int KT>
-__global__ __launch_bounds__(kDnaThreads) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
-                                                             int logR) {
+__device__ __forceinline__ uint64_t murmur_kmer(const uint32_t (&D)[8], int K, uint64_t seed) {
+  const uint64_t w0 = D[0] | ((uint64_t)D[1] << 32), w1 = D[2] | ((uint64_t)D[3] << 32);
+  const uint64_t w2 = D[4] | ((uint64_t)D[5] << 32), w3 = D[6] | ((uint64_t)D[7] << 32);
+  uint64_t h1 = seed, h2 = seed;
+  if (K >= 16) {
+    mm3_block(h1, h2, w0, w1);
+    if (K == 32) mm3_block(h1, h2, w2, w3);
+    else {
+      if (K > 24) h2 ^= mix_k2(w3);
+      if (K > 16) h1 ^= mix_k1(w2);
+    }
+  } else {
+    if (K > 8) h2 ^= mix_k2(w1);
+    h1 ^= mix_k1(w0);
+  }
+  return mm3_finish(h1, h2, (uint64_t)K);
+}
+
+// KT > 0: ksize fixed at compile time; KT == 0: any ksize in 1..32 at run time.
+// THREADS lanes per workgroup share one LUT; HB = hashes computed together in one straight-line
+// block (independent murmur chains the scheduler can interleave).
+template <int KT, int THREADS, int HB>
+__global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
+                                                         int logR, uint32_t stage_cap) {
+  // LDS: [LUT 16 KiB][staged candidates: count, hashes, positions][sequence tile]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* lut = smem;
-  uint32_t* tile = smem + kLutDwords;
+  uint32_t* st_ctl = smem + kLutDwords;                       // [0] = count, [2..3] = flush base
+  uint64_t* st_hash = reinterpret_cast<uint64_t*>(st_ctl + 4);
+  uint64_t* st_pos = st_hash + stage_cap;
+  uint32_t* tile = reinterpret_cast<uint32_t*>(st_pos + (sink.pos ? stage_cap : 0));
 
   const int K = KT ? KT : (int)hp.ksize;
   const int tid = threadIdx.x;
   const uint32_t R = 1u << logR;
-  const uint64_t TILE = (uint64_t)kDnaThreads << logR;
+  const uint64_t TILE = (uint64_t)THREADS << logR;
   const uint64_t MASK = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
+  const uint32_t MASK_LO = (uint32_t)MASK, MASK_HI = (uint32_t)(MASK >> 32);
   const int top_shift = 2 * K - 2;
   const bool multi = b.starts != nullptr;
 
   // 4 two-bit digits -> 4 ASCII bytes, digit d -> "ACGT"[d], first digit in the low byte
-  for (int e = tid; e < kLutDwords; e += kDnaThreads) {
+  for (int e = tid; e < kLutDwords; e += THREADS) {
     uint32_t idx = (uint32_t)e >> 4, v = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
     lut[e] = v;
   }
   const uint32_t lut_lane = (uint32_t)(tid & (kLutReplicas - 1)) << 2;  // byte offset of my replica
+  if (tid == 0) st_ctl[0] = 0;
 
   const uint64_t span = hp.range_hi - hp.range_lo;
   const uint64_t ntiles = (span + TILE - 1) / TILE;
@@ -144,7 +174,7 @@ __global__ __launch_bounds__(kDnaThreads) void k_dna_rolling(SeqBatch b, HashPar
     const uint32_t m = (uint32_t)(g0 - ga);
     const uint32_t nchunks = (m + (uint32_t)TILE + 40 + 15) >> 4;  // K <= 32: last lane reads < m+TILE+38
     __syncthreads();  // LUT ready / previous tile fully consumed
-    for (uint32_t c = tid; c < nchunks; c += kDnaThreads) {
+    for (uint32_t c = tid; c < nchunks; c += THREADS) {
       uintptr_t addr = ga + ((uintptr_t)c << 4);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (addr < gend) v = *reinterpret_cast<const uint4*>(addr);
@@ -155,7 +185,7 @@ __global__ __launch_bounds__(kDnaThreads) void k_dna_rolling(SeqBatch b, HashPar
     __syncthreads();
 
     const uint64_t p0 = T0 + ((uint64_t)tid << logR);  // my first k-mer start position
-    if (p0 >= hp.range_hi) continue;                   // no barrier below this point in the tile
+    if (p0 < hp.range_hi) {
     const uint32_t nk = (hp.range_hi - p0) < R ? (uint32_t)(hp.range_hi - p0) : R;
 
     // record bookkeeping: `lim` = index of the first base of my run that is not inside the
@@ -172,8 +202,9 @@ __global__ __launch_bounds__(kDnaThreads) void k_dna_rolling(SeqBatch b, HashPar
     uint32_t x = (m & ~3u) + ((uint32_t)tid << logR);
     const uint32_t sh = m & 3u;
     uint32_t cur = tile[(x >> 2) + (x >> logR)];
-    uint64_t fbe = 0, fle = 0;  // forward k-mer, first base most / least significant
-    uint32_t vrun = 0;          // consecutive valid bases ending here
+    // forward k-mer as 2-bit digits: fbe = first base most significant, fle = first base least
+    uint32_t fbe_lo = 0, fbe_hi = 0, fle_lo = 0, fle_hi = 0;
+    uint32_t vrun = 0;  // consecutive valid bases ending here
 
     for (uint32_t i0 = 0; i0 < nsteps; i0 += 4) {
       x += 4;
@@ -187,62 +218,93 @@ __global__ __launch_bounds__(kDnaThreads) void k_dna_rolling(SeqBatch b, HashPar
       const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
       const uint32_t diff4 = u4 ^ exp4;
 #pragma unroll
-      for (int bb = 0; bb < 4; bb++) {
-        const uint32_t i = i0 + bb;
-        const uint32_t code = (code4 >> (8 * bb)) & 3u;
-        uint32_t bad = (diff4 >> (8 * bb)) & 0xffu;
-        if (i >= lim) {
-          // at or past the end of the record's valid part: find where base p0+i belongs
-          const uint64_t q = p0 + i;
-          if (multi) {
-            while (rec + 1 < b.nrec && q >= b.starts[rec + 1]) { rec++; vrun = 0; }
-            cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+      for (int g0b = 0; g0b < 4; g0b += HB) {
+        uint32_t Xlo[HB], Xhi[HB];
+        bool ok[HB];
+#pragma unroll
+        for (int q = 0; q < HB; q++) {
+          const int bb = g0b + q;
+          const uint32_t i = i0 + bb;
+          const uint32_t code = (code4 >> (8 * bb)) & 3u;
+          uint32_t bad = (diff4 >> (8 * bb)) & 0xffu;
+          if (i >= lim) {
+            // at or past the end of the record's valid part: find where base p0+i belongs
+            const uint64_t qpos = p0 + i;
+            if (multi) {
+              while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vrun = 0; }
+              cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+            }
+            if (qpos >= cur_end) { bad = 1; lim = i + 1; }
+            else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
           }
-          if (q >= cur_end) { bad = 1; lim = i + 1; }
-          else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
+          vrun = bad ? 0u : vrun + 1u;
+          // fbe = ((fbe << 2) | code) & MASK ; fle = (fle >> 2) | code << top_shift  (32-bit halves)
+          fbe_hi = __builtin_amdgcn_alignbit(fbe_hi, fbe_lo, 30) & MASK_HI;
+          fbe_lo = ((fbe_lo << 2) | code) & MASK_LO;
+          fle_lo = __builtin_amdgcn_alignbit(fle_hi, fle_lo, 2);
+          fle_hi = fle_hi >> 2;
+          if (top_shift >= 32) fle_hi |= code << (top_shift - 32);
+          else fle_lo |= code << top_shift;
+          // canonical strand: the reverse complement with ITS first base most significant is ~fle
+          const uint64_t fbe = ((uint64_t)fbe_hi << 32) | fbe_lo;
+          const uint64_t rbe = ((uint64_t)(~fle_hi & MASK_HI) << 32) | (~fle_lo & MASK_LO);
+          const bool fwd = fbe < rbe;
+          Xlo[q] = fwd ? fle_lo : ~fbe_lo;  // chosen strand, first base in the low bits
+          Xhi[q] = fwd ? fle_hi : ~fbe_hi;
+          ok[q] = (vrun >= (uint32_t)K) && (i + 1 >= (uint32_t)K) && (i + 1 - (uint32_t)K < nk);
         }
-        vrun = bad ? 0u : vrun + 1u;
-        fbe = ((fbe << 2) | code) & MASK;
-        fle = (fle >> 2) | ((uint64_t)code << top_shift);
-        if (i + 1 >= (uint32_t)K) {
-          const uint32_t s = i + 1 - (uint32_t)K;  // k-mer start index inside my run
-          if (vrun >= (uint32_t)K && s < nk) {
-            // canonical strand: reverse complement, first base most significant, is ~fle
-            const uint64_t rbe = ~fle & MASK;
-            const uint64_t X = fbe < rbe ? fle : ~fbe;  // chosen strand, first base in the low bits
+        if (i0 + g0b + HB >= (uint32_t)K) {  // uniform: past the warm-up bases
+          uint64_t h[HB];
+#pragma unroll
+          for (int q = 0; q < HB; q++) {
             uint32_t D[8];
 #pragma unroll
             for (int g = 0; g < 8; g++) {
               if (4 * g < K) {
-                uint32_t idx = (uint32_t)(X >> (8 * g)) & 0xffu;
+                const uint32_t src = g < 4 ? Xlo[q] : Xhi[q];
+                const uint32_t idx = (src >> (8 * (g & 3))) & 0xffu;
                 uint32_t w = *reinterpret_cast<const uint32_t*>(
                     reinterpret_cast<const char*>(lut) + ((idx << 6) | lut_lane));
-                int nb = K - 4 * g;  // bytes of this dword that belong to the k-mer
+                const int nb = K - 4 * g;  // bytes of this dword that belong to the k-mer
                 if (nb < 4) w &= (1u << (8 * nb)) - 1u;
                 D[g] = w;
               } else {
                 D[g] = 0;
               }
             }
-            const uint64_t w0 = D[0] | ((uint64_t)D[1] << 32), w1 = D[2] | ((uint64_t)D[3] << 32);
-            const uint64_t w2 = D[4] | ((uint64_t)D[5] << 32), w3 = D[6] | ((uint64_t)D[7] << 32);
-            uint64_t h1 = hp.seed, h2 = hp.seed;
-            if (K >= 16) {
-              mm3_block(h1, h2, w0, w1);
-              if (K == 32) mm3_block(h1, h2, w2, w3);
-              else {
-                if (K > 24) h2 ^= mix_k2(w3);
-                if (K > 16) h1 ^= mix_k1(w2);
-              }
-            } else {
-              if (K > 8) h2 ^= mix_k2(w1);
-              h1 ^= mix_k1(w0);
-            }
-            const uint64_t h = mm3_finish(h1, h2, (uint64_t)K);
-            if (h <= thr) emit(sink, h, hp.pos_base + p0 + s);
+            h[q] = murmur_kmer<KT>(D, K, hp.seed);
           }
+#pragma unroll
+          for (int q = 0; q < HB; q++)
+            if (ok[q] && h[q] <= thr) {
+              // stage in LDS (one LDS atomic); a full stage falls through to the global sink
+              const uint64_t pos = hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K);
+              const uint32_t slot = atomicAdd(&st_ctl[0], 1u);
+              if (slot < stage_cap) { st_hash[slot] = h[q]; if (sink.pos) st_pos[slot] = pos; }
+              else emit(sink, h[q], pos);
+            }
         }
       }
+    }
+    }  // p0 < range_hi
+
+    // ---- flush the staged candidates: ONE global atomic per tile, coalesced stores
+    __syncthreads();
+    const uint32_t staged = min(st_ctl[0], stage_cap);
+    if (staged) {
+      if (tid == 0) {
+        unsigned long long base = atomicAdd(sink.count, (unsigned long long)staged);
+        st_ctl[2] = (uint32_t)base; st_ctl[3] = (uint32_t)(base >> 32);
+      }
+      __syncthreads();
+      const uint64_t base = ((uint64_t)st_ctl[3] << 32) | st_ctl[2];
+      for (uint32_t e = tid; e < staged; e += THREADS)
+        if (base + e < sink.capacity) {
+          sink.hash[base + e] = st_hash[e];
+          if (sink.pos) sink.pos[base + e] = st_pos[e];
+        }
+      __syncthreads();
+      if (tid == 0) st_ctl[0] = 0;
     }
   }
 }
@@ -436,6 +498,30 @@ inline int grid_for(uint64_t items, int per_block, int cap) {
 // ---------------------------------------------------------------------------------
 // launchers
 
+// launch geometry of the rolling kernel (override for experiments: SOURMASH_AMD_DNA_CFG="threads,logR,hb")
+struct DnaCfg { int threads, logR, hb; };
+static DnaCfg dna_cfg() {
+  static DnaCfg cfg = [] {
+    DnaCfg c{512, 6, 2};
+    if (const char* e = std::getenv("SOURMASH_AMD_DNA_CFG")) {
+      int t = 0, r = 0, h = 0;
+      if (sscanf(e, "%d,%d,%d", &t, &r, &h) == 3 && (t == 256 || t == 512) && r >= 5 && r <= 7 &&
+          (h == 1 || h == 2 || h == 4)) c = DnaCfg{t, r, h};
+    }
+    return c;
+  }();
+  return cfg;
+}
+
+template <int KT>
+static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSink& sink, int grid, size_t lds,
+                           int logR, uint32_t stage_cap, const DnaCfg& c, hipStream_t s) {
+#define SMH_LAUNCH(T, H) hipLaunchKernelGGL((k_dna_rolling<KT, T, H>), dim3(grid), dim3(T), lds, s, b, p, sink, logR, stage_cap)
+  if (c.threads == 512) { if (c.hb == 4) SMH_LAUNCH(512, 4); else if (c.hb == 2) SMH_LAUNCH(512, 2); else SMH_LAUNCH(512, 1); }
+  else { if (c.hb == 4) SMH_LAUNCH(256, 4); else if (c.hb == 2) SMH_LAUNCH(256, 2); else SMH_LAUNCH(256, 1); }
+#undef SMH_LAUNCH
+}
+
 void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sink, Device& dev,
                      hipStream_t s, bool force_generic) {
   if (p.range_hi <= p.range_lo) return;
@@ -444,19 +530,24 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
   if (p.ksize >= 1 && p.ksize <= 32 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
-    int logR = 7;
-    while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * kDnaThreads * 2) logR--;
-    const uint64_t tile = (uint64_t)kDnaThreads << logR;
+    const DnaCfg c = dna_cfg();
+    int logR = c.logR;
+    while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * c.threads * 2) logR--;
+    const uint64_t tile = (uint64_t)c.threads << logR;
     const uint64_t ntiles = (span + tile - 1) / tile;
     int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
     const uint32_t x_bytes = (uint32_t)tile + 96;
-    const size_t lds = (size_t)kLutDwords * 4 + x_bytes + 4 * ((x_bytes >> logR) + 2);
-    if (p.ksize == 31)
-      hipLaunchKernelGGL(k_dna_rolling<31>, dim3(grid), dim3(kDnaThreads), lds, s, b, p, sink, logR);
-    else if (p.ksize == 21)
-      hipLaunchKernelGGL(k_dna_rolling<21>, dim3(grid), dim3(kDnaThreads), lds, s, b, p, sink, logR);
-    else
-      hipLaunchKernelGGL(k_dna_rolling<0>, dim3(grid), dim3(kDnaThreads), lds, s, b, p, sink, logR);
+    // LDS stage for the survivors of one tile: twice the expectation under a uniform hash, within
+    // [128, 2048] entries; anything beyond goes straight to the global sink
+    const uint64_t thr = p.thr;
+    long double expect = (long double)tile * (((long double)thr + 1.0L) / 18446744073709551616.0L);
+    uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
+    if (stage_cap < 128) stage_cap = 128;
+    const size_t lds = (size_t)kLutDwords * 4 + 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes +
+                       4 * ((x_bytes >> logR) + 2);
+    if (p.ksize == 31) launch_rolling<31>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else if (p.ksize == 21) launch_rolling<21>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else launch_rolling<0>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("dna_rolling", s);
   } else {
