@@ -191,7 +191,7 @@ uint64_t kmerminhash_intersection(KmerMinHash* ptr, const KmerMinHash* other) {
 
 const uint64_t* kmerminhash_get_mins(KmerMinHash* ptr) {
   return pad<const uint64_t*>([&] {
-    require(ptr, "ptr");
+    require(ptr, "ptr"); ptr->materialize();
     uint64_t* out = (uint64_t*)malloc((ptr->mins.size() ? ptr->mins.size() : 1) * sizeof(uint64_t));
     if (!ptr->mins.empty()) memcpy(out, ptr->mins.data(), ptr->mins.size() * sizeof(uint64_t));
     return (const uint64_t*)out;
@@ -199,24 +199,24 @@ const uint64_t* kmerminhash_get_mins(KmerMinHash* ptr) {
 }
 
 uintptr_t kmerminhash_get_mins_size(KmerMinHash* ptr) {
-  return pad<uintptr_t>([&] { require(ptr, "ptr"); return (uintptr_t)ptr->mins.size(); });
+  return pad<uintptr_t>([&] { require(ptr, "ptr"); return (uintptr_t)ptr->size(); });
 }
 
 uint64_t kmerminhash_get_min_idx(KmerMinHash* ptr, uint64_t idx) {
   return pad<uint64_t>([&] {
-    require(ptr, "ptr");
+    require(ptr, "ptr"); ptr->materialize();
     if (idx >= ptr->mins.size()) smh::throw_panic("index out of bounds");
     return ptr->mins[idx];
   });
 }
 
 void kmerminhash_mins_push(KmerMinHash* ptr, uint64_t val) {
-  pad_void([&] { require(ptr, "ptr"); ptr->mins.push_back(val); });
+  pad_void([&] { require(ptr, "ptr"); ptr->materialize(); ptr->mins.push_back(val); });
 }
 
 const uint64_t* kmerminhash_get_abunds(KmerMinHash* ptr) {
   return pad<const uint64_t*>([&] {
-    require(ptr, "ptr");
+    require(ptr, "ptr"); ptr->materialize();
     if (!ptr->has_abunds) return (const uint64_t*)nullptr;
     uint64_t* out = (uint64_t*)malloc((ptr->abunds.size() ? ptr->abunds.size() : 1) * sizeof(uint64_t));
     if (!ptr->abunds.empty()) memcpy(out, ptr->abunds.data(), ptr->abunds.size() * sizeof(uint64_t));
@@ -225,12 +225,12 @@ const uint64_t* kmerminhash_get_abunds(KmerMinHash* ptr) {
 }
 
 uintptr_t kmerminhash_get_abunds_size(KmerMinHash* ptr) {
-  return pad<uintptr_t>([&] { require(ptr, "ptr"); return (uintptr_t)(ptr->has_abunds ? ptr->abunds.size() : 0); });
+  return pad<uintptr_t>([&] { require(ptr, "ptr"); ptr->materialize(); return (uintptr_t)(ptr->has_abunds ? ptr->abunds.size() : 0); });
 }
 
 uint64_t kmerminhash_get_abund_idx(KmerMinHash* ptr, uint64_t idx) {
   return pad<uint64_t>([&] {
-    require(ptr, "ptr");
+    require(ptr, "ptr"); ptr->materialize();
     if (!ptr->has_abunds) return (uint64_t)0;
     if (idx >= ptr->abunds.size()) smh::throw_panic("index out of bounds");
     return ptr->abunds[idx];
@@ -238,7 +238,7 @@ uint64_t kmerminhash_get_abund_idx(KmerMinHash* ptr, uint64_t idx) {
 }
 
 void kmerminhash_abunds_push(KmerMinHash* ptr, uint64_t val) {
-  pad_void([&] { require(ptr, "ptr"); if (ptr->has_abunds) ptr->abunds.push_back(val); });
+  pad_void([&] { require(ptr, "ptr"); ptr->materialize(); if (ptr->has_abunds) ptr->abunds.push_back(val); });
 }
 
 bool kmerminhash_is_protein(KmerMinHash* ptr) { return pad<bool>([&] { require(ptr, "ptr"); return ptr->is_protein; }); }
@@ -430,7 +430,7 @@ int smh_add_sequences_dev(KmerMinHash* ptr, const void* seq_dev, uint64_t total_
 }
 
 int smh_add_many(KmerMinHash* ptr, const uint64_t* hashes, uint64_t n) {
-  return pad_code([&] { require(ptr, "ptr"); if (n) require(hashes, "hashes"); ptr->add_many(hashes, n); });
+  return pad_code([&] { require(ptr, "ptr"); if (n) require(hashes, "hashes"); ptr->materialize(); ptr->add_many(hashes, n); });
 }
 
 int smh_hash_words(const char* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out) {

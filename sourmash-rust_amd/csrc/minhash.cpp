@@ -23,6 +23,43 @@ KmerMinHash::KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint
   if (track) abunds.reserve(mins.capacity());
 }
 
+KmerMinHash::KmerMinHash(const KmerMinHash& o)
+    : num(o.num), ksize(o.ksize), is_protein(o.is_protein), seed(o.seed), max_hash(o.max_hash),
+      has_abunds(o.has_abunds) {
+  o.materialize();
+  mins = o.mins;
+  abunds = o.abunds;
+}
+
+KmerMinHash& KmerMinHash::operator=(const KmerMinHash& o) {
+  if (this == &o) return *this;
+  o.materialize();
+  num = o.num; ksize = o.ksize; is_protein = o.is_protein; seed = o.seed; max_hash = o.max_hash;
+  has_abunds = o.has_abunds; mins = o.mins; abunds = o.abunds; dev.reset();
+  return *this;
+}
+
+void KmerMinHash::materialize() const {
+  if (!dev) return;
+  Device& d = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(d.mutex());
+  hipStream_t s = d.stream();
+  const size_t n = (size_t)dev->n;
+  mins.resize(n);
+  if (n) HIP_CHECK(hipMemcpyAsync(mins.data(), dev->uniq.ptr, n * 8, hipMemcpyDeviceToHost, s));
+  std::vector<uint32_t> st;
+  if (has_abunds && n) {
+    st.resize(n);
+    HIP_CHECK(hipMemcpyAsync(st.data(), dev->starts.ptr, n * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (has_abunds) {
+    abunds.resize(n);
+    for (size_t k = 0; k < n; k++) abunds[k] = (k + 1 < n ? st[k + 1] : (uint32_t)dev->total) - st[k];
+  }
+  dev.reset();
+}
+
 void KmerMinHash::check_compatible(const KmerMinHash& o) const {
   if (ksize != o.ksize) throw_mismatch(kMismatchKSizes);
   if (is_protein != o.is_protein) throw_mismatch(kMismatchDNAProt);
@@ -32,6 +69,7 @@ void KmerMinHash::check_compatible(const KmerMinHash& o) const {
 
 // reference src/lib.rs:192-245 (quirks Q3, Q4)
 void KmerMinHash::add_hash(uint64_t hash) {
+  materialize();
   const uint64_t current_max = mins.empty() ? UINT64_MAX : mins.back();
   if (!(hash <= max_hash || max_hash == 0)) return;
   if (mins.empty()) {
@@ -62,6 +100,7 @@ void KmerMinHash::add_hash(uint64_t hash) {
 }
 
 void KmerMinHash::add_from(const KmerMinHash& other) {
+  other.materialize();
   for (uint64_t h : other.mins) add_hash(h);
 }
 void KmerMinHash::add_many(const uint64_t* hashes, size_t n) {
@@ -71,6 +110,8 @@ void KmerMinHash::add_many(const uint64_t* hashes, size_t n) {
 // reference src/lib.rs:307-403 (quirks Q5, Q6): the abundance iterators advance exactly as there
 void KmerMinHash::merge(const KmerMinHash& other) {
   check_compatible(other);
+  materialize();
+  other.materialize();
   std::vector<uint64_t> merged, mab;
   merged.reserve(mins.size() + other.mins.size());
   mab.reserve(mins.size() + other.mins.size());
@@ -195,7 +236,7 @@ uint64_t Engine::run_chunk(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_
 }
 
 void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s,
-                          Delta* out) {
+                          Delta* out, DeviceSketch* keep_on_device) {
   Device& dev = Device::get();
   out->uniq.clear(); out->run_start.clear(); out->minpos.clear();
   out->sorted_buf = 0; out->n = n;
@@ -209,6 +250,17 @@ void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_mi
   uint32_t nruns = run_length_encode_u64(cand_hash[cur].as<uint64_t>(), n, uniq.as<uint64_t>(),
                                          starts.as<uint32_t>(), dev.scratch, s);
   const uint32_t kept = (keep != 0 && nruns > keep) ? keep : nruns;
+  if (keep_on_device) {
+    // hand the two arrays over instead of copying them out: the sketch stays in HBM
+    std::swap(keep_on_device->uniq.ptr, uniq.ptr);
+    std::swap(keep_on_device->uniq.bytes, uniq.bytes);
+    std::swap(keep_on_device->starts.ptr, starts.ptr);
+    std::swap(keep_on_device->starts.bytes, starts.bytes);
+    keep_on_device->n = kept;
+    keep_on_device->total = n;
+    keep_on_device->has_runs = true;
+    return;
+  }
   out->uniq.resize(kept);
   out->run_start.resize(kept + 1);
   HIP_CHECK(hipMemcpyAsync(out->uniq.data(), uniq.ptr, (size_t)kept * 8, hipMemcpyDeviceToHost, s));
@@ -349,6 +401,13 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
       const uint64_t hi = std::min(P, lo + CH);
       const uint64_t n = E.run_chunk(&src, lo, hi, mh.max_hash, false, s);
       Delta d;
+      if (mh.mins.empty() && !mh.dev && lo == 0 && hi == P && n > 0) {
+        // empty sketch, whole batch in one chunk: the sorted distinct hashes ARE the new state
+        auto ds = std::make_shared<DeviceSketch>();
+        E.reduce_chunk(n, 0, false, false, s, &d, ds.get());
+        mh.dev = ds;
+        return;
+      }
       E.reduce_chunk(n, 0, false, false, s, &d);
       apply_scaled(mh, d);
     }
@@ -430,6 +489,7 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
   Engine& E = Engine::get();
   hipStream_t s = stream ? stream : dev.stream();
+  materialize();
 
   // records shorter than ksize add nothing (reference src/lib.rs:257)
   bool any_long = false;
@@ -586,6 +646,7 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
                   SketchSet* out, uint32_t* maxlen) {
     std::vector<uint64_t> off(v.size() + 1, 0);
     *maxlen = 0;
+    for (size_t i = 0; i < v.size(); i++) v[i]->materialize();
     for (size_t i = 0; i < v.size(); i++) {
       off[i + 1] = off[i] + v[i]->mins.size();
       *maxlen = std::max<uint32_t>(*maxlen, (uint32_t)v[i]->mins.size());

@@ -26,18 +26,33 @@ struct Delta {
   uint64_t n = 0;                   // candidates in the chunk
 };
 
+// A sketch that was just built on the GPU stays in HBM (distinct hashes + run boundaries, from
+// which the abundances follow) until something on the host asks for it; `mins` / `abunds` are then
+// filled by materialize().  Keeps a 10^7-hash scaled sketch out of PCIe unless it is wanted.
+struct DeviceSketch {
+  DeviceBuffer uniq;    // n ascending distinct u64
+  DeviceBuffer starts;  // n u32 run starts (abundance k = starts[k+1]-starts[k], last ends at total)
+  uint64_t n = 0;
+  uint64_t total = 0;
+  bool has_runs = false;
+};
+
 struct KmerMinHash {
   uint32_t num = 1000;
   uint32_t ksize = 21;
   bool is_protein = false;
   uint64_t seed = 42;
   uint64_t max_hash = 0;
-  std::vector<uint64_t> mins;
+  mutable std::vector<uint64_t> mins;
   bool has_abunds = false;         // Option<Vec<u64>>::is_some()
-  std::vector<uint64_t> abunds;
+  mutable std::vector<uint64_t> abunds;
+  mutable std::shared_ptr<DeviceSketch> dev;  // non-null: the state lives here, mins/abunds are empty
 
   KmerMinHash() { mins.reserve(1000); }  // Default, src/lib.rs:48-60
   KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track);  // 142-174
+  KmerMinHash(const KmerMinHash& o);             // Clone: brings a device-resident state to the host first
+  KmerMinHash& operator=(const KmerMinHash& o);
+  void materialize() const;                      // device-resident state -> mins / abunds
 
   void check_compatible(const KmerMinHash& other) const;                 // 176-190
   void add_hash(uint64_t h);                                             // 192-245
@@ -49,7 +64,7 @@ struct KmerMinHash {
   uint64_t count_common(const KmerMinHash& other) const;                 // 428-436 (device)
   void intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const;  // 470-499
   double compare(const KmerMinHash& other) const;                        // 501-508 (device)
-  size_t size() const { return mins.size(); }
+  size_t size() const { return dev ? (size_t)dev->n : mins.size(); }
 
   // --- batch entry points (additive C ABI) ---
   // Records live in ONE device buffer; h_offsets has nrec+1 host entries.  Semantics: as if
@@ -70,7 +85,8 @@ class Engine {
   // (and cand_pos[0]); returns how many.  Re-runs once with an exact buffer on overflow.
   uint64_t run_chunk(HashSourceRef src, uint64_t lo, uint64_t hi, uint64_t thr, bool want_pos, hipStream_t s);
   // sort the chunk by hash, collapse runs, keep the first `keep` runs (0 = all), fetch them
-  void reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s, Delta* out);
+  void reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s, Delta* out,
+                    DeviceSketch* keep_on_device = nullptr);
 
   // murmur64 of whole byte strings on the device (host pointers in, host pointer out)
   void hash_words(const uint8_t* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out);

@@ -90,6 +90,7 @@ struct Md5 {
 }  // namespace
 
 std::string sketch_md5(const KmerMinHash& mh) {
+  mh.materialize();
   Md5 m;
   std::string k = std::to_string(mh.ksize);
   m.update(k.data(), k.size());
@@ -361,6 +362,7 @@ void u64_array(std::string& out, const std::vector<uint64_t>& v) {
 
 // reference src/lib.rs:62-102
 void sketch_to_json(std::string& out, const KmerMinHash& mh) {
+  mh.materialize();
   out += "{\"num\":" + std::to_string(mh.num);
   out += ",\"ksize\":" + std::to_string(mh.ksize);
   out += ",\"seed\":" + std::to_string(mh.seed);
@@ -375,6 +377,8 @@ void sketch_to_json(std::string& out, const KmerMinHash& mh) {
 }  // namespace
 
 bool sketch_equal(const KmerMinHash& a, const KmerMinHash& b) {
+  a.materialize();
+  b.materialize();
   return a.num == b.num && a.ksize == b.ksize && a.is_protein == b.is_protein && a.seed == b.seed &&
          a.max_hash == b.max_hash && a.mins == b.mins && a.has_abunds == b.has_abunds &&
          (!a.has_abunds || a.abunds == b.abunds);

@@ -66,32 +66,72 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint64_t* __
   blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of a u32 array by ONE workgroup of 1024 threads (arrays of a few million
-// entries at most: 256 * tiles).  total (inclusive sum) goes to *total_out if given.
-__global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t* __restrict__ data, size_t m,
-                                                         uint32_t* __restrict__ total_out) {
-  __shared__ uint32_t part[1024];
-  const int t = threadIdx.x;
-  size_t per = (m + 1023) / 1024;
-  size_t lo = (size_t)t * per, hi = lo + per < m ? lo + per : m;
-  uint32_t s = 0;
-  for (size_t i = lo; i < hi; i++) s += data[i];
-  part[t] = s;
+// exclusive scan of a u32 array, three small launches: (1) every workgroup scans its chunk of
+// kScanChunk entries in place and records the chunk total, (2) one workgroup scans the totals,
+// (3) every workgroup adds its chunk offset.  Arrays here are 256 * tiles entries (<= a few
+// million), so (2) is a single workgroup looping over at most a few hundred totals.
+constexpr int kScanThreads = 1024;
+constexpr int kScanPer = 8;
+constexpr int kScanChunk = kScanThreads * kScanPer;
+
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* wtot /*[16]*/, uint32_t* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wtot[w] = incl;
   __syncthreads();
-  // Hillis-Steele over 1024 partial sums
-  for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = t >= off ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (int i = 0; i < kScanThreads / 64; i++) {
+    uint32_t t = wtot[i];
+    if (i < w) base += t;
+    tot += t;
   }
-  uint32_t run = t ? part[t - 1] : 0;
-  for (size_t i = lo; i < hi; i++) {
-    uint32_t v = data[i];
-    data[i] = run;
-    run += v;
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_chunks(uint32_t* __restrict__ data, size_t m,
+                                                              uint32_t* __restrict__ chunk_tot) {
+  __shared__ uint32_t wtot[kScanThreads / 64];
+  const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanPer;
+  uint32_t v[kScanPer], s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++) { v[i] = base + i < m ? data[base + i] : 0; s += v[i]; }
+  uint32_t tot;
+  uint32_t run = block_excl_scan_1024(s, wtot, &tot);
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++) {
+    if (base + i < m) data[base + i] = run;
+    run += v[i];
   }
-  if (total_out && t == 1023) *total_out = part[1023];
+  if (threadIdx.x == 0) chunk_tot[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_totals(uint32_t* __restrict__ chunk_tot, uint32_t nchunks,
+                                                              uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t wtot[kScanThreads / 64];
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nchunks; b0 += kScanThreads) {
+    uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < nchunks ? chunk_tot[i] : 0, tot;
+    uint32_t ex = block_excl_scan_1024(v, wtot, &tot);
+    if (i < nchunks) chunk_tot[i] = carry + ex;
+    carry += tot;
+  }
+  if (total_out && threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(uint32_t* __restrict__ data, size_t m,
+                                                           const uint32_t* __restrict__ chunk_off) {
+  const uint32_t add = chunk_off[blockIdx.x];
+  const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanPer;
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++)
+    if (base + i < m) data[base + i] += add;
 }
 
 // stable scatter of one digit.  Wave w of the workgroup owns the contiguous sub-tile
@@ -215,8 +255,6 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
     }
 }
 
-__global__ void k_set_u32(uint32_t* p, size_t idx, uint32_t v) { p[idx] = v; }
-
 // one thread per run: count, optional weight sum, optional min of the payload
 __global__ __launch_bounds__(256) void k_run_reduce(const uint32_t* __restrict__ starts,
                                                     uint32_t nruns, uint32_t total_runs, uint32_t n,
@@ -245,10 +283,15 @@ __global__ __launch_bounds__(256) void k_run_reduce(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------
 // host drivers
 
-static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, d, m, total);
+// `tmp` must hold ceil(m / kScanChunk) u32 entries
+static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, uint32_t* tmp, hipStream_t s) {
+  const uint32_t nchunks = (uint32_t)((m + kScanChunk - 1) / kScanChunk);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(nchunks), dim3(kScanThreads), 0, s, d, m, tmp);
+  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanThreads), 0, s, tmp, nchunks, total);
+  if (nchunks > 1) hipLaunchKernelGGL(k_scan_add, dim3(nchunks), dim3(kScanThreads), 0, s, d, m, tmp);
   HIP_CHECK(hipGetLastError());
 }
+static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanChunk + 1; }
 
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
                    DeviceBuffer& scratch, hipStream_t s) {
@@ -257,9 +300,11 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
   const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
   const size_t hist_bytes = 8 * 256 * sizeof(unsigned long long);
   const size_t bh_bytes = (size_t)256 * nblocks * sizeof(uint32_t);
-  scratch.ensure(hist_bytes + bh_bytes);
+  const size_t tmp_bytes = scan_tmp_entries((size_t)256 * nblocks) * sizeof(uint32_t);
+  scratch.ensure(hist_bytes + bh_bytes + tmp_bytes);
   auto* ghist = (unsigned long long*)scratch.ptr;
   auto* blockhist = (uint32_t*)((char*)scratch.ptr + hist_bytes);
+  auto* scan_tmp = (uint32_t*)((char*)scratch.ptr + hist_bytes + bh_bytes);
 
   HIP_CHECK(hipMemsetAsync(ghist, 0, hist_bytes, s));
   int hb = (int)((n + 255) / 256);
@@ -280,7 +325,7 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
     if (trivial) continue;  // every key has the same digit: the pass is the identity
     hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
                        blockhist, nblocks);
-    exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, s);
+    exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, scan_tmp, s);
     if (v0)
       hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
                          kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks);
@@ -298,10 +343,10 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   if (n == 0) return 0;
   if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
   const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
-  scratch.ensure((size_t)(nblocks + 1) * sizeof(uint32_t));
+  scratch.ensure((size_t)(nblocks + 1 + scan_tmp_entries(nblocks)) * sizeof(uint32_t));
   auto* bc = (uint32_t*)scratch.ptr;
   hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, n, bc);
-  exclusive_scan_u32(bc, nblocks, bc + nblocks, s);
+  exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, n, bc, uniq,
                      starts);
   HIP_CHECK(hipGetLastError());
