@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "device.hpp"
 #include "kernels.hpp"
 
@@ -115,13 +117,325 @@ __global__ __launch_bounds__(64) void k_compare_wave(SketchSet rows, SketchSet c
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// k_compare_tiled: the N x M matrix kernel.
+//
+// Pre-pass (host driver below): all hashes of rows and columns are dictionary-encoded to dense,
+// order-preserving u32 ranks (radix sort + run ids), so every comparison below is a 32-bit
+// compare and the result is unchanged.  Rank space is cut into R ranges holding equal shares of
+// the pooled elements, and part[s][r] = first element of sketch s that is >= bound[r].
+//
+// One workgroup owns a 64 x 64 tile of pairs: lane = column, each wave walks 16 rows.  Ranges are
+// visited in ascending order; for each, the 64 row segments are packed into an LDS pool (a segment
+// is at most a few dozen consecutive dwords: distinct banks, equal addresses broadcast) and the 64
+// column segments are stored transposed (element e of column j at e*64+j: lane j always hits bank
+// j mod 32).  Every lane merges its pair's two segments (sentinel-terminated), carrying the running
+// union and common counts across ranges; the union walk stops counting at n = the row's num.
+// A tile whose segments do not fit LDS for some range merges that range straight from global memory.
+constexpr int kTB = 64;
+constexpr int kCtThreads = 256;
+constexpr int kRowsPerWave = kTB / (kCtThreads / 64);
+constexpr uint32_t kSent = 0xffffffffu;
+
+struct TiledArgs {
+  const uint32_t* rrank; const uint64_t* roff; const uint32_t* rpart; uint32_t nrows;
+  const uint32_t* crank; const uint64_t* coff; const uint32_t* cpart; uint32_t ncols;
+  uint32_t R, num;
+  const uint32_t* row_nums;
+  uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
+  CompareOut out;
+};
+
+template <bool WantCC>
+__global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  uint32_t* lenA = sm;            // [64]
+  uint32_t* offA = sm + 64;       // [64]
+  uint32_t* gA = sm + 128;        // [64] global index of the segment start
+  uint32_t* lenB = sm + 192;      // [64]
+  uint32_t* gB = sm + 256;        // [64]
+  uint32_t* ctl = sm + 320;       // [0], [1] overflow flags
+  uint32_t* nrowL = sm + 328;     // [64] truncation length of each row (0xffffffff = none, 0 = no row)
+  uint32_t* poolA = sm + 392;
+  uint32_t* Bt = poolA + a.capA;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t tiles_c = (a.ncols + kTB - 1) / kTB;
+  const uint32_t bi = blockIdx.x / tiles_c, bj = blockIdx.x % tiles_c;
+  const uint32_t col = bj * kTB + lane;
+  const bool col_ok = col < a.ncols;
+
+  // per-pair running counts live in registers: every loop over q below is fully unrolled so
+  // that the indices are static
+  uint32_t ucount[kRowsPerWave], common[kRowsPerWave], cc[WantCC ? kRowsPerWave : 1];
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; q++) {
+    ucount[q] = 0; common[q] = 0;
+    if (WantCC) cc[q] = 0;
+  }
+  if (tid < 64) {
+    const uint32_t row = bi * kTB + tid;
+    uint32_t n = 0;
+    if (row < a.nrows) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : 0xffffffffu; }
+    nrowL[tid] = n;
+  }
+
+  for (uint32_t r = 0; r < a.R; r++) {
+    // ---- segment table of this range
+    if (tid < 64) {
+      const uint32_t row = bi * kTB + tid;
+      uint32_t lo = 0, hi = 0, g = 0;
+      if (row < a.nrows) {
+        lo = a.rpart[(size_t)row * (a.R + 1) + r];
+        hi = a.rpart[(size_t)row * (a.R + 1) + r + 1];
+        g = (uint32_t)a.roff[row] + lo;
+      }
+      lenA[tid] = hi - lo; gA[tid] = g;
+      // exclusive scan of (len + 1 sentinel slot) over the 64 rows, by wave 0
+      uint32_t v = hi - lo + 1, incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      offA[tid] = incl - v;
+      const uint32_t totA = __shfl(incl, 63);
+      if (tid == 0) ctl[0] = totA > a.capA ? 1u : 0u;
+    } else if (tid < 128) {
+      const uint32_t c = bj * kTB + (tid - 64);
+      uint32_t lo = 0, hi = 0, g = 0;
+      if (c < a.ncols) {
+        lo = a.cpart[(size_t)c * (a.R + 1) + r];
+        hi = a.cpart[(size_t)c * (a.R + 1) + r + 1];
+        g = (uint32_t)a.coff[c] + lo;
+      }
+      lenB[tid - 64] = hi - lo; gB[tid - 64] = g;
+      uint32_t mx = hi - lo;
+      for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
+      if (tid == 64) ctl[1] = ((mx + 1) * kTB > a.capBt) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool overflow = (ctl[0] | ctl[1]) != 0;
+
+    if (!overflow) {
+      // ---- stage: rows packed (wave w copies its 16 rows), columns transposed (lane = column)
+#pragma unroll 4
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const int t = w * kRowsPerWave + q;
+        const uint32_t la = lenA[t], oa = offA[t], g = gA[t];
+        for (uint32_t e = lane; e < la; e += 64) poolA[oa + e] = a.rrank[g + e];
+        if (lane == 0) poolA[oa + la] = kSent;
+      }
+      {
+        const uint32_t lb = lenB[lane], g = gB[lane];
+        for (uint32_t e = w; e <= lb; e += kCtThreads / 64) Bt[e * kTB + lane] = e < lb ? a.crank[g + e] : kSent;
+      }
+      __syncthreads();
+      // ---- merge: one pair per lane per row
+      const uint32_t lb = lenB[lane];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const int t = w * kRowsPerWave + q;
+        const uint32_t la = lenA[t];
+        const uint32_t n = nrowL[t];
+        if (!WantCC && ucount[q] >= n) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
+        const uint32_t* A = poolA + offA[t];
+        uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
+        uint32_t av = A[0], bv = Bt[lane];
+        while (!(av == kSent && bv == kSent)) {
+          const bool eq = av == bv;
+          cm += (eq && u < n) ? 1u : 0u;
+          if (WantCC) c2 += eq ? 1u : 0u;
+          u += 1;
+          const bool adva = av <= bv, advb = bv <= av;
+          pa += adva ? 1u : 0u;
+          pb += advb ? 1u : 0u;
+          av = A[pa];
+          bv = Bt[pb * kTB + lane];
+        }
+        ucount[q] = u; common[q] = cm;
+        if (WantCC) cc[q] += c2;
+      }
+    } else {
+      // ---- rare: this range does not fit LDS for this tile; merge from global memory
+      const uint32_t lb = lenB[lane];
+      const uint32_t* B = a.crank + gB[lane];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const int t = w * kRowsPerWave + q;
+        const uint32_t la = lenA[t];
+        const uint32_t* A = a.rrank + gA[t];
+        uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
+        const uint32_t n = nrowL[t];
+        while (pa < la && pb < lb) {
+          const uint32_t av = A[pa], bv = B[pb];
+          const bool eq = av == bv;
+          cm += (eq && u < n) ? 1u : 0u;
+          if (WantCC) c2 += eq ? 1u : 0u;
+          u += 1;
+          pa += av <= bv ? 1u : 0u;
+          pb += bv <= av ? 1u : 0u;
+        }
+        u += (la - pa) + (lb - pb);
+        ucount[q] = u; common[q] = cm;
+        if (WantCC) cc[q] += c2;
+      }
+    }
+    // ---- all pairs of the tile past their cut: the remaining ranges cannot change common or size
+    bool done = !WantCC;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) done = done && (ucount[q] >= nrowL[w * kRowsPerWave + q]);
+    if (__syncthreads_and(done || !col_ok)) {
+      // lanes of missing columns vote "done"; real lanes decide
+      break;
+    }
+  }
+
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; q++) {
+    const uint32_t row = bi * kTB + w * kRowsPerWave + q;
+    if (row < a.nrows && col_ok) {
+      const size_t pid = (size_t)row * a.ncols + col;
+      const uint32_t nq = nrowL[w * kRowsPerWave + q];
+      const uint64_t size = ucount[q] < nq ? ucount[q] : nq;
+      if (a.out.common) a.out.common[pid] = common[q];
+      if (a.out.size) a.out.size[pid] = size;
+      if (a.out.jaccard) a.out.jaccard[pid] = (double)common[q] / (double)(size > 1 ? size : 1);
+      if (WantCC) {
+        if (a.out.count_common) a.out.count_common[pid] = cc[q];
+        if (a.out.containment) {
+          const uint64_t la_full = a.roff[row + 1] - a.roff[row];
+          a.out.containment[pid] = (double)cc[q] / (double)la_full;
+        }
+      }
+    }
+  }
+}
+
+// ---- pre-pass kernels ---------------------------------------------------------------------
+__global__ void k_iota(uint64_t* p, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+// rank[origin] = run id, one thread per run
+__global__ void k_run_to_rank(const uint32_t* __restrict__ starts, uint32_t nruns, uint32_t n,
+                              const uint64_t* __restrict__ origin, uint32_t* __restrict__ rank) {
+  uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nruns) return;
+  uint32_t lo = starts[u], hi = u + 1 < nruns ? starts[u + 1] : n;
+  for (uint32_t p = lo; p < hi; p++) rank[origin[p]] = u;
+}
+// bound[r] = rank of the pooled element at sorted position r*n/R (bound[0] = 0, bound[R] = nruns)
+__global__ void k_bounds(const uint32_t* __restrict__ starts, uint32_t nruns, uint32_t n, uint32_t R,
+                         uint32_t* __restrict__ bound) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > R) return;
+  if (r == 0) { bound[0] = 0; return; }
+  if (r == R) { bound[R] = nruns; return; }
+  uint32_t pos = (uint32_t)(((uint64_t)r * n) / R);
+  uint32_t lo = 0, hi = nruns;  // last run with starts[run] <= pos
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (starts[mid] <= pos) lo = mid; else hi = mid;
+  }
+  bound[r] = lo;
+}
+// part[s][r] = first index in sketch s whose rank is >= bound[r]
+__global__ void k_partition(const uint32_t* __restrict__ rank, const uint64_t* __restrict__ off, uint32_t nsk,
+                            const uint32_t* __restrict__ bound, uint32_t R, uint32_t* __restrict__ part) {
+  uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)nsk * (R + 1)) return;
+  uint32_t s = (uint32_t)(g / (R + 1)), r = (uint32_t)(g % (R + 1));
+  const uint32_t* v = rank + off[s];
+  uint32_t len = (uint32_t)(off[s + 1] - off[s]);
+  uint32_t lo = 0, hi = len, b = bound[r];
+  if (r == R) { part[g] = len; return; }
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (v[mid] < b) lo = mid + 1; else hi = mid;
+  }
+  part[g] = lo;
+}
+
+struct TiledScratch {
+  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart;
+};
+TiledScratch& tiled_scratch() {
+  static TiledScratch* t = new TiledScratch();
+  return *t;
+}
+
 }  // namespace
+
+static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
+                         uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev, hipStream_t s) {
+  TiledScratch& T = tiled_scratch();
+  const bool same = rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
+  const uint64_t n = same ? nr_elems : nr_elems + nc_elems;
+  if (n >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
+  // ---- dictionary-encode: sort (hash, origin), run ids -> rank[origin]
+  T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 8); T.org1.ensure(n * 8);
+  HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, rows.hashes, nr_elems * 8, hipMemcpyDeviceToDevice, s));
+  if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint64_t>(), n);
+  int cur = radix_sort_u64(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint64_t>(), T.org1.as<uint64_t>(), n,
+                           dev.scratch, s);
+  uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
+  uint64_t* so = cur ? T.org1.as<uint64_t>() : T.org0.as<uint64_t>();
+  T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
+  const uint32_t nruns = run_length_encode_u64(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s);
+  hipLaunchKernelGGL(k_run_to_rank, dim3((nruns + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), nruns, (uint32_t)n, so,
+                     T.rank.as<uint32_t>());
+  // ---- ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords
+  const uint32_t nsk = same ? rows.n : rows.n + cols.n;
+  uint64_t avg = n / (nsk ? nsk : 1);
+  uint32_t R = (uint32_t)((avg + 23) / 24);
+  if (R < 1) R = 1;
+  if (R > 4096) R = 4096;
+  T.bound.ensure((size_t)(R + 1) * 4);
+  hipLaunchKernelGGL(k_bounds, dim3((R + 1 + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), nruns, (uint32_t)n, R,
+                     T.bound.as<uint32_t>());
+  const uint32_t* rrank = T.rank.as<uint32_t>();
+  const uint32_t* crank = same ? rrank : rrank + nr_elems;
+  T.rpart.ensure((size_t)rows.n * (R + 1) * 4);
+  hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)rows.n * (R + 1) + 255) / 256)), dim3(256), 0, s, rrank, rows.offsets,
+                     rows.n, T.bound.as<uint32_t>(), R, T.rpart.as<uint32_t>());
+  const uint32_t* cpart = T.rpart.as<uint32_t>();
+  if (!same) {
+    T.cpart.ensure((size_t)cols.n * (R + 1) * 4);
+    hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)cols.n * (R + 1) + 255) / 256)), dim3(256), 0, s, crank, cols.offsets,
+                       cols.n, T.bound.as<uint32_t>(), R, T.cpart.as<uint32_t>());
+    cpart = T.cpart.as<uint32_t>();
+  }
+  HIP_CHECK(hipGetLastError());
+  TiledArgs a;
+  a.rrank = rrank; a.roff = rows.offsets; a.rpart = T.rpart.as<uint32_t>(); a.nrows = rows.n;
+  a.crank = crank; a.coff = cols.offsets; a.cpart = cpart; a.ncols = cols.n;
+  a.R = R; a.num = num; a.row_nums = row_nums;
+  a.capA = 64 * 64;        // 4096 dwords: 64 rows x (up to ~63 elements + sentinel) on average
+  a.capBt = 96 * kTB;      // columns up to 95 elements in one range
+  a.out = out;
+  const size_t lds = (size_t)(392 + a.capA + a.capBt) * 4;
+  const uint32_t tiles = ((rows.n + kTB - 1) / kTB) * ((cols.n + kTB - 1) / kTB);
+  const bool want_cc = out.count_common || out.containment;
+  dev.prof_begin(s);
+  if (want_cc) hipLaunchKernelGGL(k_compare_tiled<true>, dim3(tiles), dim3(kCtThreads), lds, s, a);
+  else hipLaunchKernelGGL(k_compare_tiled<false>, dim3(tiles), dim3(kCtThreads), lds, s, a);
+  HIP_CHECK(hipGetLastError());
+  dev.prof_end("compare_tiled", s);
+}
 
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
-                          hipStream_t s, uint32_t max_row_len, uint32_t max_col_len) {
+                          hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,
+                          uint64_t nc_elems) {
   const uint64_t npairs = (uint64_t)rows.n * cols.n;
   if (npairs == 0) return;
+  // big blocks: dictionary-encode once, then the tiled kernel; small ones: one wavefront per pair
+  if (npairs >= 4096 && nr_elems + nc_elems > 0 && std::getenv("SOURMASH_AMD_NO_TILED") == nullptr) {
+    launch_tiled(rows, cols, nr_elems, nc_elems, num, row_nums, out, dev, s);
+    return;
+  }
   const size_t need = ((size_t)max_row_len + max_col_len) * sizeof(uint64_t);
   const int grid = (int)(npairs < (uint64_t)dev.cu_count() * 32 ? npairs : (uint64_t)dev.cu_count() * 32);
   dev.prof_begin(s);

@@ -480,7 +480,7 @@ int smh_compare_block_dev(const uint64_t* row_hashes_dev, const uint64_t* row_of
     smh::CompareOut o;
     o.jaccard = jaccard_dev; o.common = common_dev; o.size = size_dev; o.count_common = count_common_dev;
     o.containment = containment_dev;
-    smh::launch_compare_block(R, C, num, nullptr, o, dev, s, mr, mc);
+    smh::launch_compare_block(R, C, num, nullptr, o, dev, s, mr, mc, row_offsets[n_rows] - row_offsets[0], col_offsets[n_cols] - col_offsets[0]);
     HIP_CHECK(hipStreamSynchronize(s));  // the offset staging buffers are reused by the next call
   });
 }

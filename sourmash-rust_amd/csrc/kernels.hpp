@@ -101,6 +101,7 @@ struct CompareOut {
 // max_row_len / max_col_len: longest sketch on each side (decides LDS staging).
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
-                          hipStream_t s, uint32_t max_row_len, uint32_t max_col_len);
+                          hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,
+                          uint64_t nc_elems);
 
 }  // namespace smh

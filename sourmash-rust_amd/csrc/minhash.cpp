@@ -667,6 +667,9 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   uint32_t mr = 0, mc = 0;
   pack(rows, cmp_a, cmp_oa, &R, &mr);
   pack(cols, cmp_b, cmp_ob, &C, &mc);
+  uint64_t row_total = 0, col_total = 0;
+  for (auto* m : rows) row_total += m->mins.size();
+  for (auto* m : cols) col_total += m->mins.size();
   const size_t np = rows.size() * cols.size();
   if (np == 0) return;
   cmp_out.ensure(np * 8 * 5 + rows.size() * 4 + 64);
@@ -680,7 +683,7 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
     HIP_CHECK(hipMemcpyAsync(d_rownum, row_nums_host, rows.size() * 4, hipMemcpyHostToDevice, s));
   CompareOut o;
   o.common = d_common; o.size = d_size; o.jaccard = d_jac; o.count_common = d_cc; o.containment = d_cont;
-  launch_compare_block(R, C, num, row_nums_host ? d_rownum : nullptr, o, dev, s, mr, mc);
+  launch_compare_block(R, C, num, row_nums_host ? d_rownum : nullptr, o, dev, s, mr, mc, row_total, col_total);
   if (common) HIP_CHECK(hipMemcpyAsync(common, d_common, np * 8, hipMemcpyDeviceToHost, s));
   if (size) HIP_CHECK(hipMemcpyAsync(size, d_size, np * 8, hipMemcpyDeviceToHost, s));
   if (jaccard) HIP_CHECK(hipMemcpyAsync(jaccard, d_jac, np * 8, hipMemcpyDeviceToHost, s));
