@@ -119,23 +119,16 @@ def main():
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
     if not args.no_compare:
-        from sourmash_rust_amd import synth
+        from sourmash_rust_amd import distributed as D, synth
         n_sig = args.compare_n or {1: 1000, 2: 2500, 4: 5000, 8: 10000}.get(world, 1000 * world)
-        per = (n_sig + world - 1) // world
-        lo, hi = min(n_sig, rank * per), min(n_sig, (rank + 1) * per)
+        lo, hi, per = D.shard_range(n_sig, world, rank)
         local_sigs = np.zeros((per, 2000), dtype=np.uint64)
         local_sigs[: hi - lo] = synth.family_signatures(lo, hi, num=2000, seed=3)
         mine = torch.from_numpy(local_sigs.view(np.int64)).cuda()
-        row_off = np.arange(hi - lo + 1, dtype=np.uint64) * np.uint64(2000)
-        col_off = np.arange(n_sig + 1, dtype=np.uint64) * np.uint64(2000)
 
         def compare_step():
-            if world > 1:
-                allsigs = torch.empty((world * per, 2000), dtype=torch.int64, device="cuda")
-                dist.all_gather_into_tensor(allsigs, mine)     # RCCL over xGMI: the only collective
-            else:
-                allsigs = mine
-            return pkg.matrix.compare_block_dev(mine, row_off, allsigs, col_off, 2000, want=("jaccard",), stream=stream)
+            # rows sharded by contiguous blocks; ONE all-gather (RCCL over xGMI) of the signatures
+            return D.compare_matrix_sharded(mine, n_sig, 2000, want=("jaccard",))
 
         out = compare_step()
         barrier()
