@@ -115,6 +115,18 @@ def main():
     # algorithmic bytes per launch: 1 B read per k-mer position + 8 B per retained hash
     bytes_per_launch = (total + 8.0 * retained) / max(1.0, launches_per_step)
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 x2
+    # correction on FETCH_SIZE): measured on exactly this workload, kept under profiles/
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dna_rolling.json")))
+        if abs(total - 10e9) < 1 and launches_per_step == 1.0:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    # ceiling of any k=31 hashing kernel on this chip: bare murmur64 with operands in registers
+    # (tools/microbench.hip, profiles/r01_microbench_int_ops.txt)
+    MURMUR_CEILING = 361.4e9
 
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
@@ -181,10 +193,14 @@ def main():
                        "retained_hashes": retained, "records_sharded_across_ranks": True,
                        "result": "sorted distinct hashes left in HBM; copy to host (PCIe, not in value) took %.1f ms" % to_host_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_dna_rolling<31>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_dna_rolling<31,512,2>",
                          "kernel_ms_avg": kern_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "1 B/k-mer makes this path integer-VALU bound, not HBM bound (DESIGN.md)"},
+                         "valu_bound": {"kernel_kmers_per_s": kmers_per_step / max(1.0, launches_per_step) / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
+                                        "bare_murmur64_ceiling_per_s": MURMUR_CEILING,
+                                        "frac": (kmers_per_step / max(1.0, launches_per_step) / (kern_ms * 1e-3) / MURMUR_CEILING) if kern_ms > 0 else 0.0},
+                         "note": "1 B/k-mer: the path is integer-VALU bound (46 multiply-class + ~110 other VALU ops per k-mer), "
+                                 "not HBM bound; see DESIGN.md 'Roofline'"},
             "cpu_baseline": cpu,
             "compare": compare,
         }
