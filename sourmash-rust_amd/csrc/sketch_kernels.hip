@@ -1,7 +1,7 @@
 // sketch_kernels.hip -- gfx950 kernels for KmerMinHash::add_sequence
 // (reference src/lib.rs:252-305) and its helpers:
 //
-//   k_dna_rolling<K>   DNA arm, ksize <= 32.  One lane owns a run of R consecutive k-mer start
+//   k_dna_rolling<K>   DNA arm, ksize <= 64 (2 or 4 32-bit limbs per packed window).  One lane owns a run of R consecutive k-mer start
 //                      positions; the tile is read from HBM once with coalesced 16-byte loads
 //                      and staged in LDS; each lane rolls two 2-bit packed windows (forward in
 //                      big- and little-endian digit order; the reverse complement is their
@@ -102,34 +102,33 @@ __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ sta
 __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 
 // ---------------------------------------------------------------------------------
-// DNA arm, rolling 2-bit windows, ksize <= 32
+// DNA arm, rolling 2-bit windows, ksize <= 64
 constexpr int kLutReplicas = 16;                 // lane l uses replica l & 15: at most 2-way conflicts
 constexpr int kLutDwords = 256 * kLutReplicas;   // 16 KiB
 
-// murmur64 of a k-mer given as eight little-endian dwords (bytes beyond K are zero)
-template <int KT>
-__device__ __forceinline__ uint64_t murmur_kmer(const uint32_t (&D)[8], int K, uint64_t seed) {
-  const uint64_t w0 = D[0] | ((uint64_t)D[1] << 32), w1 = D[2] | ((uint64_t)D[3] << 32);
-  const uint64_t w2 = D[4] | ((uint64_t)D[5] << 32), w3 = D[6] | ((uint64_t)D[7] << 32);
+// murmur64 of a k-mer given as little-endian dwords D[0 .. 4*L) (bytes beyond K are zero)
+template <int L>
+__device__ __forceinline__ uint64_t murmur_kmer(const uint32_t (&D)[4 * L], int K, uint64_t seed) {
   uint64_t h1 = seed, h2 = seed;
-  if (K >= 16) {
-    mm3_block(h1, h2, w0, w1);
-    if (K == 32) mm3_block(h1, h2, w2, w3);
-    else {
-      if (K > 24) h2 ^= mix_k2(w3);
-      if (K > 16) h1 ^= mix_k1(w2);
+  const int nblocks = K >> 4, tail = K & 15;
+#pragma unroll
+  for (int blk = 0; blk < L; blk++) {
+    const uint64_t k1 = D[4 * blk] | ((uint64_t)D[4 * blk + 1] << 32);
+    const uint64_t k2 = D[4 * blk + 2] | ((uint64_t)D[4 * blk + 3] << 32);
+    if (blk < nblocks) mm3_block(h1, h2, k1, k2);
+    else if (blk == nblocks) {
+      if (tail > 8) h2 ^= mix_k2(k2);
+      if (tail > 0) h1 ^= mix_k1(k1);
     }
-  } else {
-    if (K > 8) h2 ^= mix_k2(w1);
-    h1 ^= mix_k1(w0);
   }
   return mm3_finish(h1, h2, (uint64_t)K);
 }
 
-// KT > 0: ksize fixed at compile time; KT == 0: any ksize in 1..32 at run time.
+// KT > 0: ksize fixed at compile time; KT == 0: any ksize the limb count allows, at run time.
+// L = 32-bit limbs of a packed window: 2 for ksize <= 32, 4 for ksize <= 64.
 // THREADS lanes per workgroup share one LUT; HB = hashes computed together in one straight-line
 // block (independent murmur chains the scheduler can interleave).
-template <int KT, int THREADS, int HB>
+template <int KT, int THREADS, int HB, int L>
 __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
                                                          int logR, uint32_t stage_cap) {
   // LDS: [LUT 16 KiB][staged candidates: count, hashes, positions][sequence tile]
@@ -144,9 +143,14 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
   const int tid = threadIdx.x;
   const uint32_t R = 1u << logR;
   const uint64_t TILE = (uint64_t)THREADS << logR;
-  const uint64_t MASK = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1);
-  const uint32_t MASK_LO = (uint32_t)MASK, MASK_HI = (uint32_t)(MASK >> 32);
-  const int top_shift = 2 * K - 2;
+  // 2K-bit mask, limb by limb
+  uint32_t MASK[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    const int bits = 2 * K - 32 * i;
+    MASK[i] = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+  }
+  const int top_limb = (2 * K - 2) >> 5, top_sh = (2 * K - 2) & 31;
   const bool multi = b.starts != nullptr;
 
   // 4 two-bit digits -> 4 ASCII bytes, digit d -> "ACGT"[d], first digit in the low byte
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     const uintptr_t g0 = (uintptr_t)(b.seq + T0);
     const uintptr_t ga = g0 & ~(uintptr_t)15;
     const uint32_t m = (uint32_t)(g0 - ga);
-    const uint32_t nchunks = (m + (uint32_t)TILE + 40 + 15) >> 4;  // K <= 32: last lane reads < m+TILE+38
+    const uint32_t nchunks = (m + (uint32_t)TILE + 16 * L + 8 + 15) >> 4;  // last lane reads < m+TILE+K+7
     __syncthreads();  // LUT ready / previous tile fully consumed
     for (uint32_t c = tid; c < nchunks; c += THREADS) {
       uintptr_t addr = ga + ((uintptr_t)c << 4);
@@ -202,8 +206,10 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     uint32_t x = (m & ~3u) + ((uint32_t)tid << logR);
     const uint32_t sh = m & 3u;
     uint32_t cur = tile[(x >> 2) + (x >> logR)];
-    // forward k-mer as 2-bit digits: fbe = first base most significant, fle = first base least
-    uint32_t fbe_lo = 0, fbe_hi = 0, fle_lo = 0, fle_hi = 0;
+    // forward k-mer as 2-bit digits in L limbs: fbe = first base most significant, fle = first base least
+    uint32_t fbe[L], fle[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) { fbe[i] = 0; fle[i] = 0; }
     uint32_t vrun = 0;  // consecutive valid bases ending here
 
     for (uint32_t i0 = 0; i0 < nsteps; i0 += 4) {
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
       const uint32_t diff4 = u4 ^ exp4;
 #pragma unroll
       for (int g0b = 0; g0b < 4; g0b += HB) {
-        uint32_t Xlo[HB], Xhi[HB];
+        uint32_t X[HB][L];
         bool ok[HB];
 #pragma unroll
         for (int q = 0; q < HB; q++) {
@@ -238,31 +244,43 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
             else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
           }
           vrun = bad ? 0u : vrun + 1u;
-          // fbe = ((fbe << 2) | code) & MASK ; fle = (fle >> 2) | code << top_shift  (32-bit halves)
-          fbe_hi = __builtin_amdgcn_alignbit(fbe_hi, fbe_lo, 30) & MASK_HI;
-          fbe_lo = ((fbe_lo << 2) | code) & MASK_LO;
-          fle_lo = __builtin_amdgcn_alignbit(fle_hi, fle_lo, 2);
-          fle_hi = fle_hi >> 2;
-          if (top_shift >= 32) fle_hi |= code << (top_shift - 32);
-          else fle_lo |= code << top_shift;
-          // canonical strand: the reverse complement with ITS first base most significant is ~fle
-          const uint64_t fbe = ((uint64_t)fbe_hi << 32) | fbe_lo;
-          const uint64_t rbe = ((uint64_t)(~fle_hi & MASK_HI) << 32) | (~fle_lo & MASK_LO);
-          const bool fwd = fbe < rbe;
-          Xlo[q] = fwd ? fle_lo : ~fbe_lo;  // chosen strand, first base in the low bits
-          Xhi[q] = fwd ? fle_hi : ~fbe_hi;
+          // fbe = ((fbe << 2) | code) & MASK ; fle = (fle >> 2) | code << (2K-2)   (limb-wise)
+#pragma unroll
+          for (int li = L - 1; li > 0; li--) fbe[li] = __builtin_amdgcn_alignbit(fbe[li], fbe[li - 1], 30) & MASK[li];
+          fbe[0] = ((fbe[0] << 2) | code) & MASK[0];
+#pragma unroll
+          for (int li = 0; li < L - 1; li++) fle[li] = __builtin_amdgcn_alignbit(fle[li + 1], fle[li], 2);
+          fle[L - 1] >>= 2;
+#pragma unroll
+          for (int li = 0; li < L; li++)
+            if (li == top_limb) fle[li] |= code << top_sh;
+          // canonical strand: the reverse complement with ITS first base most significant is ~fle;
+          // fwd < rc decided from the top limb down
+          bool fwd = false;
+          if (L == 2) {
+            fwd = (((uint64_t)fbe[1] << 32) | fbe[0]) <
+                  (((uint64_t)(~fle[1] & MASK[1]) << 32) | (~fle[0] & MASK[0]));
+          } else {
+            bool decided = false;
+#pragma unroll
+            for (int li = L - 1; li >= 0; li--) {
+              const uint32_t f = fbe[li], r = ~fle[li] & MASK[li];
+              if (!decided && f != r) { fwd = f < r; decided = true; }
+            }
+          }
+#pragma unroll
+          for (int li = 0; li < L; li++) X[q][li] = fwd ? fle[li] : ~fbe[li];  // chosen strand, first base low
           ok[q] = (vrun >= (uint32_t)K) && (i + 1 >= (uint32_t)K) && (i + 1 - (uint32_t)K < nk);
         }
         if (i0 + g0b + HB >= (uint32_t)K) {  // uniform: past the warm-up bases
           uint64_t h[HB];
 #pragma unroll
           for (int q = 0; q < HB; q++) {
-            uint32_t D[8];
+            uint32_t D[4 * L];
 #pragma unroll
-            for (int g = 0; g < 8; g++) {
+            for (int g = 0; g < 4 * L; g++) {
               if (4 * g < K) {
-                const uint32_t src = g < 4 ? Xlo[q] : Xhi[q];
-                const uint32_t idx = (src >> (8 * (g & 3))) & 0xffu;
+                const uint32_t idx = (X[q][g >> 2] >> (8 * (g & 3))) & 0xffu;
                 uint32_t w = *reinterpret_cast<const uint32_t*>(
                     reinterpret_cast<const char*>(lut) + ((idx << 6) | lut_lane));
                 const int nb = K - 4 * g;  // bytes of this dword that belong to the k-mer
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
                 D[g] = 0;
               }
             }
-            h[q] = murmur_kmer<KT>(D, K, hp.seed);
+            h[q] = murmur_kmer<L>(D, K, hp.seed);
           }
 #pragma unroll
           for (int q = 0; q < HB; q++)
@@ -513,10 +531,10 @@ static DnaCfg dna_cfg() {
   return cfg;
 }
 
-template <int KT>
+template <int KT, int L>
 static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSink& sink, int grid, size_t lds,
                            int logR, uint32_t stage_cap, const DnaCfg& c, hipStream_t s) {
-#define SMH_LAUNCH(T, H) hipLaunchKernelGGL((k_dna_rolling<KT, T, H>), dim3(grid), dim3(T), lds, s, b, p, sink, logR, stage_cap)
+#define SMH_LAUNCH(T, H) hipLaunchKernelGGL((k_dna_rolling<KT, T, H, L>), dim3(grid), dim3(T), lds, s, b, p, sink, logR, stage_cap)
   if (c.threads == 512) { if (c.hb == 4) SMH_LAUNCH(512, 4); else if (c.hb == 2) SMH_LAUNCH(512, 2); else SMH_LAUNCH(512, 1); }
   else { if (c.hb == 4) SMH_LAUNCH(256, 4); else if (c.hb == 2) SMH_LAUNCH(256, 2); else SMH_LAUNCH(256, 1); }
 #undef SMH_LAUNCH
@@ -527,7 +545,7 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
   if (p.range_hi <= p.range_lo) return;
   const uint64_t span = p.range_hi - p.range_lo;
   dev.prof_begin(s);
-  if (p.ksize >= 1 && p.ksize <= 32 && !force_generic) {
+  if (p.ksize >= 1 && p.ksize <= 64 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
     const DnaCfg c = dna_cfg();
@@ -536,7 +554,7 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     const uint64_t tile = (uint64_t)c.threads << logR;
     const uint64_t ntiles = (span + tile - 1) / tile;
     int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
-    const uint32_t x_bytes = (uint32_t)tile + 96;
+    const uint32_t x_bytes = (uint32_t)tile + 160;
     // LDS stage for the survivors of one tile: twice the expectation under a uniform hash, within
     // [128, 2048] entries; anything beyond goes straight to the global sink
     const uint64_t thr = p.thr;
@@ -545,9 +563,11 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     if (stage_cap < 128) stage_cap = 128;
     const size_t lds = (size_t)kLutDwords * 4 + 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes +
                        4 * ((x_bytes >> logR) + 2);
-    if (p.ksize == 31) launch_rolling<31>(b, p, sink, grid, lds, logR, stage_cap, c, s);
-    else if (p.ksize == 21) launch_rolling<21>(b, p, sink, grid, lds, logR, stage_cap, c, s);
-    else launch_rolling<0>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    if (p.ksize == 31) launch_rolling<31, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else if (p.ksize == 21) launch_rolling<21, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else if (p.ksize == 51) launch_rolling<51, 4>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else if (p.ksize <= 32) launch_rolling<0, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else launch_rolling<0, 4>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("dna_rolling", s);
   } else {

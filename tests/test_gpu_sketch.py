@@ -107,6 +107,11 @@ CASES = [
     (30, 33, False, 42, 0, True),              # byte-wise kernel
     (30, 51, False, 42, 0, True),
     (0, 51, False, 42, 1 << 60, True),
+    (20, 48, False, 42, 0, True),              # 4-limb rolling kernel, run-time k
+    (20, 63, False, 42, 0, False),
+    (20, 64, False, 42, 0, True),
+    (20, 65, False, 42, 0, True),              # byte-wise kernel (k > 64)
+    (10, 100, False, 42, 0, False),
     (50, 9, True, 42, 0, True),
     (0, 27, True, 42, 1 << 60, True),
     (30, 12, True, (1 << 40) + 5, 0, False),
