@@ -133,9 +133,8 @@ __global__ __launch_bounds__(64) void k_compare_wave(SketchSet rows, SketchSet c
 // j mod 32).  Every lane merges its pair's two segments (sentinel-terminated), carrying the running
 // union and common counts across ranges; the union walk stops counting at n = the row's num.
 // A tile whose segments do not fit LDS for some range merges that range straight from global memory.
-constexpr int kTB = 64;
+constexpr int kTB = 64;          // columns per tile (= lanes of a wave); rows per tile = 4 * RPW
 constexpr int kCtThreads = 256;
-constexpr int kRowsPerWave = kTB / (kCtThreads / 64);
 constexpr uint32_t kSent = 0xffffffffu;
 
 struct TiledArgs {
@@ -147,8 +146,10 @@ struct TiledArgs {
   CompareOut out;
 };
 
-template <bool WantCC>
+template <bool WantCC, int RPW>
 __global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
+  constexpr int kRowsPerWave = RPW;
+  constexpr int kTR = 4 * RPW;   // rows per tile
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   uint32_t* lenA = sm;            // [64]
   uint32_t* offA = sm + 64;       // [64]
@@ -175,25 +176,25 @@ __global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
     if (WantCC) cc[q] = 0;
   }
   if (tid < 64) {
-    const uint32_t row = bi * kTB + tid;
+    const uint32_t row = bi * kTR + tid;
     uint32_t n = 0;
-    if (row < a.nrows) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : 0xffffffffu; }
+    if (tid < kTR && row < a.nrows) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : 0xffffffffu; }
     nrowL[tid] = n;
   }
 
   for (uint32_t r = 0; r < a.R; r++) {
     // ---- segment table of this range
     if (tid < 64) {
-      const uint32_t row = bi * kTB + tid;
+      const uint32_t row = bi * kTR + tid;
       uint32_t lo = 0, hi = 0, g = 0;
-      if (row < a.nrows) {
+      if (tid < kTR && row < a.nrows) {
         lo = a.rpart[(size_t)row * (a.R + 1) + r];
         hi = a.rpart[(size_t)row * (a.R + 1) + r + 1];
         g = (uint32_t)a.roff[row] + lo;
       }
       lenA[tid] = hi - lo; gA[tid] = g;
-      // exclusive scan of (len + 1 sentinel slot) over the 64 rows, by wave 0
-      uint32_t v = hi - lo + 1, incl = v;
+      // exclusive scan of (len + 1 sentinel slot) over the tile's rows, by wave 0
+      uint32_t v = tid < kTR ? hi - lo + 1 : 0, incl = v;
       for (int off = 1; off < 64; off <<= 1) {
         uint32_t o = __shfl_up(incl, off);
         if (lane >= off) incl += o;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
 
 #pragma unroll
   for (int q = 0; q < kRowsPerWave; q++) {
-    const uint32_t row = bi * kTB + w * kRowsPerWave + q;
+    const uint32_t row = bi * kTR + w * kRowsPerWave + q;
     if (row < a.nrows && col_ok) {
       const size_t pid = (size_t)row * a.ncols + col;
       const uint32_t nq = nrowL[w * kRowsPerWave + q];
@@ -416,11 +417,22 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   a.capBt = 96 * kTB;      // columns up to 95 elements in one range
   a.out = out;
   const size_t lds = (size_t)(392 + a.capA + a.capBt) * 4;
-  const uint32_t tiles = ((rows.n + kTB - 1) / kTB) * ((cols.n + kTB - 1) / kTB);
   const bool want_cc = out.count_common || out.containment;
+  // rows per wave: 16 (64-row tiles) amortises staging best; small problems use shorter tiles so
+  // that the launch still covers the chip several times
+  int rpw = 16;
+  if (const char* e = std::getenv("SOURMASH_AMD_CMP_RPW")) rpw = std::atoi(e);
+  else {
+    const uint64_t ct = (cols.n + kTB - 1) / kTB;
+    while (rpw > 4 && ((rows.n + 4 * rpw - 1) / (4 * rpw)) * ct < (uint64_t)dev.cu_count() * 6) rpw >>= 1;
+  }
+  if (rpw != 4 && rpw != 8 && rpw != 16) rpw = 16;
+  const uint32_t tiles = ((rows.n + 4 * rpw - 1) / (4 * rpw)) * ((cols.n + kTB - 1) / kTB);
   dev.prof_begin(s);
-  if (want_cc) hipLaunchKernelGGL(k_compare_tiled<true>, dim3(tiles), dim3(kCtThreads), lds, s, a);
-  else hipLaunchKernelGGL(k_compare_tiled<false>, dim3(tiles), dim3(kCtThreads), lds, s, a);
+#define SMH_CT(CC, R_) hipLaunchKernelGGL((k_compare_tiled<CC, R_>), dim3(tiles), dim3(kCtThreads), lds, s, a)
+  if (want_cc) { if (rpw == 16) SMH_CT(true, 16); else if (rpw == 8) SMH_CT(true, 8); else SMH_CT(true, 4); }
+  else { if (rpw == 16) SMH_CT(false, 16); else if (rpw == 8) SMH_CT(false, 8); else SMH_CT(false, 4); }
+#undef SMH_CT
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_tiled", s);
 }
