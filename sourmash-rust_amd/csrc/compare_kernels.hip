@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "device.hpp"
@@ -133,8 +134,7 @@ __global__ __launch_bounds__(64) void k_compare_wave(SketchSet rows, SketchSet c
 // j mod 32).  Every lane merges its pair's two segments (sentinel-terminated), carrying the running
 // union and common counts across ranges; the union walk stops counting at n = the row's num.
 // A tile whose segments do not fit LDS for some range merges that range straight from global memory.
-constexpr int kTB = 64;          // columns per tile (= lanes of a wave); rows per tile = 4 * RPW
-constexpr int kCtThreads = 256;
+constexpr int kTB = 64;          // columns per tile (= lanes of a wave); rows per tile = WPB * RPW
 constexpr uint32_t kSent = 0xffffffffu;
 
 struct TiledArgs {
@@ -143,13 +143,16 @@ struct TiledArgs {
   uint32_t R, num;
   const uint32_t* row_nums;
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
+  uint32_t dbg;          // timing experiments only: 1 = stage but do not merge
   CompareOut out;
 };
 
-template <bool WantCC, int RPW>
-__global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
+// RPW rows per wave, WPB waves per workgroup (they share the staged column tile), MINW = waves per
+// SIMD the register allocator must leave room for
+template <bool WantCC, int RPW, int WPB, int MINW>
+__global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
   constexpr int kRowsPerWave = RPW;
-  constexpr int kTR = 4 * RPW;   // rows per tile
+  constexpr int kTR = WPB * RPW;   // rows per tile (<= 64)
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   uint32_t* lenA = sm;            // [64]
   uint32_t* offA = sm + 64;       // [64]
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
       }
       {
         const uint32_t lb = lenB[lane], g = gB[lane];
-        for (uint32_t e = w; e <= lb; e += kCtThreads / 64) Bt[e * kTB + lane] = e < lb ? a.crank[g + e] : kSent;
+        for (uint32_t e = w; e <= lb; e += WPB) Bt[e * kTB + lane] = e < lb ? a.crank[g + e] : kSent;
       }
       __syncthreads();
       // ---- merge: one pair per lane per row
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(kCtThreads) void k_compare_tiled(TiledArgs a) {
         const int t = w * kRowsPerWave + q;
         const uint32_t la = lenA[t];
         const uint32_t n = nrowL[t];
-        if (!WantCC && ucount[q] >= n) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
+        if ((!WantCC && ucount[q] >= n) || a.dbg == 1) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
         const uint32_t* A = poolA + offA[t];
         uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
         uint32_t av = A[0], bv = Bt[lane];
@@ -390,7 +393,10 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // ---- ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords
   const uint32_t nsk = same ? rows.n : rows.n + cols.n;
   uint64_t avg = n / (nsk ? nsk : 1);
-  uint32_t R = (uint32_t)((avg + 23) / 24);
+  uint32_t per_range = 24;
+  if (const char* e = std::getenv("SOURMASH_AMD_CMP_PER_RANGE")) per_range = (uint32_t)std::atoi(e);
+  if (per_range < 4) per_range = 4;
+  uint32_t R = (uint32_t)((avg + per_range - 1) / per_range);
   if (R < 1) R = 1;
   if (R > 4096) R = 4096;
   T.bound.ensure((size_t)(R + 1) * 4);
@@ -413,26 +419,38 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   a.rrank = rrank; a.roff = rows.offsets; a.rpart = T.rpart.as<uint32_t>(); a.nrows = rows.n;
   a.crank = crank; a.coff = cols.offsets; a.cpart = cpart; a.ncols = cols.n;
   a.R = R; a.num = num; a.row_nums = row_nums;
-  a.capA = 64 * 64;        // 4096 dwords: 64 rows x (up to ~63 elements + sentinel) on average
-  a.capBt = 96 * kTB;      // columns up to 95 elements in one range
+  // LDS budget per workgroup ~18 KB so that 8 workgroups of 4 waves fit a CU: the merge loop is a
+  // dependent LDS-read -> compare -> advance chain, and occupancy is what hides its latency
+  // (profiles/r01_compare_geometry.txt: 575 -> 1000 M pairs/s from 3 to 8 waves per SIMD)
+  a.capA = 1024;           // 16 rows x (~24 elements + sentinel) with 2.5x head-room
+  a.capBt = 48 * kTB;      // columns up to 47 elements in one range
+  if (const char* e = std::getenv("SOURMASH_AMD_CMP_LDS")) {
+    int ca = 0, cb = 0;
+    if (sscanf(e, "%d,%d", &ca, &cb) == 2 && ca >= 256 && cb >= 8) { a.capA = ca; a.capBt = cb * kTB; }
+  }
   a.out = out;
+  a.dbg = std::getenv("SOURMASH_AMD_CMP_DBG") ? (uint32_t)std::atoi(std::getenv("SOURMASH_AMD_CMP_DBG")) : 0;
   const size_t lds = (size_t)(392 + a.capA + a.capBt) * 4;
   const bool want_cc = out.count_common || out.containment;
   // rows per wave: 16 (64-row tiles) amortises staging best; small problems use shorter tiles so
   // that the launch still covers the chip several times
-  int rpw = 16;
-  if (const char* e = std::getenv("SOURMASH_AMD_CMP_RPW")) rpw = std::atoi(e);
-  else {
-    const uint64_t ct = (cols.n + kTB - 1) / kTB;
-    while (rpw > 4 && ((rows.n + 4 * rpw - 1) / (4 * rpw)) * ct < (uint64_t)dev.cu_count() * 6) rpw >>= 1;
-  }
-  if (rpw != 4 && rpw != 8 && rpw != 16) rpw = 16;
-  const uint32_t tiles = ((rows.n + 4 * rpw - 1) / (4 * rpw)) * ((cols.n + kTB - 1) / kTB);
+  // geometry "rpw,wpb,minw" (experiments: SOURMASH_AMD_CMP_GEO)
+  int rpw = 4, wpb = 4, minw = 8;
+  if (const char* e = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(e, "%d,%d,%d", &rpw, &wpb, &minw);
+  const uint32_t tr = (uint32_t)(rpw * wpb);
+  const uint32_t tiles = ((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
   dev.prof_begin(s);
-#define SMH_CT(CC, R_) hipLaunchKernelGGL((k_compare_tiled<CC, R_>), dim3(tiles), dim3(kCtThreads), lds, s, a)
-  if (want_cc) { if (rpw == 16) SMH_CT(true, 16); else if (rpw == 8) SMH_CT(true, 8); else SMH_CT(true, 4); }
-  else { if (rpw == 16) SMH_CT(false, 16); else if (rpw == 8) SMH_CT(false, 8); else SMH_CT(false, 4); }
+  bool launched = false;
+#define SMH_CT(R_, W_, M_)                                                                              \
+  if (!launched && rpw == R_ && wpb == W_ && minw == M_) {                                              \
+    launched = true;                                                                                    \
+    if (want_cc) hipLaunchKernelGGL((k_compare_tiled<true, R_, W_, M_>), dim3(tiles), dim3(64 * W_), lds, s, a);  \
+    else hipLaunchKernelGGL((k_compare_tiled<false, R_, W_, M_>), dim3(tiles), dim3(64 * W_), lds, s, a);        \
+  }
+  SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
+  SMH_CT(4, 4, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
 #undef SMH_CT
+  if (!launched) throw_internal("compare geometry not instantiated");
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_tiled", s);
 }
