@@ -62,6 +62,20 @@ int smh_compare_block_dev(const uint64_t *row_hashes_dev, const uint64_t *row_of
                           uint32_t num, double *jaccard_dev, uint64_t *common_dev, uint64_t *size_dev,
                           uint64_t *count_common_dev, double *containment_dev, void *stream);
 
+/* One query against many nodes: LinearIndex::find (reference src/index/linear.rs:25-45) with
+ * search_minhashes / search_minhashes_containment (reference src/index/search.rs:3-9).  Writes the
+ * positions of the nodes whose node.similarity(query) -- or node.containment(query) =
+ * count_common / |node| (reference src/index.rs:131-161) -- is > threshold, in node order.
+ * out_indices must hold n_nodes entries. */
+int smh_find(KmerMinHash *const *nodes, uint32_t n_nodes, const KmerMinHash *query, double threshold,
+             bool containment, uint32_t *out_indices, uint32_t *out_count);
+
+/* scaffold's nearest leaf (reference src/index/sbt.rs:361-370): position of the candidate with the
+ * largest count_common(leaf, candidate) -- the first one on ties, 0 when none is > 0 -- and that
+ * count. */
+int smh_most_common(const KmerMinHash *leaf, KmerMinHash *const *candidates, uint32_t n,
+                    uint32_t *best_pos, uint64_t *best_common);
+
 /* deterministic synthetic DNA of SURVEY.md 8d written to device memory (benchmark input) */
 int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       void *stream);

@@ -7,7 +7,7 @@ csrc/ (libsourmash_amd.so).  There is no CPU fallback.
 from ._lib import SO_PATH, build, exported_symbols, lib  # noqa: F401
 from .errors import SourmashError  # noqa: F401
 from .minhash import KmerMinHash, hash_murmur, hash_words  # noqa: F401
-from . import matrix  # noqa: F401
+from . import index, matrix  # noqa: F401
 
 
 def device_available():

@@ -462,7 +462,8 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
   const uint64_t npairs = (uint64_t)rows.n * cols.n;
   if (npairs == 0) return;
   // big blocks: dictionary-encode once, then the tiled kernel; small ones: one wavefront per pair
-  if (npairs >= 4096 && nr_elems + nc_elems > 0 && std::getenv("SOURMASH_AMD_NO_TILED") == nullptr) {
+  if (npairs >= 4096 && rows.n >= 8 && cols.n >= 16 && nr_elems + nc_elems > 0 &&
+      std::getenv("SOURMASH_AMD_NO_TILED") == nullptr) {
     launch_tiled(rows, cols, nr_elems, nc_elems, num, row_nums, out, dev, s);
     return;
   }

@@ -485,6 +485,50 @@ int smh_compare_block_dev(const uint64_t* row_hashes_dev, const uint64_t* row_of
   });
 }
 
+int smh_find(KmerMinHash* const* nodes, uint32_t n_nodes, const KmerMinHash* query, double threshold,
+             bool containment, uint32_t* out_indices, uint32_t* out_count) {
+  return pad_code([&] {
+    require(out_count, "out_count");
+    *out_count = 0;
+    if (n_nodes == 0) return;
+    require(nodes, "nodes"); require(query, "query"); require(out_indices, "out_indices");
+    std::vector<const smh::KmerMinHash*> R(n_nodes), C(1, query);
+    std::vector<uint32_t> nums(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+      require(nodes[i], "nodes[i]");
+      R[i] = nodes[i]; nums[i] = nodes[i]->num;
+      R[i]->check_compatible(*query);   // Leaf::similarity unwraps compare(): an Err is fatal there too
+    }
+    std::vector<double> val(n_nodes);
+    if (containment) smh::Engine::get().compare_host(R, C, nums.data(), 0, nullptr, nullptr, nullptr, nullptr, val.data());
+    else smh::Engine::get().compare_host(R, C, nums.data(), 0, nullptr, nullptr, val.data(), nullptr, nullptr);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < n_nodes; i++)
+      if (val[i] > threshold) out_indices[k++] = i;   // NaN (empty node, containment) is never > threshold
+    *out_count = k;
+  });
+}
+
+int smh_most_common(const KmerMinHash* leaf, KmerMinHash* const* candidates, uint32_t n, uint32_t* best_pos,
+                    uint64_t* best_common) {
+  return pad_code([&] {
+    if (best_pos) *best_pos = 0;
+    if (best_common) *best_common = 0;
+    if (n == 0) return;
+    require(leaf, "leaf"); require(candidates, "candidates");
+    std::vector<const smh::KmerMinHash*> R(1, leaf), C(n);
+    for (uint32_t j = 0; j < n; j++) { require(candidates[j], "candidates[j]"); C[j] = candidates[j]; leaf->check_compatible(*C[j]); }
+    std::vector<uint64_t> cc(n);
+    smh::Engine::get().compare_host(R, C, nullptr, leaf->num, nullptr, nullptr, nullptr, cc.data(), nullptr);
+    uint32_t pos = 0;
+    uint64_t mx = 0;
+    for (uint32_t j = 0; j < n; j++)
+      if (cc[j] > mx) { mx = cc[j]; pos = j; }
+    if (best_pos) *best_pos = pos;
+    if (best_common) *best_common = mx;
+  });
+}
+
 int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every, void* stream) {
   return pad_code([&] {
     require(out_dev, "out_dev");

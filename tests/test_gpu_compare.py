@@ -100,3 +100,30 @@ def test_device_csr_block(pkg, coracle):
         assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
         assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
         assert (out["jaccard"].cpu().numpy() == jac).all()
+
+
+def test_linear_index_find_and_scaffold(pkg, coracle, sbt_v5_leaves):
+    # reference src/index/sbt.rs:567-601 on tests/data/v5.sbt.json
+    leaves = {pos: mh_from_sketch(pkg.KmerMinHash, sk) for pos, sk in sbt_v5_leaves.items()}
+    oleaves = {pos: mh_from_sketch(coracle.MinHash, sk) for pos, sk in sbt_v5_leaves.items()}
+    lin = pkg.index.LinearIndex()
+    order = sorted(leaves)
+    for p in order:
+        lin.insert(leaves[p])
+    q = leaves[7]
+    assert len(lin.find(pkg.index.search_minhashes, q, 0.5)) == 1
+    assert len(lin.find(pkg.index.search_minhashes, q, 0.1)) == 2
+    assert len(lin.find(pkg.index.search_minhashes_containment, q, 0.5)) == 2
+    assert len(lin.find(pkg.index.search_minhashes_containment, q, 0.1)) == 4
+    got = pkg.index.search_minhashes([leaves[p] for p in order], q, 0.05)
+    exp = [i for i, p in enumerate(order) if oleaves[p].compare(oleaves[7]) > 0.05]
+    assert got == exp
+    # scaffold pairing: every leaf ends up in exactly one pair (7 leaves -> 4 pairs, one single)
+    pairs = pkg.index.scaffold_pairs([leaves[p] for p in order])
+    assert len(pairs) == 4 and sum(1 for a, b in pairs if b is None) == 1
+    # nearest leaf = arg-max count_common, first on ties, like the reference loop
+    rest = [leaves[p] for p in order if p != 7]
+    orest = [oleaves[p] for p in order if p != 7]
+    pos, cm = pkg.index.most_common(q, rest)
+    ocs = [oleaves[7].count_common(o) for o in orest]
+    assert cm == max(ocs) and pos == ocs.index(max(ocs))
