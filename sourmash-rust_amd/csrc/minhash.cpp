@@ -560,7 +560,7 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
     if (total == 0) return;
     E.segbuf.ensure((size_t)(nseg + 1) * 8);
     E.badbuf.ensure((size_t)nseg * 4);
-    E.resbuf.ensure(total);
+    E.resbuf.ensure(total + 64);  // k_hash_windows reads whole 8-byte words past the last start
     HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(E.badbuf.ptr, 0, (size_t)nseg * 4, s));
     launch_translate(b, E.segbuf.as<uint64_t>(), nseg, total, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);

@@ -88,6 +88,41 @@ __device__ __forceinline__ void emit(const CandSink& sink, uint64_t h, uint64_t 
   }
 }
 
+// Survivors are staged in LDS and every workgroup flushes with ONE global atomic + coalesced
+// stores: a per-wave global atomic on the single counter word saturates at ~88 M atomics/s
+// (MI355X_MICROARCH.md "dequeue") and capped the DNA kernel at 84 G k-mers/s.
+struct Stage {
+  uint32_t* ctl;   // [0] = count, [2..3] = flush base
+  uint64_t* hash;
+  uint64_t* pos;   // valid when the sink wants positions
+  uint32_t cap;
+};
+__device__ __forceinline__ void stage_emit(const Stage& st, const CandSink& sink, uint64_t h, uint64_t pos) {
+  const uint32_t slot = atomicAdd(&st.ctl[0], 1u);  // LDS atomic
+  if (slot < st.cap) { st.hash[slot] = h; if (sink.pos) st.pos[slot] = pos; }
+  else emit(sink, h, pos);                          // stage full: straight to the global sink
+}
+// all threads of the workgroup must call this (it synchronises)
+__device__ __forceinline__ void stage_flush(const Stage& st, const CandSink& sink, int tid, int nthreads) {
+  __syncthreads();
+  const uint32_t staged = min(st.ctl[0], st.cap);
+  if (staged) {
+    if (tid == 0) {
+      unsigned long long base = atomicAdd(sink.count, (unsigned long long)staged);
+      st.ctl[2] = (uint32_t)base; st.ctl[3] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    const uint64_t base = ((uint64_t)st.ctl[3] << 32) | st.ctl[2];
+    for (uint32_t e = tid; e < staged; e += nthreads)
+      if (base + e < sink.capacity) {
+        sink.hash[base + e] = st.hash[e];
+        if (sink.pos) sink.pos[base + e] = st.pos[e];
+      }
+    __syncthreads();
+    if (tid == 0) st.ctl[0] = 0;
+  }
+}
+
 // last record whose start is <= p   (starts has nrec+1 entries, starts[nrec] = total length)
 __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ starts, uint32_t nrec,
                                                 uint64_t p) {
@@ -138,6 +173,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
   uint64_t* st_hash = reinterpret_cast<uint64_t*>(st_ctl + 4);
   uint64_t* st_pos = st_hash + stage_cap;
   uint32_t* tile = reinterpret_cast<uint32_t*>(st_pos + (sink.pos ? stage_cap : 0));
+  const Stage stage{st_ctl, st_hash, st_pos, stage_cap};
 
   const int K = KT ? KT : (int)hp.ksize;
   const int tid = threadIdx.x;
@@ -294,36 +330,15 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
           }
 #pragma unroll
           for (int q = 0; q < HB; q++)
-            if (ok[q] && h[q] <= thr) {
-              // stage in LDS (one LDS atomic); a full stage falls through to the global sink
-              const uint64_t pos = hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K);
-              const uint32_t slot = atomicAdd(&st_ctl[0], 1u);
-              if (slot < stage_cap) { st_hash[slot] = h[q]; if (sink.pos) st_pos[slot] = pos; }
-              else emit(sink, h[q], pos);
-            }
+            if (ok[q] && h[q] <= thr)
+              stage_emit(stage, sink, h[q], hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K));
         }
       }
     }
     }  // p0 < range_hi
 
     // ---- flush the staged candidates: ONE global atomic per tile, coalesced stores
-    __syncthreads();
-    const uint32_t staged = min(st_ctl[0], stage_cap);
-    if (staged) {
-      if (tid == 0) {
-        unsigned long long base = atomicAdd(sink.count, (unsigned long long)staged);
-        st_ctl[2] = (uint32_t)base; st_ctl[3] = (uint32_t)(base >> 32);
-      }
-      __syncthreads();
-      const uint64_t base = ((uint64_t)st_ctl[3] << 32) | st_ctl[2];
-      for (uint32_t e = tid; e < staged; e += THREADS)
-        if (base + e < sink.capacity) {
-          sink.hash[base + e] = st_hash[e];
-          if (sink.pos) sink.pos[base + e] = st_pos[e];
-        }
-      __syncthreads();
-      if (tid == 0) st_ctl[0] = 0;
-    }
+    stage_flush(stage, sink, tid, THREADS);
   }
 }
 
@@ -413,55 +428,161 @@ __device__ __forceinline__ bool utf8_ok3(uint32_t a, uint32_t c, uint32_t d) {
   return false;
 }
 
+__device__ __forceinline__ uint32_t translate_one(const SeqBatch& b, uint64_t rs, uint64_t rl, uint32_t f, uint64_t j,
+                                                  uint32_t* bad_flag) {
+  const uint32_t frame = f >> 1;
+  uint32_t c0, c1, c2;
+  if ((f & 1) == 0) {
+    const uint8_t* s = b.seq + rs + frame + 3 * j;
+    c0 = upper(s[0]); c1 = upper(s[1]); c2 = upper(s[2]);
+  } else {
+    const uint8_t* s = b.seq + rs + (rl - 1 - frame - 3 * j);
+    c0 = comp_upper(upper(s[0])); c1 = comp_upper(upper(*(s - 1))); c2 = comp_upper(upper(*(s - 2)));
+  }
+  if ((c0 | c1 | c2) & 0x80u) {
+    if (!utf8_ok3(c0, c1, c2)) *bad_flag = 1;
+  }
+  const int i0 = tcag(c0), i1 = tcag(c1), i2 = tcag(c2);
+  return (i0 < 0 || i1 < 0 || i2 < 0) ? kDropped : (uint32_t)(uint8_t)kCodonAA[16 * i0 + 4 * i1 + i2];
+}
+
+// one lane translates four consecutive residues (one dword store); a group that straddles two
+// segments resolves each residue separately
 __global__ __launch_bounds__(256) void k_translate(SeqBatch b, const uint64_t* __restrict__ seg_off,
                                                    uint32_t nseg, uint8_t* __restrict__ res,
                                                    uint32_t* __restrict__ bad_utf8) {
   const uint64_t total = seg_off[nseg];
+  const uint64_t ngroups = (total + 3) / 4;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+  for (uint64_t gi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
+    const uint64_t g = gi * 4;
     uint32_t seg = find_record(seg_off, nseg, g);
-    uint32_t r = seg / 6, f = seg % 6, frame = f >> 1;
-    uint64_t j = g - seg_off[seg];
+    uint64_t sbeg = seg_off[seg], send = seg_off[seg + 1];
+    uint32_t r = seg / 6, f = seg % 6;
     uint64_t rs = b.starts ? b.starts[r] : 0;
     uint64_t rl = (b.starts ? b.starts[r + 1] : b.len) - rs;
-    uint32_t c0, c1, c2;
-    if ((f & 1) == 0) {
-      const uint8_t* s = b.seq + rs + frame + 3 * j;
-      c0 = upper(s[0]); c1 = upper(s[1]); c2 = upper(s[2]);
-    } else {
-      const uint8_t* s = b.seq + rs + (rl - 1 - frame - 3 * j);
-      c0 = comp_upper(upper(s[0])); c1 = comp_upper(upper(*(s - 1))); c2 = comp_upper(upper(*(s - 2)));
+    uint32_t packed = 0, bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint64_t p = g + q;
+      if (p >= total) break;
+      while (p >= send) {  // next (possibly empty) segment
+        if (bad) { atomicOr(&bad_utf8[seg], 1u); bad = 0; }
+        seg++;
+        sbeg = send; send = seg_off[seg + 1];
+        r = seg / 6; f = seg % 6;
+        rs = b.starts ? b.starts[r] : 0;
+        rl = (b.starts ? b.starts[r + 1] : b.len) - rs;
+      }
+      packed |= translate_one(b, rs, rl, f, p - sbeg, &bad) << (8 * q);
     }
-    if ((c0 | c1 | c2) & 0x80u) {
-      if (!utf8_ok3(c0, c1, c2)) atomicOr(&bad_utf8[seg], 1u);
-    }
-    int i0 = tcag(c0), i1 = tcag(c1), i2 = tcag(c2);
-    res[g] = (i0 < 0 || i1 < 0 || i2 < 0) ? (uint8_t)kDropped : (uint8_t)kCodonAA[16 * i0 + 4 * i1 + i2];
+    if (bad) atomicOr(&bad_utf8[seg], 1u);
+    if (g + 4 <= total) *reinterpret_cast<uint32_t*>(res + g) = packed;
+    else for (uint64_t p = g; p < total; p++) res[p] = (uint8_t)(packed >> (8 * (p - g)));
   }
 }
 
 // protein arm, phase 2: a window starts at every kept residue and takes the next `win` kept
 // residues of the same segment (dropped codons are spliced out, quirk Q8).
+__device__ __forceinline__ void hash_window_slow(const uint8_t* __restrict__ res, uint64_t g, uint64_t end, uint32_t win,
+                                                 const HashParams& hp, uint64_t thr, const CandSink& sink,
+                                                 const Stage& stage) {
+  if (res[g] == kDropped) return;
+  Mm3Stream st(hp.seed);
+  uint32_t got = 0;
+  for (uint64_t q = g; q < end && got < win; q++) {
+    uint32_t c = res[q];
+    if (c != kDropped) { st.push(c); got++; }
+  }
+  if (got < win) return;
+  uint64_t h = st.finish();
+  if (h <= thr) stage_emit(stage, sink, h, hp.pos_base + g);
+}
+
+constexpr int kWinRun = 8;
+__device__ __forceinline__ void hash_run(const uint8_t* __restrict__ res, const uint64_t* __restrict__ seg_off,
+                                         uint32_t nseg, uint32_t win, const HashParams& hp, uint64_t thr,
+                                         const CandSink& sink, const Stage& stage, bool aligned, uint64_t g0) {
+  {
+    const uint32_t seg = find_record(seg_off, nseg, g0);
+    const uint64_t end = seg_off[seg + 1];
+    const uint64_t last = g0 + kWinRun < hp.range_hi ? g0 + kWinRun : hp.range_hi;  // window starts [g0, last)
+    bool fast = aligned && last == g0 + kWinRun && g0 + kWinRun - 1 + win <= end;
+    uint32_t D[12];  // 48 bytes: 8 starts + up to 32-byte windows, little-endian dwords
+    if (fast) {
+      const uint2* src = reinterpret_cast<const uint2*>(res + g0);
+      const int nw = (kWinRun + (int)win - 1 + 7) >> 3;  // 8-byte words covering the stretch
+      uint32_t anydrop = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        uint2 v = make_uint2(0, 0);
+        if (i < nw) v = src[i];
+        D[2 * i] = v.x; D[2 * i + 1] = v.y;
+        if (i < nw) {
+          // a byte equal to 0xFF anywhere in the loaded words (bytes past the stretch may flag too: harmless)
+          uint32_t nx = ~v.x, ny = ~v.y;
+          anydrop |= ((nx - 0x01010101u) & ~nx & 0x80808080u) | ((ny - 0x01010101u) & ~ny & 0x80808080u);
+        }
+      }
+      if (anydrop) fast = false;
+    }
+    if (!fast) {
+      for (uint64_t g = g0; g < last; g++) {
+        uint64_t e = end;
+        if (g >= end) e = seg_off[find_record(seg_off, nseg, g) + 1];
+        hash_window_slow(res, g, e, win, hp, thr, sink, stage);
+      }
+      return;
+    }
+    const int nblocks = (int)win >> 4, tail = (int)win & 15;
+#pragma unroll
+    for (int j = 0; j < kWinRun; j++) {
+      // window j = bytes [j, j+win) of the stretch
+      uint32_t Wd[8];
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        const int lo = d + (j >> 2);
+        Wd[d] = (4 * d < (int)win) ? __builtin_amdgcn_alignbyte(D[lo + 1 < 12 ? lo + 1 : 11], D[lo], j & 3) : 0u;
+        const int nb = (int)win - 4 * d;
+        if (nb > 0 && nb < 4) Wd[d] &= (1u << (8 * nb)) - 1u;
+      }
+      uint64_t h1 = hp.seed, h2 = hp.seed;
+#pragma unroll
+      for (int blk = 0; blk < 2; blk++) {
+        const uint64_t k1 = Wd[4 * blk] | ((uint64_t)Wd[4 * blk + 1] << 32);
+        const uint64_t k2 = Wd[4 * blk + 2] | ((uint64_t)Wd[4 * blk + 3] << 32);
+        if (blk < nblocks) mm3_block(h1, h2, k1, k2);
+        else if (blk == nblocks) {
+          if (tail > 8) h2 ^= mix_k2(k2);
+          if (tail > 0) h1 ^= mix_k1(k1);
+        }
+      }
+      const uint64_t h = mm3_finish(h1, h2, (uint64_t)win);
+      if (h <= thr) stage_emit(stage, sink, h, hp.pos_base + g0 + j);
+    }
+  }
+}
+
+// One lane owns 8 consecutive window starts and reads the 8+win-1 residues they cover once
+// (aligned 8-byte loads).  When that stretch lies inside one segment and holds no dropped codon --
+// the normal case -- every window is a byte-shifted view of those registers; otherwise the lane
+// falls back to the residue-by-residue walk.  win <= 32 for the fast path.
 __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict__ res,
                                                       const uint64_t* __restrict__ seg_off,
                                                       uint32_t nseg, uint32_t win, HashParams hp,
-                                                      CandSink sink) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+                                                      CandSink sink, uint32_t stage_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
+  const Stage stage{wsm, reinterpret_cast<uint64_t*>(wsm + 4), reinterpret_cast<uint64_t*>(wsm + 4) + stage_cap, stage_cap};
+  if (threadIdx.x == 0) wsm[0] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * kWinRun;
   const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
-  for (uint64_t g = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < hp.range_hi;
-       g += stride) {
-    if (res[g] == kDropped) continue;
-    uint32_t seg = find_record(seg_off, nseg, g);
-    const uint64_t end = seg_off[seg + 1];
-    Mm3Stream st(hp.seed);
-    uint32_t got = 0;
-    for (uint64_t q = g; q < end && got < win; q++) {
-      uint32_t c = res[q];
-      if (c != kDropped) { st.push(c); got++; }
-    }
-    if (got < win) continue;
-    uint64_t h = st.finish();
-    if (h <= thr) emit(sink, h, hp.pos_base + g);
+  const bool aligned = ((hp.range_lo | (uintptr_t)res) & 7) == 0 && win <= 32 && win >= 1;
+  // the loop bound is the same for every lane of the workgroup: the flush inside synchronises
+  for (uint64_t b0 = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x * kWinRun; b0 < hp.range_hi; b0 += stride) {
+    const uint64_t g0 = b0 + (uint64_t)threadIdx.x * kWinRun;
+    if (g0 < hp.range_hi) hash_run(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0);
+    stage_flush(stage, sink, threadIdx.x, blockDim.x);
   }
 }
 
@@ -588,7 +709,7 @@ void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s)
 void launch_translate(const SeqBatch& b, const uint64_t* seg_off, uint32_t nseg, uint64_t total,
                       uint8_t* residues, uint32_t* bad_utf8, hipStream_t s) {
   if (total == 0) return;
-  hipLaunchKernelGGL(k_translate, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, b, seg_off, nseg,
+  hipLaunchKernelGGL(k_translate, dim3(grid_for((total + 3) / 4, 256, 16384)), dim3(256), 0, s, b, seg_off, nseg,
                      residues, bad_utf8);
   HIP_CHECK(hipGetLastError());
 }
@@ -598,8 +719,10 @@ void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* s
                          hipStream_t s) {
   (void)total;
   if (p.range_hi <= p.range_lo) return;
-  hipLaunchKernelGGL(k_hash_windows, dim3(grid_for(p.range_hi - p.range_lo, 256, 8192)), dim3(256), 0,
-                     s, bytes, seg_offsets, nseg, win, p, sink);
+  const uint32_t stage_cap = 1024;
+  const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1);
+  hipLaunchKernelGGL(k_hash_windows, dim3(grid_for((p.range_hi - p.range_lo + kWinRun - 1) / kWinRun, 256, 16384)),
+                     dim3(256), lds, s, bytes, seg_offsets, nseg, win, p, sink, stage_cap);
   HIP_CHECK(hipGetLastError());
 }
 
