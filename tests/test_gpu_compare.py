@@ -127,3 +127,74 @@ def test_linear_index_find_and_scaffold(pkg, coracle, sbt_v5_leaves):
     pos, cm = pkg.index.most_common(q, rest)
     ocs = [oleaves[7].count_common(o) for o in orest]
     assert cm == max(ocs) and pos == ocs.index(max(ocs))
+
+
+def test_tiled_block_edge_cases(pkg, coracle):
+    """The tiled matrix kernel on shapes that are not multiples of its 16 x 64 tiles, with empty and
+    ragged sketches, per-row nums that differ (H6: row i's num truncates pair (i, j)), a range that
+    overflows the LDS stage (falls back to the global-memory merge) and duplicate-heavy families."""
+    rng = np.random.RandomState(11)
+    pool = np.unique(rng.randint(0, 1 << 62, size=20000, dtype=np.int64).astype(np.uint64))
+    dense = pool[:3000]                                  # one sketch holding a dense prefix of rank space
+    sizes = [0, 1, 5, 300, 300, 300, 300, 1200, 3000]
+    rows, cols = [], []
+    for i in range(83):
+        k = sizes[i % len(sizes)]
+        rows.append(dense if k == 3000 else np.sort(rng.choice(pool, k, replace=False)))
+    for j in range(131):
+        k = sizes[(j * 5 + 3) % len(sizes)]
+        cols.append(dense[:2500] if k == 3000 else np.sort(rng.choice(pool, k, replace=False)))
+    nums = [0, 1, 7, 300, 5000]
+    row_mh, orow = [], []
+    for i, r in enumerate(rows):
+        n = nums[i % len(nums)]
+        g = pkg.KmerMinHash(n, 21, False, 42, 0); o = coracle.MinHash(n, 21, False, 42, 0)
+        for h in r:
+            g.mins_push(int(h)); o.mins_push(int(h))
+        row_mh.append(g); orow.append(o)
+    col_mh, ocol = [], []
+    for c in cols:
+        g = pkg.KmerMinHash(300, 21, False, 42, 0); o = coracle.MinHash(300, 21, False, 42, 0)
+        for h in c:
+            g.mins_push(int(h)); o.mins_push(int(h))
+        col_mh.append(g); ocol.append(o)
+    out = pkg.matrix.compare_block(row_mh, col_mh, want=("jaccard", "common", "size", "count_common", "containment"))
+    for i in range(len(rows)):
+        for j in range(0, len(cols), 7):
+            c, s_ = orow[i].intersection_size(ocol[j])
+            assert (int(out["common"][i, j]), int(out["size"][i, j])) == (c, s_), (i, j)
+            assert out["jaccard"][i, j] == orow[i].compare(ocol[j])
+            assert int(out["count_common"][i, j]) == orow[i].count_common(ocol[j])
+            if len(rows[i]):
+                assert out["containment"][i, j] == orow[i].containment(ocol[j])
+            else:
+                assert np.isnan(out["containment"][i, j])
+    # jaccard-only request takes the early-exit instantiation: same numbers
+    out2 = pkg.matrix.compare_block(row_mh, col_mh, want=("jaccard", "common", "size"))
+    assert (out2["jaccard"] == out["jaccard"]).all() and (out2["common"] == out["common"]).all()
+    assert (out2["size"] == out["size"]).all()
+
+
+def test_matrix_at_benchmark_size_properties(pkg):
+    """C3 at full size (1000 x 1000, num=2000): symmetry (all nums equal), unit diagonal, and a
+    checksum against the wavefront-per-pair kernel on a sample of rows."""
+    import os
+    import torch
+    from sourmash_rust_amd import synth
+    n = 1000
+    sigs = synth.family_signatures(0, n, num=2000, seed=3)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
+    out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard", "common", "size"))
+    j = out["jaccard"].cpu().numpy()
+    assert (j == j.T).all() and (np.diag(j) == 1.0).all()
+    assert (out["size"].cpu().numpy() == 2000).all()
+    os.environ["SOURMASH_AMD_NO_TILED"] = "1"
+    try:
+        sub = pkg.matrix.compare_block_dev(t[:37].contiguous(), off[:38], t, off, 2000, want=("jaccard", "common"))
+    finally:
+        del os.environ["SOURMASH_AMD_NO_TILED"]
+    assert (sub["jaccard"].cpu().numpy() == j[:37]).all()
+    assert (sub["common"].cpu().numpy() == out["common"].cpu().numpy()[:37]).all()
+    # same-family pairs share hashes, different families do not
+    assert j[0, 50] > 0.2 and j[0, 1] == 0.0

@@ -289,3 +289,53 @@ def test_full_size_properties(pkg, coracle):
     g = pkg.KmerMinHash(0, 31, False, 42, mx, True)
     g.add_sequences_dev(buf.data_ptr(), 2_000_000, [0, 2_000_000], True)
     same_state(g, o)
+
+
+def test_candidate_buffer_overflow_is_rerun(pkg, coracle):
+    """Far more survivors than the uniform-hash estimate: poly-A where the single k-mer passes the
+    filter.  The first launch overflows its buffer (the counter keeps counting), the library re-runs
+    it with the exact size, and the LDS stage spills to the global sink."""
+    k = 21
+    h = int(pkg.hash_words([b"A" * k], 42)[0])
+    n = 3_000_000
+    seq = b"A" * n
+    for num, mx in [(0, h), (0, h - 1), (10, 0)]:
+        g = pkg.KmerMinHash(num, k, False, 42, mx, True)
+        g.add_sequence(seq, True)
+        if mx == h - 1:
+            assert g.mins == [] and g.abunds == []
+        else:
+            assert g.mins == [h]
+            # num mode: a full sketch would stop counting its maximum (Q3); with num=10 it is not full
+            assert g.abunds == [n - k + 1]
+    # mixed: the repeat sits between two random stretches
+    rnd = bytes(coracle.synth_dna(0, 40000, 21, 0))
+    seq2 = rnd[:20000] + b"ac" * 300000 + rnd[20000:]
+    for case in [(0, k, False, 42, 1 << 63, True), (50, k, False, 42, 0, True)]:
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        g.add_sequence(seq2, True); o.add_sequence(seq2, True)
+        same_state(g, o)
+
+
+def test_repeated_device_adds_accumulate(pkg, coracle):
+    import torch
+    host = bytes(coracle.synth_dna(0, 600000, 33, 0))
+    buf = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+    mx = 1 << 57
+    g, o = pkg.KmerMinHash(0, 31, False, 42, mx, True), coracle.MinHash(0, 31, False, 42, mx, True)
+    g.add_sequences_dev(buf.data_ptr(), 300000, [0, 300000], True)          # state stays in HBM
+    assert len(g) == len(set(g.mins))
+    g.add_sequences_dev(buf.data_ptr() + 200000, 400000, [0, 150000, 400000], True)   # materialises, merges
+    o.add_sequence(host[:300000], True)
+    o.add_sequence(host[200000:350000], True)
+    o.add_sequence(host[350000:600000], True)
+    same_state(g, o)
+    # a copy of a device-resident sketch is a host sketch with the same content
+    g2 = pkg.KmerMinHash(0, 31, False, 42, mx, True)
+    g2.add_sequences_dev(buf.data_ptr(), 300000, [0, 300000], True)
+    from sourmash_rust_amd import signature as S
+    sig = S.Signature()
+    sig.push_mh(g2)
+    o2 = coracle.MinHash(0, 31, False, 42, mx, True)
+    o2.add_sequence(host[:300000], True)
+    assert sig.first_mh().mins == o2.mins and g2.mins == o2.mins and g2.abunds == o2.abunds
