@@ -26,6 +26,12 @@ constexpr int ITERS = 2048;
 #define I_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %8\n"
 #define I_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 #define I_MUL24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define I_MUL_LO_V(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
+#define I_ADD_S(n) "v_add_u32 %" #n ", %9, %" #n "\n"
+#define I_ADD_E64(n) "v_add_u32_e64 %" #n ", %" #n ", %8\n"
+#define I_MAD_U32_U24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %8\n"
+#define I_LSHRREV(n) "v_lshrrev_b32 %" #n ", 3, %" #n "\n"
+#define I_AND_OR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %8\n"
 
 template <int OP>
 __global__ __launch_bounds__(256) void k32(uint32_t* out, uint32_t b, uint32_t c) {
@@ -42,6 +48,12 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, uint32_t b, uint32_t c
   if (OP == 8) BODY8(I_PERM)
   if (OP == 9) BODY8(I_CNDMASK)
   if (OP == 10) BODY8(I_MUL24)
+  if (OP == 11) BODY8(I_MUL_LO_V)
+  if (OP == 12) BODY8(I_ADD_S)
+  if (OP == 15) BODY8(I_ADD_E64)
+  if (OP == 16) BODY8(I_MAD_U32_U24)
+  if (OP == 17) BODY8(I_LSHRREV)
+  if (OP == 18) BODY8(I_AND_OR)
   uint32_t r = 0;
   for (int i = 0; i < 8; i++) r ^= a[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
@@ -93,6 +105,8 @@ int main() {
     printf("%-18s %7.3f ms %8.2f T lane-ops/s %7.1f lanes/clk/CU @2.4GHz\n", NAME, ms, ops / ms / 1e9, ops / (ms * 1e-3) / cus / 2.4e9); }
   RUN32(2, "v_add_u32") RUN32(3, "v_xor_b32") RUN32(0, "v_mul_lo_u32") RUN32(1, "v_mul_hi_u32") RUN32(10, "v_mul_u32_u24")
   RUN32(4, "v_alignbit_b32") RUN32(5, "v_add3_u32") RUN32(6, "v_lshl_add_u32") RUN32(7, "v_bfe_u32") RUN32(8, "v_perm_b32") RUN32(9, "v_cndmask_b32")
+  RUN32(11, "mul_lo v,v,v") RUN32(12, "v_add_u32 sgpr") RUN32(15, "v_add_u32_e64")
+  RUN32(16, "v_mad_u32_u24") RUN32(17, "v_lshrrev_b32") RUN32(18, "v_and_or_b32")
   RUN64(0, "v_mad_u64_u32") RUN64(1, "v_lshl_add_u64") RUN64(2, "v_lshlrev_b64") RUN64(3, "v_lshrrev_b64")
   return 0;
 }
