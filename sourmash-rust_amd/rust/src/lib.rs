@@ -1,0 +1,208 @@
+//! Rust face of `libsourmash_amd.so`: the `extern "C"` declarations of `include/sourmash.h` /
+//! `include/sourmash_amd.h` that the hot path needs, and a `KmerMinHash` with the reference's
+//! public fields and method names (reference `src/lib.rs:37-46, 141-513`) whose hot-path methods
+//! forward to the GPU library.  SOURCE ONLY — never compiled in the build image (no toolchain).
+#![allow(non_camel_case_types)]
+
+use std::ffi::CStr;
+use std::os::raw::c_char;
+
+#[repr(C)]
+pub struct RawKmerMinHash {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct SourmashStr {
+    pub data: *mut c_char,
+    pub len: usize,
+    pub owned: bool,
+}
+
+extern "C" {
+    // include/sourmash.h (reference src/ffi.rs)
+    pub fn hash_murmur(kmer: *const c_char, seed: u64) -> u64;
+    pub fn kmerminhash_new(n: u32, k: u32, prot: bool, seed: u64, mx: u64, track_abundance: bool) -> *mut RawKmerMinHash;
+    pub fn kmerminhash_free(ptr: *mut RawKmerMinHash);
+    pub fn kmerminhash_mins_push(ptr: *mut RawKmerMinHash, val: u64);
+    pub fn kmerminhash_abunds_push(ptr: *mut RawKmerMinHash, val: u64);
+    pub fn kmerminhash_get_mins(ptr: *mut RawKmerMinHash) -> *const u64;
+    pub fn kmerminhash_get_mins_size(ptr: *mut RawKmerMinHash) -> usize;
+    pub fn kmerminhash_get_abunds(ptr: *mut RawKmerMinHash) -> *const u64;
+    pub fn kmerminhash_get_abunds_size(ptr: *mut RawKmerMinHash) -> usize;
+    pub fn kmerminhash_track_abundance(ptr: *mut RawKmerMinHash) -> bool;
+    pub fn kmerminhash_compare(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash) -> f64;
+    pub fn kmerminhash_count_common(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash) -> u64;
+    pub fn kmerminhash_intersection(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash) -> u64;
+    pub fn sourmash_init();
+    pub fn sourmash_err_get_last_code() -> u32;
+    pub fn sourmash_err_get_last_message() -> SourmashStr;
+    pub fn sourmash_err_clear();
+    pub fn sourmash_str_free(s: *mut SourmashStr);
+    // include/sourmash_amd.h (additive)
+    pub fn smh_add_sequence_len(ptr: *mut RawKmerMinHash, seq: *const c_char, len: u64, force: bool) -> i32;
+    pub fn smh_add_sequences(ptr: *mut RawKmerMinHash, seq: *const c_char, offsets: *const u64, n_records: u32, force: bool) -> i32;
+    pub fn smh_compare_block(
+        rows: *const *mut RawKmerMinHash, n_rows: u32, cols: *const *mut RawKmerMinHash, n_cols: u32,
+        jaccard: *mut f64, common: *mut u64, size: *mut u64, count_common: *mut u64, containment: *mut f64,
+    ) -> i32;
+}
+
+extern "C" {
+    fn free(p: *mut std::os::raw::c_void);
+}
+
+/// Error codes of reference `src/errors.rs:28-50`.
+#[derive(Debug, Clone, PartialEq)]
+pub struct SourmashError {
+    pub code: u32,
+    pub message: String,
+}
+
+fn take_error() -> SourmashError {
+    unsafe {
+        let code = sourmash_err_get_last_code();
+        let mut s = sourmash_err_get_last_message();
+        let message = if s.data.is_null() {
+            String::new()
+        } else {
+            String::from_utf8_lossy(std::slice::from_raw_parts(s.data as *const u8, s.len)).into_owned()
+        };
+        sourmash_str_free(&mut s);
+        sourmash_err_clear();
+        SourmashError { code, message }
+    }
+}
+
+/// Same public fields as the reference struct (`src/lib.rs:37-46`).
+#[derive(Debug, Clone, PartialEq)]
+pub struct KmerMinHash {
+    pub num: u32,
+    pub ksize: u32,
+    pub is_protein: bool,
+    pub seed: u64,
+    pub max_hash: u64,
+    pub mins: Vec<u64>,
+    pub abunds: Option<Vec<u64>>,
+}
+
+struct Handle(*mut RawKmerMinHash);
+impl Drop for Handle {
+    fn drop(&mut self) {
+        unsafe { kmerminhash_free(self.0) }
+    }
+}
+
+impl KmerMinHash {
+    pub fn new(num: u32, ksize: u32, is_protein: bool, seed: u64, max_hash: u64, track_abundance: bool) -> KmerMinHash {
+        KmerMinHash { num, ksize, is_protein, seed, max_hash, mins: Vec::new(), abunds: if track_abundance { Some(Vec::new()) } else { None } }
+    }
+
+    /// Library-side copy of the current state (raw pushes: no ordering check, like the reference ABI).
+    fn to_handle(&self) -> Handle {
+        unsafe {
+            let h = kmerminhash_new(self.num, self.ksize, self.is_protein, self.seed, self.max_hash, self.abunds.is_some());
+            for &m in &self.mins {
+                kmerminhash_mins_push(h, m);
+            }
+            if let Some(ab) = &self.abunds {
+                for &a in ab {
+                    kmerminhash_abunds_push(h, a);
+                }
+            }
+            Handle(h)
+        }
+    }
+
+    fn read_back(&mut self, h: &Handle) {
+        unsafe {
+            let n = kmerminhash_get_mins_size(h.0);
+            let p = kmerminhash_get_mins(h.0);
+            self.mins = std::slice::from_raw_parts(p, n).to_vec();
+            free(p as *mut _);
+            if kmerminhash_track_abundance(h.0) {
+                let na = kmerminhash_get_abunds_size(h.0);
+                let pa = kmerminhash_get_abunds(h.0);
+                self.abunds = Some(std::slice::from_raw_parts(pa, na).to_vec());
+                free(pa as *mut _);
+            }
+        }
+    }
+
+    /// Reference `add_sequence` (`src/lib.rs:252-305`): on `Err` the windows before the offending
+    /// one have been added, exactly as there.
+    pub fn add_sequence(&mut self, seq: &[u8], force: bool) -> Result<(), SourmashError> {
+        let h = self.to_handle();
+        let rc = unsafe { smh_add_sequence_len(h.0, seq.as_ptr() as *const c_char, seq.len() as u64, force) };
+        self.read_back(&h);
+        if rc != 0 {
+            return Err(take_error());
+        }
+        Ok(())
+    }
+
+    /// Many records in one device pass (no counterpart in the reference API).
+    pub fn add_sequences(&mut self, records: &[&[u8]], force: bool) -> Result<(), SourmashError> {
+        let mut flat = Vec::new();
+        let mut off = vec![0u64];
+        for r in records {
+            flat.extend_from_slice(r);
+            off.push(flat.len() as u64);
+        }
+        let h = self.to_handle();
+        let rc = unsafe { smh_add_sequences(h.0, flat.as_ptr() as *const c_char, off.as_ptr(), records.len() as u32, force) };
+        self.read_back(&h);
+        if rc != 0 {
+            return Err(take_error());
+        }
+        Ok(())
+    }
+
+    /// Reference `compare` (`src/lib.rs:501-508`).
+    pub fn compare(&self, other: &KmerMinHash) -> Result<f64, SourmashError> {
+        let (a, b) = (self.to_handle(), other.to_handle());
+        unsafe {
+            sourmash_err_clear();
+            let j = kmerminhash_compare(a.0, b.0);
+            if sourmash_err_get_last_code() != 0 {
+                return Err(take_error());
+            }
+            Ok(j)
+        }
+    }
+
+    /// Reference `count_common` (`src/lib.rs:428-436`).
+    pub fn count_common(&self, other: &KmerMinHash) -> Result<u64, SourmashError> {
+        let (a, b) = (self.to_handle(), other.to_handle());
+        unsafe {
+            sourmash_err_clear();
+            let c = kmerminhash_count_common(a.0, b.0);
+            if sourmash_err_get_last_code() != 0 {
+                return Err(take_error());
+            }
+            Ok(c)
+        }
+    }
+}
+
+/// Reference `_hash_murmur` (`src/lib.rs:33-35`) for NUL-free input.
+pub fn _hash_murmur(kmer: &CStr, seed: u64) -> u64 {
+    unsafe { hash_murmur(kmer.as_ptr(), seed) }
+}
+
+/// rows x cols Jaccard block in one launch (N^2 calls of `compare` in the reference).
+pub fn compare_matrix(rows: &[KmerMinHash], cols: &[KmerMinHash]) -> Result<Vec<f64>, SourmashError> {
+    let rh: Vec<Handle> = rows.iter().map(|m| m.to_handle()).collect();
+    let ch: Vec<Handle> = cols.iter().map(|m| m.to_handle()).collect();
+    let rp: Vec<*mut RawKmerMinHash> = rh.iter().map(|h| h.0).collect();
+    let cp: Vec<*mut RawKmerMinHash> = ch.iter().map(|h| h.0).collect();
+    let mut out = vec![0f64; rows.len() * cols.len()];
+    let rc = unsafe {
+        smh_compare_block(rp.as_ptr(), rp.len() as u32, cp.as_ptr(), cp.len() as u32, out.as_mut_ptr(),
+                          std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut())
+    };
+    if rc != 0 {
+        return Err(take_error());
+    }
+    Ok(out)
+}
