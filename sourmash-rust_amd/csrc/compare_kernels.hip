@@ -185,14 +185,23 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
     nrowL[tid] = n;
   }
 
-  for (uint32_t r = 0; r < a.R; r++) {
-    // ---- segment table of this range
+  // Ranges are fine-grained (sized for the longest sketch); a tile whose sketches are short in
+  // this part of rank space walks several of them at once: span m doubles while the segments
+  // still fit the LDS stage and halves when they do not.
+  uint32_t r = 0, m = 1, cool = 0;
+  while (r < a.R) {
+    uint32_t mt = m;
+    if (cool == 0 && m < 64) mt = m * 2; else if (cool) cool--;
+    if (mt > a.R - r) mt = a.R - r;
+    bool overflow;
+    while (true) {
+    // ---- segment table of ranges [r, r + mt)
     if (tid < 64) {
       const uint32_t row = bi * kTR + tid;
       uint32_t lo = 0, hi = 0, g = 0;
       if (tid < kTR && row < a.nrows) {
         lo = a.rpart[(size_t)row * (a.R + 1) + r];
-        hi = a.rpart[(size_t)row * (a.R + 1) + r + 1];
+        hi = a.rpart[(size_t)row * (a.R + 1) + r + mt];
         g = (uint32_t)a.roff[row] + lo;
       }
       lenA[tid] = hi - lo; gA[tid] = g;
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       uint32_t lo = 0, hi = 0, g = 0;
       if (c < a.ncols) {
         lo = a.cpart[(size_t)c * (a.R + 1) + r];
-        hi = a.cpart[(size_t)c * (a.R + 1) + r + 1];
+        hi = a.cpart[(size_t)c * (a.R + 1) + r + mt];
         g = (uint32_t)a.coff[c] + lo;
       }
       lenB[tid - 64] = hi - lo; gB[tid - 64] = g;
@@ -219,7 +228,13 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       if (tid == 64) ctl[1] = ((mx + 1) * kTB > a.capBt) ? 1u : 0u;
     }
     __syncthreads();
-    const bool overflow = (ctl[0] | ctl[1]) != 0;
+    overflow = (ctl[0] | ctl[1]) != 0;
+    if (!overflow || mt == 1) break;
+    __syncthreads();           // everyone has read the flags before the table is rebuilt
+    mt >>= 1;
+    cool = 16;                 // do not try to grow again for a while
+    }
+    m = mt;
 
     if (!overflow) {
       // ---- stage: rows packed (wave w copies its 16 rows), columns transposed (lane = column)
@@ -293,6 +308,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       // lanes of missing columns vote "done"; real lanes decide
       break;
     }
+    r += m;
   }
 
 #pragma unroll
@@ -372,7 +388,8 @@ TiledScratch& tiled_scratch() {
 }  // namespace
 
 static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
-                         uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev, hipStream_t s) {
+                         uint32_t max_len, uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
+                         hipStream_t s) {
   TiledScratch& T = tiled_scratch();
   const bool same = rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
   const uint64_t n = same ? nr_elems : nr_elems + nc_elems;
@@ -391,14 +408,15 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   hipLaunchKernelGGL(k_run_to_rank, dim3((nruns + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), nruns, (uint32_t)n, so,
                      T.rank.as<uint32_t>());
   // ---- ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords
-  const uint32_t nsk = same ? rows.n : rows.n + cols.n;
-  uint64_t avg = n / (nsk ? nsk : 1);
+  // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
+  // sketches walk several ranges per step
+  uint64_t avg = max_len;
   uint32_t per_range = 24;
   if (const char* e = std::getenv("SOURMASH_AMD_CMP_PER_RANGE")) per_range = (uint32_t)std::atoi(e);
   if (per_range < 4) per_range = 4;
   uint32_t R = (uint32_t)((avg + per_range - 1) / per_range);
   if (R < 1) R = 1;
-  if (R > 4096) R = 4096;
+  if (R > 8192) R = 8192;
   T.bound.ensure((size_t)(R + 1) * 4);
   hipLaunchKernelGGL(k_bounds, dim3((R + 1 + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), nruns, (uint32_t)n, R,
                      T.bound.as<uint32_t>());
@@ -464,7 +482,8 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
   // big blocks: dictionary-encode once, then the tiled kernel; small ones: one wavefront per pair
   if (npairs >= 4096 && rows.n >= 8 && cols.n >= 16 && nr_elems + nc_elems > 0 &&
       std::getenv("SOURMASH_AMD_NO_TILED") == nullptr) {
-    launch_tiled(rows, cols, nr_elems, nc_elems, num, row_nums, out, dev, s);
+    launch_tiled(rows, cols, nr_elems, nc_elems, max_row_len > max_col_len ? max_row_len : max_col_len, num, row_nums, out,
+                 dev, s);
     return;
   }
   const size_t need = ((size_t)max_row_len + max_col_len) * sizeof(uint64_t);
