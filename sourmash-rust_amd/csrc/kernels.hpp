@@ -66,6 +66,10 @@ void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* s
 void launch_translate(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t nseg, uint64_t total,
                       uint8_t* residues, uint32_t* bad_utf8, hipStream_t s);
 
+// hashes[lo..hi) that are <= thr go to the sink with their index as stream position
+// (bulk add_many, reference src/lib.rs:412-417)
+void launch_filter_hashes(const uint64_t* hashes, const HashParams& p, const CandSink& sink, hipStream_t s);
+
 // synthetic DNA generator (same definition as oracle osynth_dna)
 void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       hipStream_t s);

@@ -104,7 +104,13 @@ void KmerMinHash::add_from(const KmerMinHash& other) {
   for (uint64_t h : other.mins) add_hash(h);
 }
 void KmerMinHash::add_many(const uint64_t* hashes, size_t n) {
-  for (size_t i = 0; i < n; i++) add_hash(hashes[i]);
+  // a handful of hashes: the reference's loop.  A bulk array: same result through the device fold
+  // (filter + sort + distinct + count), which does not degrade quadratically like Vec::insert.
+  if (n < 4096) {
+    for (size_t i = 0; i < n; i++) add_hash(hashes[i]);
+    return;
+  }
+  add_many_bulk(hashes, n);
 }
 
 // reference src/lib.rs:307-403 (quirks Q5, Q6): the abundance iterators advance exactly as there
@@ -112,6 +118,7 @@ void KmerMinHash::merge(const KmerMinHash& other) {
   check_compatible(other);
   materialize();
   other.materialize();
+  if (merge_on_device(other)) return;
   std::vector<uint64_t> merged, mab;
   merged.reserve(mins.size() + other.mins.size());
   mab.reserve(mins.size() + other.mins.size());
@@ -195,6 +202,17 @@ struct ProteinSource : HashSource {
     dev->prof_begin(s);
     launch_hash_windows(res, total, seg_off, nseg, win, p, sink, s);
     dev->prof_end("hash_windows", s);
+  }
+};
+
+struct RawHashSource : HashSource {
+  const uint64_t* hashes = nullptr;  // device
+  uint64_t n = 0;
+  uint64_t positions() const override { return n; }
+  void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
+    HashParams p;
+    p.thr = thr; p.range_lo = lo; p.range_hi = hi;
+    launch_filter_hashes(hashes, p, sink, s);
   }
 };
 
@@ -451,6 +469,69 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
     for (uint64_t h : hs) mh.add_hash(h);
   }
 }
+
+}  // namespace
+
+void KmerMinHash::add_many_bulk(const uint64_t* hashes, size_t n) {
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  Engine& E = Engine::get();
+  hipStream_t s = dev.stream();
+  materialize();
+  E.seqbuf.ensure(n * 8);
+  HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, hashes, n * 8, hipMemcpyHostToDevice, s));
+  RawHashSource src;
+  src.hashes = E.seqbuf.as<uint64_t>();
+  src.n = n;
+  ingest(*this, src, s);
+}
+
+// merge (reference src/lib.rs:307-403) of two large, well-formed sketches on the device:
+// concatenate, radix sort with the abundances as payload, collapse runs (sum), truncate to num.
+// Used only when the host two-pointer loop would be the slow part; small or odd-shaped sketches
+// (quirk Q5 states) stay on the statement-faithful host path.
+bool KmerMinHash::merge_on_device(const KmerMinHash& other) {
+  const size_t na = mins.size(), nb = other.mins.size(), n = na + nb;
+  const bool both_tracked = has_abunds && other.has_abunds && abunds.size() == na && other.abunds.size() == nb;
+  const bool none_tracked = !has_abunds && !other.has_abunds;
+  if (n < (1u << 16) || n >= (1ull << 31) || !(both_tracked || none_tracked) || !Device::available()) return false;
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  Engine& E = Engine::get();
+  hipStream_t s = dev.stream();
+  E.cand_hash[0].ensure(n * 8); E.cand_hash[1].ensure(n * 8);
+  HIP_CHECK(hipMemcpyAsync(E.cand_hash[0].ptr, mins.data(), na * 8, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(E.cand_hash[0].as<uint64_t>() + na, other.mins.data(), nb * 8, hipMemcpyHostToDevice, s));
+  if (both_tracked) {
+    E.cand_pos[0].ensure(n * 8); E.cand_pos[1].ensure(n * 8);
+    HIP_CHECK(hipMemcpyAsync(E.cand_pos[0].ptr, abunds.data(), na * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(E.cand_pos[0].as<uint64_t>() + na, other.abunds.data(), nb * 8, hipMemcpyHostToDevice, s));
+  }
+  int cur = radix_sort_u64(E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(),
+                           both_tracked ? E.cand_pos[0].as<uint64_t>() : nullptr,
+                           both_tracked ? E.cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s);
+  E.uniq.ensure(n * 8);
+  E.starts.ensure((n + 1) * 4);
+  const uint32_t nruns = run_length_encode_u64(E.cand_hash[cur].as<uint64_t>(), n, E.uniq.as<uint64_t>(),
+                                               E.starts.as<uint32_t>(), dev.scratch, s);
+  std::vector<uint64_t> nm(nruns), na_sum;
+  HIP_CHECK(hipMemcpyAsync(nm.data(), E.uniq.ptr, (size_t)nruns * 8, hipMemcpyDeviceToHost, s));
+  if (both_tracked) {
+    E.red_b.ensure((size_t)nruns * 8);
+    run_reduce(E.starts.as<uint32_t>(), nruns, nruns, (uint32_t)n, E.cand_pos[cur].as<uint64_t>(), nullptr,
+               E.red_b.as<uint64_t>(), nullptr, s);
+    na_sum.resize(nruns);
+    HIP_CHECK(hipMemcpyAsync(na_sum.data(), E.red_b.ptr, (size_t)nruns * 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (!(nm.size() < (size_t)num || num == 0)) nm.resize(num);  // abundances are NOT truncated (Q5/Q6)
+  mins.swap(nm);
+  abunds.swap(na_sum);   // untracked inputs: Some(vec![]) like the reference
+  has_abunds = true;
+  return true;
+}
+
+namespace {
 
 // String::from_utf8(kmer).unwrap() of reference src/lib.rs:270
 bool utf8_valid(const uint8_t* s, size_t n) {

@@ -597,6 +597,18 @@ __global__ __launch_bounds__(256) void k_hash_segments(const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------
+// add_many (reference src/lib.rs:412-417) in bulk: the hashes already exist, only the filter and
+// the append remain; the stream position of hash i is i.
+__global__ __launch_bounds__(256) void k_filter_hashes(const uint64_t* __restrict__ hashes, HashParams hp, CandSink sink) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+  for (uint64_t i = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hp.range_hi; i += stride) {
+    const uint64_t h = hashes[i];
+    if (h <= thr) emit(sink, h, hp.pos_base + i);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t index) {
   uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -731,6 +743,12 @@ void launch_hash_segments(const uint8_t* bytes, const uint64_t* seg_offsets, uin
   if (nseg == 0) return;
   hipLaunchKernelGGL(k_hash_segments, dim3((nseg + 255) / 256), dim3(256), 0, s, bytes, seg_offsets,
                      nseg, seed, out);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_filter_hashes(const uint64_t* hashes, const HashParams& p, const CandSink& sink, hipStream_t s) {
+  if (p.range_hi <= p.range_lo) return;
+  hipLaunchKernelGGL(k_filter_hashes, dim3(grid_for(p.range_hi - p.range_lo, 256, 4096)), dim3(256), 0, s, hashes, p, sink);
   HIP_CHECK(hipGetLastError());
 }
 

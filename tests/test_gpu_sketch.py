@@ -339,3 +339,30 @@ def test_repeated_device_adds_accumulate(pkg, coracle):
     o2 = coracle.MinHash(0, 31, False, 42, mx, True)
     o2.add_sequence(host[:300000], True)
     assert sig.first_mh().mins == o2.mins and g2.mins == o2.mins and g2.abunds == o2.abunds
+
+
+def test_bulk_add_many_and_device_merge(pkg, coracle):
+    """add_many over a large array goes through the device fold; merging two large sketches goes
+    through the device union.  Both must equal the reference's one-by-one semantics."""
+    rng = np.random.RandomState(17)
+    universe = rng.randint(0, 1 << 62, size=60000, dtype=np.int64).astype(np.uint64)
+    stream = rng.choice(universe, 250000)                     # many repeats
+    for case in [(0, 21, False, 42, 1 << 61, True), (0, 21, False, 42, 1 << 61, False), (300, 21, False, 42, 0, True),
+                 (300, 21, False, 42, 0, False), (50, 21, False, 42, 1 << 61, True)]:
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        g.add_many(stream[:100]); o.add_many(stream[:100])    # scalar path first
+        g.add_many(stream); o.add_many(stream)                # bulk path on a non-empty sketch
+        same_state(g, o)
+    # large merges: both tracked / none tracked (Q5: abundances become Some([]) and are never truncated)
+    for track in (True, False):
+        for num, mx in [(0, 1 << 62), (40000, 0)]:
+            ga, oa = pkg.KmerMinHash(num, 21, False, 42, mx, track), coracle.MinHash(num, 21, False, 42, mx, track)
+            gb, ob = pkg.KmerMinHash(num, 21, False, 42, mx, track), coracle.MinHash(num, 21, False, 42, mx, track)
+            a = rng.choice(universe, 120000); b = rng.choice(universe, 90000)
+            ga.add_many(a); oa.add_many(a)
+            gb.add_many(b); ob.add_many(b)
+            same_state(ga, oa); same_state(gb, ob)
+            assert len(ga) + len(gb) >= (1 << 16)
+            ga.merge(gb); oa.merge(ob)
+            same_state(ga, oa)
+            assert ga.track_abundance
