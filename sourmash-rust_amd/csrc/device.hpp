@@ -36,14 +36,6 @@ struct DeviceBuffer {
   ~DeviceBuffer();
 };
 
-// pinned host staging buffer for H2D/D2H copies of the legacy (host-pointer) ABI
-struct PinnedBuffer {
-  void* ptr = nullptr;
-  size_t bytes = 0;
-  void ensure(size_t need);
-  ~PinnedBuffer();
-};
-
 struct KernelTimes {
   double ms = 0.0;
   uint64_t launches = 0;

@@ -49,10 +49,10 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
 // pre-filled with the record ends.  (reference src/lib.rs:795-804 _checkdna, applied per byte)
 void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s);
 
-// hash every window of `win` bytes inside each segment of a byte buffer (protein arm second
-// phase, reference src/lib.rs:289-300), or whole segments when win == 0 (add_word / hash_murmur,
-// reference src/lib.rs:247-250, src/ffi.rs:15-24).  Output: out[i] for whole-segment mode, the
-// candidate sink otherwise.
+// launch_hash_segments: murmur64 of whole byte strings (add_word / hash_murmur, reference
+// src/lib.rs:247-250, src/ffi.rs:15-24) -> out[i].
+// launch_hash_windows: every window of `win` kept residues inside each segment of the translated
+// buffer (protein arm second phase, reference src/lib.rs:289-300) -> candidate sink.
 void launch_hash_segments(const uint8_t* bytes, const uint64_t* seg_offsets, uint32_t nseg,
                           uint64_t seed, uint64_t* out, hipStream_t s);
 void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* seg_offsets,
