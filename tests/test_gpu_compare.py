@@ -198,3 +198,32 @@ def test_matrix_at_benchmark_size_properties(pkg):
     assert (sub["common"].cpu().numpy() == out["common"].cpu().numpy()[:37]).all()
     # same-family pairs share hashes, different families do not
     assert j[0, 50] > 0.2 and j[0, 1] == 0.0
+
+
+def test_matrix_at_c4_size_properties(pkg):
+    """C4 at full size on one GPU (10 000 x 10 000, num=2000): symmetry, unit diagonal, constant
+    size, family structure, and agreement of a row sample with the wavefront-per-pair kernel."""
+    import os
+    import torch
+    from sourmash_rust_amd import synth
+    n = 10000
+    sigs = synth.family_signatures(0, n, num=2000, seed=4)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
+    out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard", "common"))
+    j = out["jaccard"]
+    assert bool((j == j.T).all()) and bool((j.diagonal() == 1.0).all())
+    # size == num everywhere: jaccard is exactly common / 2000 (IEEE division; checked with numpy on
+    # the host -- torch's GPU division by a scalar multiplies by the reciprocal)
+    assert (out["common"][:600].cpu().numpy().astype(np.float64) / 2000.0 == j[:600].cpu().numpy()).all()
+    fam = torch.arange(n, device="cuda") % 50
+    same = fam[:, None] == fam[None, :]
+    assert float(j[same].min()) > 0.2 and float(j[~same].max()) < 0.01
+    rows = torch.tensor([0, 1, 4999, 9999], device="cuda")
+    sub_t = t[rows].contiguous()
+    os.environ["SOURMASH_AMD_NO_TILED"] = "1"
+    try:
+        sub = pkg.matrix.compare_block_dev(sub_t, off[:5], t, off, 2000, want=("jaccard",))
+    finally:
+        del os.environ["SOURMASH_AMD_NO_TILED"]
+    assert bool((sub["jaccard"] == j[rows]).all())

@@ -258,12 +258,12 @@ def test_device_resident_input_and_generator(pkg, coracle):
 
 
 def test_full_size_properties(pkg, coracle):
-    """Size-independent checks at a size the oracle cannot finish quickly (256 MB): chunking is
+    """Size-independent checks at a size the oracle cannot finish quickly (2 GB): chunking is
     exact (sketching two halves with k-1 overlap and merging == sketching the whole) and the
     abundance total equals the number of retained k-mer occurrences."""
     import ctypes as C
     import torch
-    n = 256 * 1024 * 1024
+    n = 2 * 1024 * 1024 * 1024
     mx = 18446744073709552
     buf = torch.empty(n, dtype=torch.uint8, device="cuda")
     pkg.lib().smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, n, 2, 0, C.c_void_p(0))
