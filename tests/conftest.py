@@ -72,6 +72,9 @@ def sorted_sketch(sk):
 
 @pytest.fixture(scope="session")
 def pkg():
-    """The product package (sourmash-rust_amd/)."""
-    from __graft_entry__ import load_package
-    return load_package()
+    """The product package (sourmash-rust_amd/).  Built in-tree on first use (hipcc cross-compiles
+    gfx950 without a GPU); on the GPU box the prebuilt .so travels with the snapshot."""
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "sourmash-rust_amd", "lib", "libsourmash_amd.so")):
+        ge.build()
+    return ge.load_package()
