@@ -63,7 +63,7 @@ void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* s
 // entries, nseg = 6*nrec) gives where each (record, frame, strand) segment lives in `residues`;
 // unknown codons are written as 0xFF and skipped by launch_hash_windows; bad_utf8[seg] is set when
 // a codon chunk is not valid UTF-8 (the reference panics there).
-void launch_translate(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t nseg, uint64_t total,
+void launch_translate(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t nseg, uint64_t total, uint32_t ksize,
                       uint8_t* residues, uint32_t* bad_utf8, hipStream_t s);
 
 // hashes[lo..hi) that are <= thr go to the sink with their index as stream position

@@ -102,11 +102,13 @@ __device__ __forceinline__ void stage_emit(const Stage& st, const CandSink& sink
   if (slot < st.cap) { st.hash[slot] = h; if (sink.pos) st.pos[slot] = pos; }
   else emit(sink, h, pos);                          // stage full: straight to the global sink
 }
-// all threads of the workgroup must call this (it synchronises)
-__device__ __forceinline__ void stage_flush(const Stage& st, const CandSink& sink, int tid, int nthreads) {
+// all threads of the workgroup must call this (it synchronises).  Nothing is written while fewer
+// than `at_least` survivors are staged (0 = flush whatever is there).
+__device__ __forceinline__ void stage_flush(const Stage& st, const CandSink& sink, int tid, int nthreads,
+                                            uint32_t at_least = 0) {
   __syncthreads();
   const uint32_t staged = min(st.ctl[0], st.cap);
-  if (staged) {
+  if (staged && staged >= at_least) {
     if (tid == 0) {
       unsigned long long base = atomicAdd(sink.count, (unsigned long long)staged);
       st.ctl[2] = (uint32_t)base; st.ctl[3] = (uint32_t)(base >> 32);
@@ -428,57 +430,95 @@ __device__ __forceinline__ bool utf8_ok3(uint32_t a, uint32_t c, uint32_t d) {
   return false;
 }
 
-__device__ __forceinline__ uint32_t translate_one(const SeqBatch& b, uint64_t rs, uint64_t rl, uint32_t f, uint64_t j,
-                                                  uint32_t* bad_flag) {
-  const uint32_t frame = f >> 1;
-  uint32_t c0, c1, c2;
-  if ((f & 1) == 0) {
-    const uint8_t* s = b.seq + rs + frame + 3 * j;
-    c0 = upper(s[0]); c1 = upper(s[1]); c2 = upper(s[2]);
-  } else {
-    const uint8_t* s = b.seq + rs + (rl - 1 - frame - 3 * j);
-    c0 = comp_upper(upper(s[0])); c1 = comp_upper(upper(*(s - 1))); c2 = comp_upper(upper(*(s - 2)));
-  }
-  if ((c0 | c1 | c2) & 0x80u) {
-    if (!utf8_ok3(c0, c1, c2)) *bad_flag = 1;
-  }
-  const int i0 = tcag(c0), i1 = tcag(c1), i2 = tcag(c2);
-  return (i0 < 0 || i1 < 0 || i2 < 0) ? kDropped : (uint32_t)(uint8_t)kCodonAA[16 * i0 + 4 * i1 + i2];
-}
+// Six-frame translation in ONE read of the sequence.  Every base position p of a record is the first
+// base of exactly one forward codon (frame p mod 3, residue p/3) and the last-read base of exactly one
+// reverse-complement codon (frame (len-1-p) mod 3), so one lane per base position produces both
+// from the five bytes p-2 .. p+2, served from an LDS tile that the workgroup loaded with coalesced
+// 16-byte reads.  Segment order in the residue buffer: reference src/lib.rs:280-300.
+constexpr int kTrThreads = 256;
+// 3 consecutive bases per lane: at a given q all lanes of a wave are in the same frame and their
+// residue indices are consecutive, so the byte stores of a wave fall in one contiguous run per frame
+constexpr int kTrPerThread = 3;
+constexpr int kTrTile = kTrThreads * kTrPerThread;  // bases per workgroup tile
 
-// one lane translates four consecutive residues (one dword store); a group that straddles two
-// segments resolves each residue separately
-__global__ __launch_bounds__(256) void k_translate(SeqBatch b, const uint64_t* __restrict__ seg_off,
-                                                   uint32_t nseg, uint8_t* __restrict__ res,
-                                                   uint32_t* __restrict__ bad_utf8) {
-  const uint64_t total = seg_off[nseg];
-  const uint64_t ngroups = (total + 3) / 4;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t gi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
-    const uint64_t g = gi * 4;
-    uint32_t seg = find_record(seg_off, nseg, g);
-    uint64_t sbeg = seg_off[seg], send = seg_off[seg + 1];
-    uint32_t r = seg / 6, f = seg % 6;
-    uint64_t rs = b.starts ? b.starts[r] : 0;
-    uint64_t rl = (b.starts ? b.starts[r + 1] : b.len) - rs;
-    uint32_t packed = 0, bad = 0;
+__global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint64_t* __restrict__ seg_off,
+                                                          uint32_t nseg, uint32_t ksize, uint8_t* __restrict__ res,
+                                                          uint32_t* __restrict__ bad_utf8) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kTrTile + 64];   // raw bytes (only the UTF-8 check reads them)
+  __shared__ __attribute__((aligned(16))) uint8_t code[kTrTile + 64];   // T0 C1 A2 G3 (complement = ^2), 0x80 = not a base
+  __shared__ uint8_t lut_code[256];
+  __shared__ uint8_t lut_aa[64];
+  const int tid = threadIdx.x;
+  {
+    // byte -> base code, case-insensitive (the reference upper-cases first, src/lib.rs:253-256)
+    const uint32_t c = (uint32_t)tid, u = upper(c);
+    const int t = tcag(u);
+    lut_code[tid] = t < 0 ? 0x80u : (uint8_t)t;
+    if (tid < 64) lut_aa[tid] = (uint8_t)kCodonAA[tid];
+  }
+  const uint64_t ntiles = (b.len + kTrTile - 1) / kTrTile;
+  const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
+  for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const uint64_t T0 = tix * kTrTile;
+    // tile bytes [T0 - 16, T0 + kTrTile + 16) relative to an aligned base (a halo of 2 each side is needed)
+    const uintptr_t g0 = (uintptr_t)(b.seq + T0);
+    const uintptr_t ga = (g0 & ~(uintptr_t)15) - 16;
+    const uint32_t m = (uint32_t)(g0 - ga);  // 16..31: offset of position T0 inside the tile
+    __syncthreads();
+    for (uint32_t c = tid; c < (kTrTile + 64) / 16; c += kTrThreads) {
+      const uintptr_t addr = ga + ((uintptr_t)c << 4);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (addr >= ((uintptr_t)b.seq & ~(uintptr_t)15) && addr < gend) v = *reinterpret_cast<const uint4*>(addr);
+      *reinterpret_cast<uint4*>(tile + (c << 4)) = v;
+      uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint64_t p = g + q;
-      if (p >= total) break;
-      while (p >= send) {  // next (possibly empty) segment
-        if (bad) { atomicOr(&bad_utf8[seg], 1u); bad = 0; }
-        seg++;
-        sbeg = send; send = seg_off[seg + 1];
-        r = seg / 6; f = seg % 6;
-        rs = b.starts ? b.starts[r] : 0;
-        rl = (b.starts ? b.starts[r + 1] : b.len) - rs;
-      }
-      packed |= translate_one(b, rs, rl, f, p - sbeg, &bad) << (8 * q);
+      for (int d = 0; d < 4; d++)
+        o[d] = (uint32_t)lut_code[w[d] & 0xff] | ((uint32_t)lut_code[(w[d] >> 8) & 0xff] << 8) |
+               ((uint32_t)lut_code[(w[d] >> 16) & 0xff] << 16) | ((uint32_t)lut_code[w[d] >> 24] << 24);
+      *reinterpret_cast<uint4*>(code + (c << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    if (bad) atomicOr(&bad_utf8[seg], 1u);
-    if (g + 4 <= total) *reinterpret_cast<uint32_t*>(res + g) = packed;
-    else for (uint64_t p = g; p < total; p++) res[p] = (uint8_t)(packed >> (8 * (p - g)));
+    __syncthreads();
+    // record of the lane's first position; lanes then step forward (records are walked in order)
+    uint32_t rec = 0;
+    uint64_t rs = 0, re = b.len;
+    const uint64_t pfirst = T0 + (uint64_t)tid * kTrPerThread;
+    if (b.starts && pfirst < b.len) {
+      rec = find_record(b.starts, b.nrec, pfirst);
+      rs = b.starts[rec]; re = b.starts[rec + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < kTrPerThread; q++) {
+      const uint64_t p = pfirst + q;
+      if (p >= b.len) break;
+      while (p >= re) { rec++; rs = b.starts[rec]; re = b.starts[rec + 1]; }
+      const uint64_t rl = re - rs, o = p - rs;
+      if (rl < ksize) continue;  // reference src/lib.rs:257: shorter records add nothing
+      const uint32_t x = m + (uint32_t)(p - T0);
+      const uint32_t k0 = code[x];
+      // forward codon starting at o
+      if (o + 2 < rl) {
+        const uint32_t k1 = code[x + 1], k2 = code[x + 2];
+        const uint32_t seg = 6 * rec + 2 * (uint32_t)(o % 3);
+        const uint32_t bad = (k0 | k1 | k2) & 0x80u;
+        if (bad) {
+          const uint32_t c0 = upper(tile[x]), c1 = upper(tile[x + 1]), c2 = upper(tile[x + 2]);
+          if (((c0 | c1 | c2) & 0x80u) && !utf8_ok3(c0, c1, c2)) atomicOr(&bad_utf8[seg], 1u);
+        }
+        res[seg_off[seg] + o / 3] = bad ? (uint8_t)kDropped : lut_aa[(k0 << 4) | (k1 << 2) | k2];
+      }
+      // reverse-complement codon whose first base is the complement of position o
+      if (o >= 2) {
+        const uint32_t k1 = code[x - 1], k2 = code[x - 2];
+        const uint64_t back = rl - 1 - o;
+        const uint32_t seg = 6 * rec + 2 * (uint32_t)(back % 3) + 1;
+        const uint32_t bad = (k0 | k1 | k2) & 0x80u;
+        if (bad) {
+          const uint32_t d0 = comp_upper(upper(tile[x])), d1 = comp_upper(upper(tile[x - 1])), d2 = comp_upper(upper(tile[x - 2]));
+          if (((d0 | d1 | d2) & 0x80u) && !utf8_ok3(d0, d1, d2)) atomicOr(&bad_utf8[seg], 1u);
+        }
+        res[seg_off[seg] + back / 3] = bad ? (uint8_t)kDropped : lut_aa[(((k0 << 4) | (k1 << 2) | k2)) ^ 0x2a];
+      }
+    }
   }
 }
 
@@ -502,10 +542,13 @@ __device__ __forceinline__ void hash_window_slow(const uint8_t* __restrict__ res
 constexpr int kWinRun = 8;
 __device__ __forceinline__ void hash_run(const uint8_t* __restrict__ res, const uint64_t* __restrict__ seg_off,
                                          uint32_t nseg, uint32_t win, const HashParams& hp, uint64_t thr,
-                                         const CandSink& sink, const Stage& stage, bool aligned, uint64_t g0) {
+                                         const CandSink& sink, const Stage& stage, bool aligned, uint64_t g0,
+                                         uint64_t blk_seg_end) {
   {
-    const uint32_t seg = find_record(seg_off, nseg, g0);
-    const uint64_t end = seg_off[seg + 1];
+    // the workgroup's first segment was looked up once with uniform (scalar) loads; only lanes
+    // past its end search for their own
+    uint64_t end = blk_seg_end;
+    if (g0 >= end) end = seg_off[find_record(seg_off, nseg, g0) + 1];
     const uint64_t last = g0 + kWinRun < hp.range_hi ? g0 + kWinRun : hp.range_hi;  // window starts [g0, last)
     bool fast = aligned && last == g0 + kWinRun && g0 + kWinRun - 1 + win <= end;
     uint32_t D[12];  // 48 bytes: 8 starts + up to 32-byte windows, little-endian dwords
@@ -581,9 +624,13 @@ __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict_
   // the loop bound is the same for every lane of the workgroup: the flush inside synchronises
   for (uint64_t b0 = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x * kWinRun; b0 < hp.range_hi; b0 += stride) {
     const uint64_t g0 = b0 + (uint64_t)threadIdx.x * kWinRun;
-    if (g0 < hp.range_hi) hash_run(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0);
-    stage_flush(stage, sink, threadIdx.x, blockDim.x);
+    const uint64_t blk_seg_end = seg_off[find_record(seg_off, nseg, b0) + 1];   // b0 is uniform
+    if (g0 < hp.range_hi) hash_run(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0, blk_seg_end);
+    // a pass covers only 2048 windows: flushing (a returning global atomic) every pass would cost
+    // more than the hashing; wait until the stage is half full
+    stage_flush(stage, sink, threadIdx.x, blockDim.x, stage_cap / 2);
   }
+  stage_flush(stage, sink, threadIdx.x, blockDim.x);
 }
 
 __global__ __launch_bounds__(256) void k_hash_segments(const uint8_t* __restrict__ bytes,
@@ -718,10 +765,10 @@ void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s)
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_translate(const SeqBatch& b, const uint64_t* seg_off, uint32_t nseg, uint64_t total,
+void launch_translate(const SeqBatch& b, const uint64_t* seg_off, uint32_t nseg, uint64_t total, uint32_t ksize,
                       uint8_t* residues, uint32_t* bad_utf8, hipStream_t s) {
   if (total == 0) return;
-  hipLaunchKernelGGL(k_translate, dim3(grid_for((total + 3) / 4, 256, 16384)), dim3(256), 0, s, b, seg_off, nseg,
+  hipLaunchKernelGGL(k_translate, dim3(grid_for(b.len, kTrTile, 16384)), dim3(kTrThreads), 0, s, b, seg_off, nseg, ksize,
                      residues, bad_utf8);
   HIP_CHECK(hipGetLastError());
 }
