@@ -301,6 +301,7 @@ SourmashStr signature_save_json(Signature* ptr) {
 KmerMinHash** signature_get_mhs(Signature* ptr, uintptr_t* size) {
   return pad<KmerMinHash**>([&] {
     require(ptr, "ptr");
+    require(size, "size");
     std::vector<KmerMinHash*> v;
     for (auto& mh : ptr->signatures) v.push_back(new KmerMinHash(mh));
     return leak_array(v, size);
@@ -319,6 +320,7 @@ SourmashStr signatures_save_buffer(Signature** ptr, uintptr_t size) {
 }
 
 static Signature** load_common(const std::string& data, uintptr_t ksize, const char* select_moltype, uintptr_t* size) {
+  require(size, "size");
   if (select_moltype && !utf8_cstr_ok(select_moltype)) throw Error(smh::kUtf8Error, "invalid utf-8 sequence");
   std::vector<smh::Signature> sigs = smh::load_signatures(data.data(), data.size(), ksize, select_moltype);
   std::vector<Signature*> v;
