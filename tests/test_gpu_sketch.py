@@ -366,3 +366,57 @@ def test_bulk_add_many_and_device_merge(pkg, coracle):
             ga.merge(gb); oa.merge(ob)
             same_state(ga, oa)
             assert ga.track_abundance
+
+
+def test_degenerate_ksize_panics_like_the_reference(pkg, coracle):
+    # slice::windows(0) panics in the reference: DNA with ksize 0, protein with ksize < 3 (Q8)
+    for case in [(10, 0, False, 42, 0, False), (10, 2, True, 42, 0, False), (10, 1, True, 42, 0, True)]:
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        with pytest.raises(pkg.SourmashError) as eg:
+            g.add_sequence(b"ACGTACGTAC", True)
+        with pytest.raises(coracle.OracleError) as eo:
+            o.add_sequence(b"ACGTACGTAC", True)
+        assert eg.value.code == eo.value.code == 1
+        same_state(g, o)
+    # shorter than ksize: silently nothing (reference src/lib.rs:257), also for protein
+    for case in [(10, 21, False, 42, 0, False), (10, 21, True, 42, 0, False)]:
+        g = pkg.KmerMinHash(*case)
+        g.add_sequence(b"ACGTACGTAC", False)
+        assert g.mins == []
+
+
+def test_concurrent_callers(pkg, coracle):
+    """Distinct sketches used from distinct threads (the reference's threading contract): the
+    engine serialises device work, the error slot is per thread."""
+    import threading
+    seqs = [bytes(coracle.synth_dna(i * 100000, 60000, 40 + i, 0)) for i in range(6)]
+    exp = []
+    for s_ in seqs:
+        o = coracle.MinHash(200, 21, False, 42, 0, True)
+        o.add_sequence(s_, True)
+        exp.append((o.mins, o.abunds))
+    got, errs = [None] * 6, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                g = pkg.KmerMinHash(200, 21, False, 42, 0, True)
+                g.add_sequence(seqs[i], True)
+                got[i] = (g.mins, g.abunds, g.compare(g))
+            if i % 2 == 0:   # an error on this thread must not leak to the others
+                bad = pkg.KmerMinHash(5, 4)
+                try:
+                    bad.add_sequence(b"ACGTNACGT", False)
+                except pkg.SourmashError as e:
+                    assert e.code == 1101
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(6):
+        assert got[i][0] == exp[i][0] and got[i][1] == exp[i][1] and got[i][2] == 1.0
