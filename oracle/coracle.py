@@ -123,7 +123,8 @@ class MinHash:
         seq = bytes(seq)
         buf = C.create_string_buffer(max(64, self.ksize + 1))
         st = self._L.omh_add_sequence(self._p, seq, len(seq), int(force), buf, len(buf))
-        self._chk(st, buf.value.decode("latin-1"))
+        # the offending k-mer is exactly ksize bytes and may hold NULs: take it by length
+        self._chk(st, buf.raw[:self.ksize].decode("latin-1") if st == 1101 else "")
 
     def merge(self, other):
         self._chk(self._L.omh_merge(self._p, other._p))

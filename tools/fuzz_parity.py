@@ -1,0 +1,159 @@
+"""Randomised GPU-vs-oracle parity fuzzer (run on the GPU box): python tools/fuzz_parity.py SECONDS [SEED]
+Sketch side: random parameters (k 1..70, num / scaled / both / neither, abundance, protein), random
+sequences of mixed composition (repeats, N runs, lowercase, arbitrary bytes), single calls and
+multi-record batches, repeated adds on one object.  Compare side: random ragged sketch sets through
+the block compare.  Stops at the first mismatch and prints a reproducer."""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import torch  # noqa: E402,F401
+import coracle  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = random.Random(seed)
+print("fuzz seed", seed)
+
+
+def rand_seq(n):
+    mode = rng.choice(["dna", "dna", "dna", "lowmix", "repeat", "nruns", "bytes", "polyA"])
+    if mode == "polyA":
+        return bytes([rng.choice(b"ACGT")]) * n
+    if mode == "repeat":
+        unit = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 40)))
+        return (unit * (n // len(unit) + 1))[:n]
+    out = bytearray(rng.choice(b"ACGT") for _ in range(n))
+    if mode == "lowmix":
+        for i in range(n):
+            if rng.random() < 0.3:
+                out[i] |= 0x20
+    if mode == "nruns":
+        for _ in range(rng.randint(0, 5)):
+            p = rng.randrange(max(1, n)); ln = rng.randint(1, 60)
+            out[p:p + ln] = b"N" * min(ln, n - p)
+    if mode == "bytes":
+        for _ in range(rng.randint(1, 6)):
+            if n:
+                out[rng.randrange(n)] = rng.choice([0, 1, 0x20, 0x2a, 0x4e, 0x7f, 0x80, 0xc3, 0xa9, 0xe2, 0x82, 0xac, 0xff])
+    return bytes(out)
+
+
+def gmsg(e):   # the offending k-mer as bytes (the library's message is UTF-8 like the reference's String)
+    return e.message.split(": ", 1)[-1].encode("utf-8") if e.code == 1101 else b""
+
+
+def omsg(e):   # the oracle binding hands the raw bytes back as latin-1
+    return e.message.encode("latin-1") if e.code == 1101 else b""
+
+
+def state(m):
+    return (m.mins, m.abunds)
+
+
+def run_both(g, o, fn):
+    eg = eo = None
+    try:
+        fn(g)
+    except pkg.SourmashError as e:
+        eg = (e.code, gmsg(e))
+    try:
+        fn(o)
+    except coracle.OracleError as e:
+        eo = (e.code, omsg(e))
+    return eg, eo
+
+
+t_end = time.time() + budget
+n_sk = n_cmp = 0
+t_print = time.time()
+while time.time() < t_end:
+    if time.time() - t_print > 30:
+        t_print = time.time()
+        print("... %d sketch cases, %d compare blocks so far" % (n_sk, n_cmp), flush=True)
+    if rng.random() < 0.75:
+        prot = rng.random() < 0.25
+        k = rng.choice([1, 2, 3, 4, 5, 7, 9, 11, 15, 16, 17, 20, 21, 24, 25, 27, 30, 31, 32, 33, 40, 48, 51, 63, 64, 65, 70])
+        if prot and k < 3:
+            k = 3
+        style = rng.choice(["num", "num", "scaled", "scaled", "both", "neither"])
+        num = rng.choice([1, 2, 5, 20, 100, 500]) if style in ("num", "both") else 0
+        mx = rng.choice([1 << 63, 1 << 61, 1 << 58, (1 << 64) // 1000]) if style in ("scaled", "both") else 0
+        case = (num, k, prot, rng.choice([42, 42, 7, (1 << 40) + 3]), mx, rng.random() < 0.6)
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        steps = []
+        for _ in range(rng.randint(1, 3)):
+            force = rng.random() < 0.6
+            if rng.random() < 0.3:
+                recs = [rand_seq(rng.choice([0, 1, k - 1 if k > 1 else 1, k, k + 1, 50, 151, 400])) for _ in range(rng.randint(1, 40))]
+                steps.append(("batch", recs, force))
+                eg = None
+                try:
+                    g.add_sequences(recs, force)
+                except pkg.SourmashError as e:
+                    eg = (e.code, gmsg(e))
+                eo = None
+                for r in recs:
+                    try:
+                        o.add_sequence(r, force)
+                    except coracle.OracleError as e:
+                        if eo is None:
+                            eo = (e.code, omsg(e))
+            else:
+                n = rng.choice([0, 1, k, k + 3, 100, 1000, 5000, 70000, 300000])
+                if style == "neither" or style == "both":
+                    n = min(n, 5000)
+                s_ = rand_seq(n)
+                steps.append(("single", s_, force))
+                eg, eo = run_both(g, o, lambda m: m.add_sequence(s_, force))
+            if eg != eo or state(g) != state(o):
+                print("SKETCH MISMATCH case", case, "errors", eg, eo)
+                for st in steps:
+                    print("  step", st[0], "force", st[2], "len", [len(x) for x in st[1]] if st[0] == "batch" else len(st[1]))
+                import pickle
+                pickle.dump((case, steps), open("gpurun_out/fuzz_fail.pkl", "wb"))
+                sys.exit(1)
+        n_sk += 1
+    else:
+        uni = np.unique(np.array([rng.getrandbits(63) for _ in range(rng.choice([50, 2000, 20000]))], dtype=np.uint64))
+        nrow, ncol = rng.randint(1, 90), rng.randint(1, 140)
+        def mk(cnt):
+            out = []
+            for _ in range(cnt):
+                sz = min(len(uni), rng.choice([0, 1, 3, 50, 300, 300, 1500]))
+                out.append(np.sort(np.random.RandomState(rng.getrandbits(31)).choice(uni, sz, replace=False)))
+            return out
+        rows, cols = mk(nrow), mk(ncol)
+        nums = [rng.choice([0, 1, 10, 300, 5000]) for _ in rows]
+        same_num = rng.random() < 0.5
+        if same_num:
+            nums = [nums[0]] * nrow
+        gm, om = [], []
+        for r, nn in zip(rows, nums):
+            a, b = pkg.KmerMinHash(nn, 21, False, 42, 0), coracle.MinHash(nn, 21, False, 42, 0)
+            for h in r:
+                a.mins_push(int(h)); b.mins_push(int(h))
+            gm.append(a); om.append(b)
+        gc, oc = [], []
+        for c in cols:
+            a, b = pkg.KmerMinHash(7, 21, False, 42, 0), coracle.MinHash(7, 21, False, 42, 0)
+            for h in c:
+                a.mins_push(int(h)); b.mins_push(int(h))
+            gc.append(a); oc.append(b)
+        out = pkg.matrix.compare_block(gm, gc, want=("jaccard", "common", "size", "count_common"))
+        for i in range(nrow):
+            for j in range(ncol):
+                c, s_ = om[i].intersection_size(oc[j])
+                if (int(out["common"][i, j]), int(out["size"][i, j])) != (c, s_) or out["jaccard"][i, j] != om[i].compare(oc[j]) \
+                        or int(out["count_common"][i, j]) != om[i].count_common(oc[j]):
+                    print("COMPARE MISMATCH", nrow, ncol, i, j, nums[i], len(rows[i]), len(cols[j]))
+                    sys.exit(1)
+        n_cmp += 1
+print("fuzz ok: %d sketch cases, %d compare blocks, seed %d" % (n_sk, n_cmp, seed))
