@@ -161,7 +161,12 @@ def main():
             diag_ok = bool((j[idx, idx + lo] == 1.0).all().item())
         compare = {"metric": "signature pairs compared/sec (ordered pairs, num=2000)", "value": n_sig * n_sig / cdt,
                    "unit": "pairs/s", "n_signatures": n_sig, "seconds": cdt, "self_jaccard_is_1": diag_ok,
-                   "effective_GBps": n_sig * n_sig * 32008 / cdt / 1e9}
+                   "effective_GBps": n_sig * n_sig * 32008 / cdt / 1e9,
+                   "roofline": {"bound": "hbm", "achieved": n_sig * n_sig * 32008 / cdt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": n_sig * n_sig * 32008 / cdt / 1e9 / HBM_PEAK_GBS,
+                                "label": "EFFECTIVE bytes (32 008 B per ordered pair, SURVEY.md 8d): tiles are served from LDS/L2, "
+                                         "compulsory HBM traffic is N*16 KB in + N^2*8 B out; the kernel is bound by VALU issue and "
+                                         "LDS latency (DESIGN.md 3.4)"}}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
