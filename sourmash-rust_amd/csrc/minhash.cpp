@@ -26,7 +26,7 @@ KmerMinHash::KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint
 KmerMinHash::KmerMinHash(const KmerMinHash& o)
     : num(o.num), ksize(o.ksize), is_protein(o.is_protein), seed(o.seed), max_hash(o.max_hash),
       has_abunds(o.has_abunds) {
-  o.materialize();
+  o.materialize();   // also drains o's queued sequences
   mins = o.mins;
   abunds = o.abunds;
 }
@@ -34,12 +34,14 @@ KmerMinHash::KmerMinHash(const KmerMinHash& o)
 KmerMinHash& KmerMinHash::operator=(const KmerMinHash& o) {
   if (this == &o) return *this;
   o.materialize();
+  pend_seq.clear(); pend_off.clear();
   num = o.num; ksize = o.ksize; is_protein = o.is_protein; seed = o.seed; max_hash = o.max_hash;
   has_abunds = o.has_abunds; mins = o.mins; abunds = o.abunds; dev.reset();
   return *this;
 }
 
 void KmerMinHash::materialize() const {
+  flush_pending();
   if (!dev) return;
   Device& d = Device::get();
   std::lock_guard<std::recursive_mutex> lock(d.mutex());
@@ -570,7 +572,7 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
   Engine& E = Engine::get();
   hipStream_t s = stream ? stream : dev.stream();
-  materialize();
+  materialize();   // drains queued small sequences first: stream order is part of the semantics
 
   // records shorter than ksize add nothing (reference src/lib.rs:257)
   bool any_long = false;
@@ -674,15 +676,79 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
   }
 }
 
-void KmerMinHash::add_sequence(const uint8_t* seq, size_t len, bool force) {
-  if (len < ksize) return;  // reference src/lib.rs:257
+namespace {
+constexpr size_t kLazyMaxRecord = 1u << 20;   // calls at least this long go straight to the device
+constexpr size_t kLazyFlushBytes = 8u << 20;  // queued bytes that trigger a batch
+}  // namespace
+
+void KmerMinHash::flush_pending() const {
+  if (pend_off.size() <= 1) { pend_seq.clear(); pend_off.clear(); return; }
+  // move the queue out first: add_sequences_device() calls back into materialize()
+  std::vector<uint8_t> seqs;
+  std::vector<uint64_t> offs;
+  seqs.swap(pend_seq);
+  offs.swap(pend_off);
   Device& dev = Device::get();
   Engine& E = Engine::get();
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
-  E.seqbuf.ensure(len + 64);
-  HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq, len, hipMemcpyHostToDevice, dev.stream()));
-  const uint64_t off[2] = {0, (uint64_t)len};
-  add_sequences_device(E.seqbuf.as<uint8_t>(), len, off, 1, force, dev.stream(), nullptr);
+  E.seqbuf.ensure(seqs.size() + 64);
+  HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seqs.data(), seqs.size(), hipMemcpyHostToDevice, dev.stream()));
+  // queued DNA records were cut at their first invalid byte when force was false, so force=true
+  // reproduces both settings; protein ignores force (reference src/lib.rs:275-302)
+  const_cast<KmerMinHash*>(this)->add_sequences_device(E.seqbuf.as<uint8_t>(), seqs.size(), offs.data(),
+                                                       (uint32_t)(offs.size() - 1), true, dev.stream(), nullptr);
+}
+
+void KmerMinHash::add_sequence(const uint8_t* seq, size_t len, bool force) {
+  if (len < ksize) return;  // reference src/lib.rs:257
+  if (!is_protein && ksize == 0) throw_panic("window size must be non-zero");
+  if (is_protein && ksize / 3 == 0) throw_panic("window size must be non-zero");
+  Device& dev = Device::get();   // raises here, not at the deferred batch, when there is no GPU
+  bool direct = len >= kLazyMaxRecord || pend_off.size() >= (1u << 20);
+  size_t use = len;
+  bool have_err = false;
+  Error err(kNoError, "");
+  if (!direct && !is_protein && !force) {
+    // force=false: the call itself must report the first window holding a non-ACGT byte (Q1); the
+    // windows before it are still added, i.e. the record is cut at that byte
+    for (size_t i = 0; i < len; i++) {
+      const uint8_t u = seq[i] & 0xDFu;
+      if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) {
+        const size_t ws = i + 1 >= (size_t)ksize ? i + 1 - ksize : 0;
+        std::vector<uint8_t> kmer(seq + ws, seq + ws + ksize);
+        for (auto& c : kmer) if (c >= 'a' && c <= 'z') c -= 32;
+        have_err = true;
+        if (!utf8_valid(kmer.data(), kmer.size()))
+          err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: FromUtf8Error");
+        else
+          err = Error(kInvalidDNA, "invalid DNA character in input k-mer: " + std::string(kmer.begin(), kmer.end()));
+        use = i;
+        break;
+      }
+    }
+  }
+  if (!direct && is_protein) {
+    // a codon chunk that is not UTF-8 panics in the reference: take the synchronous path, which
+    // reproduces which frames were added before the panic
+    for (size_t i = 0; i < len; i++) if (seq[i] & 0x80u) { direct = true; break; }
+  }
+  if (direct) {
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    flush_pending();
+    Engine& E = Engine::get();
+    E.seqbuf.ensure(len + 64);
+    HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq, len, hipMemcpyHostToDevice, dev.stream()));
+    const uint64_t off[2] = {0, (uint64_t)len};
+    add_sequences_device(E.seqbuf.as<uint8_t>(), len, off, 1, force, dev.stream(), nullptr);
+    return;
+  }
+  if (use >= ksize) {
+    if (pend_off.empty()) pend_off.push_back(0);
+    pend_seq.insert(pend_seq.end(), seq, seq + use);
+    pend_off.push_back(pend_seq.size());
+    if (pend_seq.size() >= kLazyFlushBytes) flush_pending();
+  }
+  if (have_err) throw err;
 }
 
 // ------------------------------------------------------------------------------------

@@ -47,6 +47,12 @@ struct KmerMinHash {
   bool has_abunds = false;         // Option<Vec<u64>>::is_some()
   mutable std::vector<uint64_t> abunds;
   mutable std::shared_ptr<DeviceSketch> dev;  // non-null: the state lives here, mins/abunds are empty
+  // Small add_sequence calls (a read at a time through the legacy ABI) are queued here and hashed
+  // in one device batch when the state is next observed or the queue is large: same result as one
+  // launch per call, without the per-launch latency.  Errors are still raised by the call itself.
+  mutable std::vector<uint8_t> pend_seq;
+  mutable std::vector<uint64_t> pend_off;
+  void flush_pending() const;
 
   KmerMinHash() { mins.reserve(1000); }  // Default, src/lib.rs:48-60
   KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track);  // 142-174
@@ -66,7 +72,7 @@ struct KmerMinHash {
   uint64_t count_common(const KmerMinHash& other) const;                 // 428-436 (device)
   void intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const;  // 470-499
   double compare(const KmerMinHash& other) const;                        // 501-508 (device)
-  size_t size() const { return dev ? (size_t)dev->n : mins.size(); }
+  size_t size() const { flush_pending(); return dev ? (size_t)dev->n : mins.size(); }
 
   // --- batch entry points (additive C ABI) ---
   // Records live in ONE device buffer; h_offsets has nrec+1 host entries.  Semantics: as if

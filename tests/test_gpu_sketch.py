@@ -420,3 +420,45 @@ def test_concurrent_callers(pkg, coracle):
     assert not errs, errs
     for i in range(6):
         assert got[i][0] == exp[i][0] and got[i][1] == exp[i][1] and got[i][2] == 1.0
+
+
+def test_read_at_a_time_through_the_legacy_abi(pkg, coracle):
+    """Thousands of small add_sequence calls are queued and hashed in device batches; the result and
+    every error must be what one call at a time gives, whatever is interleaved with them."""
+    import time
+    rng = random.Random(99)
+    for case in [(500, 21, False, 42, 0, True), (0, 31, False, 42, 1 << 58, True), (40, 15, True, 42, 0, True),
+                 (6, 5, False, 7, 1 << 62, True)]:
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        for i in range(1500):
+            r = rand_seq(rng, rng.choice([0, 10, 40, 151, 151, 151, 600]), bad=rng.choice([0, 0, 0, 0.01]))
+            force = rng.random() < 0.5
+            eg = eo = None
+            try:
+                g.add_sequence(r, force)
+            except pkg.SourmashError as e:
+                eg = (e.code, e.message.split(": ")[-1])
+            try:
+                o.add_sequence(r, force)
+            except coracle.OracleError as e:
+                eo = (e.code, e.message)
+            assert eg == eo
+            if i % 397 == 0:
+                h = rng.getrandbits(60)
+                g.add_hash(h); o.add_hash(h)          # scalar op in the middle: order must hold
+            if i % 501 == 0:
+                assert len(g) == len(o.mins)
+        same_state(g, o)
+    # and it is fast: 20 000 reads of 150 bp
+    reads = [rand_seq(rng, 150, bad=0.0) for _ in range(20000)]
+    g = pkg.KmerMinHash(0, 31, False, 42, (1 << 64) // 1000, False)
+    t0 = time.perf_counter()
+    for r in reads:
+        g.add_sequence(r, True)
+    n = len(g)
+    dt = time.perf_counter() - t0
+    o = coracle.MinHash(0, 31, False, 42, (1 << 64) // 1000, False)
+    for r in reads:
+        o.add_sequence(r, True)
+    assert g.mins == o.mins and n == len(o.mins)
+    assert dt < 2.0, "per-read calls must not pay a device launch each (took %.2f s)" % dt
