@@ -227,3 +227,42 @@ def test_matrix_at_c4_size_properties(pkg):
     finally:
         del os.environ["SOURMASH_AMD_NO_TILED"]
     assert bool((sub["jaccard"] == j[rows]).all())
+
+
+def test_end_to_end_genomes_to_matrix(pkg, coracle):
+    """Whole path as a caller would use it: sketch a set of related synthetic genomes through the
+    C ABI (one add_sequence per contig), wrap them in Signatures, write/read the .sig JSON, run the
+    all-vs-all block and the index-style find -- every number equal to the oracle's."""
+    from sourmash_rust_amd import signature as S
+    rng = random.Random(31)
+    base = bytearray(coracle.synth_dna(0, 120000, 77, 0))
+    genomes = []
+    for gi in range(24):
+        g = bytearray(base)
+        for _ in range(gi * 40):                       # point mutations: more for later genomes
+            p = rng.randrange(len(g)); g[p] = rng.choice(b"ACGT")
+        cut = sorted(rng.sample(range(1000, len(g) - 1000), 5))
+        contigs = [bytes(g[a:b]) for a, b in zip([0] + cut, cut + [len(g)])]
+        genomes.append(contigs)
+    gms, oms = [], []
+    for contigs in genomes:
+        gm, om = pkg.KmerMinHash(400, 31, False, 42, 0, True), coracle.MinHash(400, 31, False, 42, 0, True)
+        for c in contigs:
+            gm.add_sequence(c, False); om.add_sequence(c, False)
+        gms.append(gm); oms.append(om)
+    sigs = []
+    for i, gm in enumerate(gms):
+        sg = S.Signature(); sg.name = "genome%d" % i; sg.push_mh(gm); sigs.append(sg)
+    text = S.save_signatures(sigs)
+    back = S.load_signatures_buffer(text.encode(), ksize=31, moltype="DNA")
+    assert len(back) == 24 and all(b == s_ for b, s_ in zip(back, sigs))
+    loaded = [b.first_mh() for b in back]
+    assert all(l.mins == o.mins and l.abunds == o.abunds for l, o in zip(loaded, oms))
+    out = pkg.matrix.compare_block(loaded, loaded, want=("jaccard", "containment"))
+    for i in range(24):
+        for j in range(24):
+            assert out["jaccard"][i, j] == oms[i].compare(oms[j])
+            assert out["containment"][i, j] == oms[i].containment(oms[j])
+    assert out["jaccard"][0, 1] > out["jaccard"][0, 23] > 0          # similarity decays with mutations
+    hits = pkg.index.search_minhashes(loaded, loaded[0], 0.5)
+    assert hits == [i for i in range(24) if oms[i].compare(oms[0]) > 0.5] and 0 in hits
