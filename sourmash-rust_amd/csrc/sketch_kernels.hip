@@ -1,7 +1,7 @@
 // sketch_kernels.hip -- gfx950 kernels for KmerMinHash::add_sequence
 // (reference src/lib.rs:252-305) and its helpers:
 //
-//   k_dna_rolling<K>   DNA arm, ksize <= 64 (2 or 4 32-bit limbs per packed window).  One lane owns a run of R consecutive k-mer start
+//   k_dna_rolling<K>   DNA arm, ksize <= 128 (2, 4 or 8 32-bit limbs per packed window).  One lane owns a run of R consecutive k-mer start
 //                      positions; the tile is read from HBM once with coalesced 16-byte loads
 //                      and staged in LDS; each lane rolls two 2-bit packed windows (forward in
 //                      big- and little-endian digit order; the reverse complement is their
@@ -162,7 +162,7 @@ __device__ __forceinline__ uint64_t murmur_kmer(const uint32_t (&D)[4 * L], int 
 }
 
 // KT > 0: ksize fixed at compile time; KT == 0: any ksize the limb count allows, at run time.
-// L = 32-bit limbs of a packed window: 2 for ksize <= 32, 4 for ksize <= 64.
+// L = 32-bit limbs of a packed window: 2 for ksize <= 32, 4 for ksize <= 64, 8 for ksize <= 128.
 // THREADS lanes per workgroup share one LUT; HB = hashes computed together in one straight-line
 // block (independent murmur chains the scheduler can interleave).
 template <int KT, int THREADS, int HB, int L>
@@ -725,7 +725,7 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
   if (p.range_hi <= p.range_lo) return;
   const uint64_t span = p.range_hi - p.range_lo;
   dev.prof_begin(s);
-  if (p.ksize >= 1 && p.ksize <= 64 && !force_generic) {
+  if (p.ksize >= 1 && p.ksize <= 128 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
     const DnaCfg c = dna_cfg();
@@ -734,7 +734,8 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     const uint64_t tile = (uint64_t)c.threads << logR;
     const uint64_t ntiles = (span + tile - 1) / tile;
     int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
-    const uint32_t x_bytes = (uint32_t)tile + 160;
+    const int limbs = p.ksize <= 32 ? 2 : (p.ksize <= 64 ? 4 : 8);
+    const uint32_t x_bytes = (uint32_t)tile + 16 * limbs + 96;
     // LDS stage for the survivors of one tile: twice the expectation under a uniform hash, within
     // [128, 2048] entries; anything beyond goes straight to the global sink
     const uint64_t thr = p.thr;
@@ -747,7 +748,8 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     else if (p.ksize == 21) launch_rolling<21, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     else if (p.ksize == 51) launch_rolling<51, 4>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     else if (p.ksize <= 32) launch_rolling<0, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
-    else launch_rolling<0, 4>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else if (p.ksize <= 64) launch_rolling<0, 4>(b, p, sink, grid, lds, logR, stage_cap, c, s);
+    else launch_rolling<0, 8>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("dna_rolling", s);
   } else {

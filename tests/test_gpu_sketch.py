@@ -110,8 +110,11 @@ CASES = [
     (20, 48, False, 42, 0, True),              # 4-limb rolling kernel, run-time k
     (20, 63, False, 42, 0, False),
     (20, 64, False, 42, 0, True),
-    (20, 65, False, 42, 0, True),              # byte-wise kernel (k > 64)
+    (20, 65, False, 42, 0, True),              # 8-limb rolling kernel
     (10, 100, False, 42, 0, False),
+    (10, 128, False, 42, 0, True),
+    (10, 129, False, 42, 0, True),             # byte-wise kernel (k > 128)
+    (5, 300, False, 42, 0, False),
     (50, 9, True, 42, 0, True),
     (0, 27, True, 42, 1 << 60, True),
     (30, 12, True, (1 << 40) + 5, 0, False),

@@ -80,7 +80,7 @@ while time.time() < t_end:
         print("... %d sketch cases, %d compare blocks so far" % (n_sk, n_cmp), flush=True)
     if rng.random() < 0.75:
         prot = rng.random() < 0.25
-        k = rng.choice([1, 2, 3, 4, 5, 7, 9, 11, 15, 16, 17, 20, 21, 24, 25, 27, 30, 31, 32, 33, 40, 48, 51, 63, 64, 65, 70])
+        k = rng.choice([1, 2, 3, 4, 5, 7, 9, 11, 15, 16, 17, 20, 21, 24, 25, 27, 30, 31, 32, 33, 40, 48, 51, 63, 64, 65, 70, 96, 127, 128, 129, 150])
         if prot and k < 3:
             k = 3
         style = rng.choice(["num", "num", "scaled", "scaled", "both", "neither"])
