@@ -337,14 +337,6 @@ __global__ void k_iota(uint64_t* p, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
 }
-// rank[origin] = run id, one thread per run
-__global__ void k_run_to_rank(const uint32_t* __restrict__ starts, uint32_t nruns, uint32_t n,
-                              const uint64_t* __restrict__ origin, uint32_t* __restrict__ rank) {
-  uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= nruns) return;
-  uint32_t lo = starts[u], hi = u + 1 < nruns ? starts[u + 1] : n;
-  for (uint32_t p = lo; p < hi; p++) rank[origin[p]] = u;
-}
 // bound[r] = rank of the pooled element at sorted position r*n/R (bound[0] = 0, bound[R] = nruns)
 __global__ void k_bounds(const uint32_t* __restrict__ starts, uint32_t nruns, uint32_t n, uint32_t R,
                          uint32_t* __restrict__ bound) {
@@ -404,9 +396,8 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint64_t* so = cur ? T.org1.as<uint64_t>() : T.org0.as<uint64_t>();
   T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
-  const uint32_t nruns = run_length_encode_u64(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s);
-  hipLaunchKernelGGL(k_run_to_rank, dim3((nruns + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), nruns, (uint32_t)n, so,
-                     T.rank.as<uint32_t>());
+  const uint32_t nruns = run_length_encode_u64(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so,
+                                               T.rank.as<uint32_t>());
   // ---- ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords
   // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
   // sketches walk several ranges per step

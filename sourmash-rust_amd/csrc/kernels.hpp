@@ -79,8 +79,10 @@ void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed,
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
                    DeviceBuffer& scratch, hipStream_t s);
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).
+// origin / rank_out (optional): also write rank_out[origin[i]] = run id of sorted position i.
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
-                               DeviceBuffer& scratch, hipStream_t s);
+                               DeviceBuffer& scratch, hipStream_t s, const uint64_t* origin = nullptr,
+                               uint32_t* rank_out = nullptr);
 // reduces the first `nruns` of `total_runs` runs (run u ends at starts[u+1], the last one at n)
 void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t total_runs, uint32_t n,
                 const uint64_t* weights, const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos,

@@ -224,11 +224,16 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __res
 
 // thread owns kRleItems consecutive keys; exclusive position of its first head inside the
 // workgroup comes from a wave scan + per-wave offsets.
+// With `origin` / `rank_out` it also scatters the run id of every element back to where the
+// element came from (rank_out[origin[i]] = run of sorted position i): the dictionary encoding of
+// the compare pre-pass, fused here instead of a second pass over the runs.
 __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __restrict__ keys,
                                                            size_t n,
                                                            const uint32_t* __restrict__ bscan,
                                                            uint64_t* __restrict__ uniq,
-                                                           uint32_t* __restrict__ starts) {
+                                                           uint32_t* __restrict__ starts,
+                                                           const uint64_t* __restrict__ origin,
+                                                           uint32_t* __restrict__ rank_out) {
   __shared__ uint32_t wsum[kRleThreads / 64];
   size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
   uint32_t flags = 0, c = 0;
@@ -247,12 +252,14 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
   for (int i = 0; i < (int)(threadIdx.x >> 6); i++) woffs += wsum[i];
   uint32_t o = bscan[blockIdx.x] + woffs + incl - c;
 #pragma unroll
-  for (int i = 0; i < kRleItems; i++)
+  for (int i = 0; i < kRleItems; i++) {
     if (flags & (1u << i)) {
       uniq[o] = keys[base + i];
       starts[o] = (uint32_t)(base + i);
       o++;
     }
+    if (rank_out && base + i < n) rank_out[origin[base + i]] = o - 1;
+  }
 }
 
 // one thread per run: count, optional weight sum, optional min of the payload
@@ -339,7 +346,7 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
 }
 
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
-                               DeviceBuffer& scratch, hipStream_t s) {
+                               DeviceBuffer& scratch, hipStream_t s, const uint64_t* origin, uint32_t* rank_out) {
   if (n == 0) return 0;
   if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
   const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
@@ -348,7 +355,7 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, n, bc);
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, n, bc, uniq,
-                     starts);
+                     starts, origin, rank_out);
   HIP_CHECK(hipGetLastError());
   uint32_t nruns = 0;
   HIP_CHECK(hipMemcpyAsync(&nruns, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
