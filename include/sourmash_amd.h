@@ -76,6 +76,21 @@ int smh_find(KmerMinHash *const *nodes, uint32_t n_nodes, const KmerMinHash *que
 int smh_most_common(const KmerMinHash *leaf, KmerMinHash *const *candidates, uint32_t n,
                     uint32_t *best_pos, uint64_t *best_common);
 
+/* A set of sketches kept resident in HBM (CSR: hashes + offsets + per-node num), so that repeated
+ * one-vs-many queries -- LinearIndex::find over a fixed index, reference src/index/linear.rs:25-45 --
+ * upload only the query.  Nodes are copied at construction; later changes to them are not seen. */
+typedef struct SmhIndex SmhIndex;
+SmhIndex *smh_index_new(KmerMinHash *const *nodes, uint32_t n_nodes);
+void smh_index_free(SmhIndex *index);
+uint32_t smh_index_len(const SmhIndex *index);
+/* same contracts as smh_find / smh_most_common, against the resident nodes */
+int smh_index_find(SmhIndex *index, const KmerMinHash *query, double threshold, bool containment,
+                   uint32_t *out_indices, uint32_t *out_count);
+int smh_index_most_common(SmhIndex *index, const KmerMinHash *leaf, uint32_t *best_pos, uint64_t *best_common);
+/* rows x cols block between two resident sets (rows' num truncates); host outputs, any may be NULL */
+int smh_index_compare(SmhIndex *rows, SmhIndex *cols, double *jaccard, uint64_t *common, uint64_t *size,
+                      uint64_t *count_common, double *containment);
+
 /* deterministic synthetic DNA of SURVEY.md 8d written to device memory (benchmark input) */
 int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       void *stream);

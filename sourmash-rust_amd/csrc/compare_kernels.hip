@@ -118,6 +118,72 @@ __global__ __launch_bounds__(64) void k_compare_wave(SketchSet rows, SketchSet c
   }
 }
 
+// ---------------------------------------------------------------------------------
+// k_compare_few: a few sketches against many (LinearIndex::find, the scaffold arg-max, a query
+// against a resident index).  blockIdx.y picks the "few" sketch Q, kept in LDS by the workgroup;
+// each wave streams whole "many" sketches A from HBM, 64 consecutive elements per step (one
+// coalesced 512 B read).  Lane i binary-searches its element in Q: lb = #(Q < a), match = Q[lb]==a.
+// Its position in the sorted union is  u = i + lb - (#matches before i)  (ballot prefix), so the
+// truncated walk needs no serial merge:  common = #(match && u < n),  count_common = #match,
+// |A u Q| = |A| + |Q| - count_common.  The search window's lower end is carried from step to step
+// (elements ascend).  Unlike k_compare_wave the LDS footprint is one Q per workgroup, not A + B per
+// wave, so occupancy stays high.
+template <bool QLds, bool WantCC>
+__global__ __launch_bounds__(256) void k_compare_few(SketchSet many, SketchSet few, uint32_t many_is_row, uint32_t num,
+                                                     const uint32_t* __restrict__ row_nums, CompareOut out) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t y = blockIdx.y;
+  const uint64_t qo = few.offsets[y];
+  const uint32_t lq = (uint32_t)(few.offsets[y + 1] - qo);
+  const uint64_t* Q = few.hashes + qo;
+  if (QLds) {
+    for (uint32_t t = tid; t < lq; t += 256) lds64[t] = Q[t];
+    __syncthreads();
+    Q = lds64;
+  }
+  for (uint32_t node = blockIdx.x * 4 + w; node < many.n; node += gridDim.x * 4) {
+    const uint64_t ao = many.offsets[node];
+    const uint32_t la = (uint32_t)(many.offsets[node + 1] - ao);
+    const uint64_t* A = many.hashes + ao;
+    uint32_t n = row_nums ? row_nums[many_is_row ? node : y] : num;
+    n = n ? n : 0xffffffffu;
+    uint32_t base = 0, cc = 0, cm = 0;
+    bool cut = false;
+    for (uint32_t i0 = 0; i0 < la; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool ok = i < la;
+      const uint64_t a = ok ? A[i] : ~0ull;
+      uint32_t lo = base, len = lq - base;
+      while (len > 0) {
+        const uint32_t half = len >> 1, mid = lo + half;
+        const bool lt = Q[mid] < a;
+        lo = lt ? mid + 1 : lo;
+        len = lt ? len - half - 1 : half;
+      }
+      const bool match = ok && lo < lq && Q[lo] == a;
+      const uint64_t mm = __ballot(match);
+      const uint32_t u = i + lo - (cc + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
+      cm += (uint32_t)__popcll(__ballot(match && u < n));
+      cc += (uint32_t)__popcll(mm);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+      // union rank of the step's last element already past the cut: nothing later can count
+      if (!WantCC && (uint32_t)__builtin_amdgcn_readlane((int)u, 63) >= n && i0 + 64 <= la) { cut = true; break; }
+    }
+    if (lane == 0) {
+      const uint64_t tot_u = (uint64_t)la + lq - cc;
+      const uint64_t size = (cut || tot_u > n) ? n : tot_u;
+      const size_t pid = many_is_row ? (size_t)node * few.n + y : (size_t)y * many.n + node;
+      if (out.common) out.common[pid] = cm;
+      if (out.size) out.size[pid] = size;
+      if (out.jaccard) out.jaccard[pid] = (double)cm / (double)(size > 1 ? size : 1);
+      if (WantCC) {
+        if (out.count_common) out.count_common[pid] = cc;
+        if (out.containment) out.containment[pid] = (double)cc / (double)(many_is_row ? la : lq);
+      }
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------
 // k_compare_tiled: the N x M matrix kernel.
@@ -476,6 +542,30 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
     launch_tiled(rows, cols, nr_elems, nc_elems, max_row_len > max_col_len ? max_row_len : max_col_len, num, row_nums, out,
                  dev, s);
     return;
+  }
+  // a few against many: the few side sits in LDS, the many side streams
+  {
+    const bool rows_many = rows.n >= cols.n;
+    const SketchSet& many = rows_many ? rows : cols;
+    const SketchSet& few = rows_many ? cols : rows;
+    const uint32_t few_max = rows_many ? max_col_len : max_row_len;
+    if (many.n >= 64 && std::getenv("SOURMASH_AMD_NO_FEW") == nullptr) {
+      const bool q_lds = few_max <= 8192;
+      const size_t lds = q_lds ? (size_t)(few_max ? few_max : 1) * 8 : 16;
+      const bool want_cc = out.count_common || out.containment;
+      uint32_t gx = (many.n + 3) / 4;
+      const uint32_t cap = (uint32_t)dev.cu_count() * 8;
+      if (gx > cap) gx = cap;
+      dev.prof_begin(s);
+#define SMH_CF(L_, C_) hipLaunchKernelGGL((k_compare_few<L_, C_>), dim3(gx, few.n), dim3(256), lds, s, many, few, \
+                                          rows_many ? 1u : 0u, num, row_nums, out)
+      if (q_lds) { if (want_cc) SMH_CF(true, true); else SMH_CF(true, false); }
+      else { if (want_cc) SMH_CF(false, true); else SMH_CF(false, false); }
+#undef SMH_CF
+      HIP_CHECK(hipGetLastError());
+      dev.prof_end("compare_few", s);
+      return;
+    }
   }
   const size_t need = ((size_t)max_row_len + max_col_len) * sizeof(uint64_t);
   const int grid = (int)(npairs < (uint64_t)dev.cu_count() * 32 ? npairs : (uint64_t)dev.cu_count() * 32);

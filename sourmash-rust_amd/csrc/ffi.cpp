@@ -2,6 +2,7 @@
 // src/ffi.rs and src/utils.rs) and the additive MI355X entry points of include/sourmash_amd.h.
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -528,6 +529,157 @@ int smh_most_common(const KmerMinHash* leaf, KmerMinHash* const* candidates, uin
       if (cc[j] > mx) { mx = cc[j]; pos = j; }
     if (best_pos) *best_pos = pos;
     if (best_common) *best_common = mx;
+  });
+}
+
+// ------------------------------------------------------------------ resident index
+
+struct SmhIndex {
+  smh::DeviceBuffer hashes, offsets, nums;
+  std::vector<uint64_t> h_offsets;
+  std::vector<uint32_t> h_nums;
+  std::vector<smh::KmerMinHash> params;   // parameters only (mins cleared): check_compatible per node
+  uint32_t max_len = 0;
+  uint32_t n = 0;
+};
+
+SmhIndex* smh_index_new(KmerMinHash* const* nodes, uint32_t n_nodes) {
+  return pad<SmhIndex*>([&] {
+    if (n_nodes) require(nodes, "nodes");
+    auto idx = std::make_unique<SmhIndex>();
+    idx->n = n_nodes;
+    idx->h_offsets.assign(n_nodes + 1, 0);
+    idx->h_nums.resize(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+      require(nodes[i], "nodes[i]");
+      nodes[i]->materialize();
+      idx->h_offsets[i + 1] = idx->h_offsets[i] + nodes[i]->mins.size();
+      idx->h_nums[i] = nodes[i]->num;
+      idx->max_len = std::max<uint32_t>(idx->max_len, (uint32_t)nodes[i]->mins.size());
+      smh::KmerMinHash p(nodes[i]->num, nodes[i]->ksize, nodes[i]->is_protein, nodes[i]->seed, nodes[i]->max_hash, false);
+      idx->params.push_back(p);
+    }
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.stream();
+    idx->hashes.ensure(idx->h_offsets.back() * 8 + 8);
+    idx->offsets.ensure((size_t)(n_nodes + 1) * 8);
+    idx->nums.ensure((size_t)n_nodes * 4 + 4);
+    for (uint32_t i = 0; i < n_nodes; i++)
+      if (!nodes[i]->mins.empty())
+        HIP_CHECK(hipMemcpyAsync(idx->hashes.as<uint64_t>() + idx->h_offsets[i], nodes[i]->mins.data(),
+                                 nodes[i]->mins.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx->offsets.ptr, idx->h_offsets.data(), (size_t)(n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_nodes) HIP_CHECK(hipMemcpyAsync(idx->nums.ptr, idx->h_nums.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return idx.release();
+  });
+}
+
+void smh_index_free(SmhIndex* index) { delete index; }
+uint32_t smh_index_len(const SmhIndex* index) { return index ? index->n : 0; }
+
+namespace {
+// rows = resident index, cols = one host sketch: N x 1 block on the device, values back on the host
+void index_vs_one(SmhIndex* index, const smh::KmerMinHash* q, bool q_is_row, double* jac, double* cont, uint64_t* cc) {
+  auto& dev = smh::Device::get();
+  auto& E = smh::Engine::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  hipStream_t s = dev.stream();
+  q->materialize();
+  const uint32_t n = index->n;
+  const uint64_t qoff[2] = {0, (uint64_t)q->mins.size()};
+  E.cmp_b.ensure(q->mins.size() * 8 + 8);
+  E.cmp_ob.ensure(16);
+  E.cmp_out.ensure((size_t)n * 8 * 3 + 64);
+  if (!q->mins.empty())
+    HIP_CHECK(hipMemcpyAsync(E.cmp_b.ptr, q->mins.data(), q->mins.size() * 8, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(E.cmp_ob.ptr, qoff, 16, hipMemcpyHostToDevice, s));
+  smh::SketchSet I, Q;
+  I.hashes = index->hashes.as<uint64_t>(); I.offsets = index->offsets.as<uint64_t>(); I.n = n;
+  Q.hashes = E.cmp_b.as<uint64_t>(); Q.offsets = E.cmp_ob.as<uint64_t>(); Q.n = 1;
+  double* d_j = E.cmp_out.as<double>();
+  double* d_c = d_j + n;
+  uint64_t* d_cc = reinterpret_cast<uint64_t*>(d_c + n);
+  smh::CompareOut o;
+  o.jaccard = jac ? d_j : nullptr; o.containment = cont ? d_c : nullptr; o.count_common = cc ? d_cc : nullptr;
+  if (!q_is_row)
+    smh::launch_compare_block(I, Q, 0, index->nums.as<uint32_t>(), o, dev, s, index->max_len, (uint32_t)q->mins.size(),
+                              index->h_offsets.back(), q->mins.size());
+  else
+    smh::launch_compare_block(Q, I, q->num, nullptr, o, dev, s, (uint32_t)q->mins.size(), index->max_len, q->mins.size(),
+                              index->h_offsets.back());
+  if (jac) HIP_CHECK(hipMemcpyAsync(jac, d_j, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (cont) HIP_CHECK(hipMemcpyAsync(cont, d_c, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  if (cc) HIP_CHECK(hipMemcpyAsync(cc, d_cc, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+}  // namespace
+
+int smh_index_find(SmhIndex* index, const KmerMinHash* query, double threshold, bool containment, uint32_t* out_indices,
+                   uint32_t* out_count) {
+  return pad_code([&] {
+    require(index, "index"); require(query, "query"); require(out_count, "out_count");
+    *out_count = 0;
+    if (index->n == 0) return;
+    require(out_indices, "out_indices");
+    for (auto& p : index->params) p.check_compatible(*query);
+    std::vector<double> val(index->n);
+    index_vs_one(index, query, false, containment ? nullptr : val.data(), containment ? val.data() : nullptr, nullptr);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < index->n; i++)
+      if (val[i] > threshold) out_indices[k++] = i;
+    *out_count = k;
+  });
+}
+
+int smh_index_most_common(SmhIndex* index, const KmerMinHash* leaf, uint32_t* best_pos, uint64_t* best_common) {
+  return pad_code([&] {
+    require(index, "index"); require(leaf, "leaf");
+    if (best_pos) *best_pos = 0;
+    if (best_common) *best_common = 0;
+    if (index->n == 0) return;
+    for (auto& p : index->params) leaf->check_compatible(p);
+    std::vector<uint64_t> cc(index->n);
+    index_vs_one(index, leaf, true, nullptr, nullptr, cc.data());
+    uint32_t pos = 0; uint64_t mx = 0;
+    for (uint32_t j = 0; j < index->n; j++) if (cc[j] > mx) { mx = cc[j]; pos = j; }
+    if (best_pos) *best_pos = pos;
+    if (best_common) *best_common = mx;
+  });
+}
+
+int smh_index_compare(SmhIndex* rows, SmhIndex* cols, double* jaccard, uint64_t* common, uint64_t* size,
+                      uint64_t* count_common, double* containment) {
+  return pad_code([&] {
+    require(rows, "rows"); require(cols, "cols");
+    const size_t np = (size_t)rows->n * cols->n;
+    if (np == 0) return;
+    for (auto& r : rows->params) for (auto& c : cols->params) r.check_compatible(c);
+    auto& dev = smh::Device::get();
+    auto& E = smh::Engine::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.stream();
+    E.cmp_out.ensure(np * 8 * 5 + 64);
+    uint64_t* d_common = E.cmp_out.as<uint64_t>();
+    uint64_t* d_size = d_common + np;
+    double* d_jac = reinterpret_cast<double*>(d_size + np);
+    uint64_t* d_cc = reinterpret_cast<uint64_t*>(d_jac + np);
+    double* d_cont = reinterpret_cast<double*>(d_cc + np);
+    smh::SketchSet R, C;
+    R.hashes = rows->hashes.as<uint64_t>(); R.offsets = rows->offsets.as<uint64_t>(); R.n = rows->n;
+    C.hashes = cols->hashes.as<uint64_t>(); C.offsets = cols->offsets.as<uint64_t>(); C.n = cols->n;
+    smh::CompareOut o;
+    o.common = common ? d_common : nullptr; o.size = size ? d_size : nullptr; o.jaccard = jaccard ? d_jac : nullptr;
+    o.count_common = count_common ? d_cc : nullptr; o.containment = containment ? d_cont : nullptr;
+    smh::launch_compare_block(R, C, 0, rows->nums.as<uint32_t>(), o, dev, s, rows->max_len, cols->max_len,
+                              rows->h_offsets.back(), cols->h_offsets.back());
+    if (common) HIP_CHECK(hipMemcpyAsync(common, d_common, np * 8, hipMemcpyDeviceToHost, s));
+    if (size) HIP_CHECK(hipMemcpyAsync(size, d_size, np * 8, hipMemcpyDeviceToHost, s));
+    if (jaccard) HIP_CHECK(hipMemcpyAsync(jaccard, d_jac, np * 8, hipMemcpyDeviceToHost, s));
+    if (count_common) HIP_CHECK(hipMemcpyAsync(count_common, d_cc, np * 8, hipMemcpyDeviceToHost, s));
+    if (containment) HIP_CHECK(hipMemcpyAsync(containment, d_cont, np * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
   });
 }
 

@@ -32,15 +32,71 @@ def _find(nodes, query, threshold, containment):
     return [int(out[i]) for i in range(cnt.value)]
 
 
+class ResidentIndex:
+    """Sketches copied once into HBM (additive ABI smh_index_*): repeated queries upload only the query."""
+
+    def __init__(self, nodes):
+        self._L = lib()
+        self.nodes = list(nodes)
+        arr = (C.c_void_p * max(len(self.nodes), 1))(*[m._p for m in self.nodes])
+        self._h = call(self._L.smh_index_new, arr, len(self.nodes))
+
+    def __del__(self):
+        try:
+            self._L.smh_index_free(self._h)
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self._L.smh_index_len(self._h)
+
+    def find(self, query, threshold, containment=False):
+        out = (C.c_uint32 * max(len(self.nodes), 1))()
+        cnt = C.c_uint32()
+        call(self._L.smh_index_find, self._h, query._p, float(threshold), bool(containment), out, C.byref(cnt))
+        return [int(out[i]) for i in range(cnt.value)]
+
+    def most_common(self, leaf):
+        pos, cm = C.c_uint32(), C.c_uint64()
+        call(self._L.smh_index_most_common, self._h, leaf._p, C.byref(pos), C.byref(cm))
+        return pos.value, cm.value
+
+    def compare(self, other, want=("jaccard",)):
+        n, m = len(self), len(other)
+        kinds = {"jaccard": np.float64, "common": np.uint64, "size": np.uint64, "count_common": np.uint64,
+                 "containment": np.float64}
+        out = {k: np.zeros((n, m), dtype=kinds[k]) for k in want}
+
+        def p(name):
+            if name not in out:
+                return None
+            return out[name].ctypes.data_as(C.POINTER(C.c_double) if out[name].dtype == np.float64 else u64p)
+
+        call(self._L.smh_index_compare, self._h, other._h, p("jaccard"), p("common"), p("size"), p("count_common"),
+             p("containment"))
+        return out
+
+
 class LinearIndex:
+    """reference src/index/linear.rs: leaves + find(search_fn, query, threshold).  The leaves are
+    mirrored in HBM on the first find after an insert."""
+
     def __init__(self):
         self.leaves = []
+        self._resident = None
 
     def insert(self, mh):
         self.leaves.append(mh)
+        self._resident = None
 
     def find(self, search_fn, query, threshold):
-        return [self.leaves[i] for i in search_fn(self.leaves, query, threshold)]
+        if search_fn in (search_minhashes, search_minhashes_containment):
+            if self._resident is None:
+                self._resident = ResidentIndex(self.leaves)
+            hits = self._resident.find(query, threshold, containment=search_fn is search_minhashes_containment)
+        else:
+            hits = search_fn(self.leaves, query, threshold)
+        return [self.leaves[i] for i in hits]
 
 
 def most_common(leaf, candidates):

@@ -266,3 +266,65 @@ def test_end_to_end_genomes_to_matrix(pkg, coracle):
     assert out["jaccard"][0, 1] > out["jaccard"][0, 23] > 0          # similarity decays with mutations
     hits = pkg.index.search_minhashes(loaded, loaded[0], 0.5)
     assert hits == [i for i in range(24) if oms[i].compare(oms[0]) > 0.5] and 0 in hits
+
+
+def test_resident_index(pkg, coracle, sbt_subset_sketches):
+    """The HBM-resident index answers find / most_common / block compare exactly like the per-call paths."""
+    nodes = [mh_from_sketch(pkg.KmerMinHash, s) for s in sbt_subset_sketches]
+    onodes = [mh_from_sketch(coracle.MinHash, s) for s in sbt_subset_sketches]
+    idx = pkg.index.ResidentIndex(nodes)
+    assert len(idx) == 100
+    for qi in (0, 17, 99):
+        for thr in (0.0, 0.01, 0.2):
+            assert idx.find(nodes[qi], thr) == [i for i in range(100) if onodes[i].compare(onodes[qi]) > thr]
+            assert idx.find(nodes[qi], thr, containment=True) == \
+                [i for i in range(100) if onodes[i].containment(onodes[qi]) > thr]
+            assert idx.find(nodes[qi], thr) == pkg.index.search_minhashes(nodes, nodes[qi], thr)
+        occ = [onodes[qi].count_common(o) for o in onodes]
+        assert idx.most_common(nodes[qi]) == (occ.index(max(occ)), max(occ))
+    sub = pkg.index.ResidentIndex(nodes[:20])
+    out = sub.compare(idx, want=("jaccard", "count_common"))
+    ref = pkg.matrix.compare_block(nodes[:20], nodes, want=("jaccard", "count_common"))
+    assert (out["jaccard"] == ref["jaccard"]).all() and (out["count_common"] == ref["count_common"]).all()
+    bad = pkg.KmerMinHash(0, 31, False, 42, 9223372036854776)
+    with pytest.raises(pkg.SourmashError) as ei:
+        idx.find(bad, 0.1)
+    assert ei.value.code == 101
+
+
+def _pair(pkg, coracle, n, mins):
+    g = pkg.KmerMinHash(n, 21, False, 42, 0); o = coracle.MinHash(n, 21, False, 42, 0)
+    for h in mins:
+        g.mins_push(int(h)); o.mins_push(int(h))
+    return g, o
+
+
+@pytest.mark.parametrize("few_is_row", [False, True])
+def test_few_vs_many_kernel(few_is_row, pkg, coracle):
+    """k_compare_few (a handful of sketches against many; the LinearIndex / scaffold shape) in both
+    orientations: ragged and empty sketches, per-row nums (H6), identical sketches, a query too
+    long for LDS, and the jaccard-only early-exit instantiation."""
+    rng = np.random.RandomState(5 + few_is_row)
+    pool = np.unique(rng.randint(0, 1 << 62, size=30000, dtype=np.int64).astype(np.uint64))
+    sizes = [0, 1, 5, 64, 65, 300, 300, 1200, 3000]
+    nums = [0, 1, 7, 64, 300, 5000]
+    many = [np.sort(rng.choice(pool, sizes[i % len(sizes)], replace=False)) for i in range(150)]
+    few = [np.sort(rng.choice(pool, k, replace=False)) for k in (0, 1, 300, 2999, 9000)]
+    many[10] = few[2].copy(); many[11] = few[3].copy(); many[12] = few[4][:3000].copy()
+    gm, om = zip(*[_pair(pkg, coracle, nums[i % len(nums)], m) for i, m in enumerate(many)])
+    gf, of = zip(*[_pair(pkg, coracle, nums[(i + 2) % len(nums)], f) for i, f in enumerate(few)])
+    R, C_, oR, oC = (gf, gm, of, om) if few_is_row else (gm, gf, om, of)
+    want = ("jaccard", "common", "size", "count_common", "containment")
+    out = pkg.matrix.compare_block(list(R), list(C_), want=want)
+    for i in range(len(R)):
+        for j in range(len(C_)):
+            assert (int(out["common"][i, j]), int(out["size"][i, j])) == oR[i].intersection_size(oC[j]), (i, j)
+            assert out["jaccard"][i, j] == oR[i].compare(oC[j])
+            assert int(out["count_common"][i, j]) == oR[i].count_common(oC[j])
+            if len(oR[i].mins):
+                assert out["containment"][i, j] == oR[i].containment(oC[j])
+            else:
+                assert np.isnan(out["containment"][i, j])
+    out2 = pkg.matrix.compare_block(list(R), list(C_), want=("jaccard", "common", "size"))
+    for k in ("jaccard", "common", "size"):
+        assert (out2[k] == out[k]).all()
