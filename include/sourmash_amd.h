@@ -37,6 +37,17 @@ int smh_add_sequences(KmerMinHash *ptr, const char *seq, const uint64_t *offsets
 int smh_add_sequences_dev(KmerMinHash *ptr, const void *seq_dev, uint64_t total_len,
                           const uint64_t *offsets, uint32_t n_records, bool force, void *stream);
 
+/* Many sketches from one batch: record r feeds sketches[groups[r]] (one genome = one group of
+ * contigs; the loop of reference src/lib.rs:252-305 callers that build one signature per input
+ * file).  Per sketch the result is that of smh_add_sequences over its records in order.  Scaled
+ * DNA sketches with equal (ksize, seed, max_hash) share ONE hashing launch and ONE sort; other
+ * parameter combinations are served sketch by sketch. */
+int smh_add_sequences_grouped(KmerMinHash *const *sketches, uint32_t n_sketches, const char *seq,
+                              const uint64_t *offsets, const uint32_t *groups, uint32_t n_records, bool force);
+int smh_add_sequences_grouped_dev(KmerMinHash *const *sketches, uint32_t n_sketches, const void *seq_dev,
+                                  uint64_t total_len, const uint64_t *offsets, const uint32_t *groups,
+                                  uint32_t n_records, bool force, void *stream);
+
 /* add_hash over an array (reference src/lib.rs:412-417 add_many) */
 int smh_add_many(KmerMinHash *ptr, const uint64_t *hashes, uint64_t n);
 

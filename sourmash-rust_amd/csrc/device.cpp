@@ -25,6 +25,15 @@ void DeviceBuffer::release() {
 }
 DeviceBuffer::~DeviceBuffer() { release(); }
 
+void PinnedBuffer::ensure(size_t need) {
+  if (need <= bytes) return;
+  size_t want = need + need / 4 + 4096;
+  if (ptr) { HIP_CHECK(hipHostFree(ptr)); ptr = nullptr; bytes = 0; }
+  HIP_CHECK(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+  bytes = want;
+}
+PinnedBuffer::~PinnedBuffer() { if (ptr) (void)hipHostFree(ptr); }
+
 static int pick_device() {
   // SOURMASH_AMD_DEVICE selects explicitly; otherwise keep the caller's current device (a
   // torch.distributed rank has already called hipSetDevice(LOCAL_RANK) through torch).

@@ -36,6 +36,18 @@ struct DeviceBuffer {
   ~DeviceBuffer();
 };
 
+// grow-only page-locked host staging area: D2H at link speed instead of through a bounce buffer
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  void ensure(size_t need);
+  template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
+  PinnedBuffer() = default;
+  PinnedBuffer(const PinnedBuffer&) = delete;
+  PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+  ~PinnedBuffer();
+};
+
 struct KernelTimes {
   double ms = 0.0;
   uint64_t launches = 0;

@@ -432,6 +432,39 @@ int smh_add_sequences_dev(KmerMinHash* ptr, const void* seq_dev, uint64_t total_
   });
 }
 
+int smh_add_sequences_grouped(KmerMinHash* const* sketches, uint32_t n_sketches, const char* seq, const uint64_t* offsets,
+                              const uint32_t* groups, uint32_t n_records, bool force) {
+  return pad_code([&] {
+    if (n_records == 0) return;
+    require(sketches, "sketches"); require(seq, "seq"); require(offsets, "offsets"); require(groups, "groups");
+    for (uint32_t g = 0; g < n_sketches; g++) require(sketches[g], "sketches[g]");
+    auto& dev = smh::Device::get();
+    auto& E = smh::Engine::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    const uint64_t base = offsets[0], total = offsets[n_records] - base;
+    std::vector<uint64_t> rel(n_records + 1);
+    for (uint32_t i = 0; i <= n_records; i++) rel[i] = offsets[i] - base;
+    E.seqbuf.ensure(total + 64);
+    if (total) HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq + base, total, hipMemcpyHostToDevice, dev.stream()));
+    std::vector<smh::KmerMinHash*> mhs(sketches, sketches + n_sketches);
+    smh::add_sequences_grouped(mhs.data(), n_sketches, E.seqbuf.as<uint8_t>(), total, rel.data(), groups, n_records, force,
+                               dev.stream(), nullptr);
+  });
+}
+
+int smh_add_sequences_grouped_dev(KmerMinHash* const* sketches, uint32_t n_sketches, const void* seq_dev, uint64_t total_len,
+                                  const uint64_t* offsets, const uint32_t* groups, uint32_t n_records, bool force,
+                                  void* stream) {
+  return pad_code([&] {
+    if (n_records == 0) return;
+    require(sketches, "sketches"); require(seq_dev, "seq_dev"); require(offsets, "offsets"); require(groups, "groups");
+    for (uint32_t g = 0; g < n_sketches; g++) require(sketches[g], "sketches[g]");
+    std::vector<smh::KmerMinHash*> mhs(sketches, sketches + n_sketches);
+    smh::add_sequences_grouped(mhs.data(), n_sketches, (const uint8_t*)seq_dev, total_len, offsets, groups, n_records, force,
+                               (hipStream_t)stream, nullptr);
+  });
+}
+
 int smh_add_many(KmerMinHash* ptr, const uint64_t* hashes, uint64_t n) {
   return pad_code([&] { require(ptr, "ptr"); if (n) require(hashes, "hashes"); ptr->materialize(); ptr->add_many(hashes, n); });
 }

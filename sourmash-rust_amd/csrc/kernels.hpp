@@ -34,8 +34,8 @@ struct SeqBatch {
 struct HashParams {
   uint32_t ksize = 31;
   uint64_t seed = 42;
-  const uint64_t* thr_ptr = nullptr;  // device-resident threshold (num-mode rounds) or null
-  uint64_t thr = ~0ull;               // used when thr_ptr is null
+  const uint64_t* thr_rec = nullptr;  // DNA arm: per-record thresholds (device, nrec entries) or null
+  uint64_t thr = ~0ull;               // the threshold when thr_rec is null (and the LDS stage estimate)
   uint64_t pos_base = 0;
   uint64_t range_lo = 0, range_hi = 0;  // k-mer start positions [lo, hi) handled by this launch
 };
@@ -80,9 +80,15 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
                    DeviceBuffer& scratch, hipStream_t s);
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).
 // origin / rank_out (optional): also write rank_out[origin[i]] = run id of sorted position i.
+// key2 / uniq2 (optional): a more significant second key (array sorted by (key2, keys)); a run
+// ends where either changes and uniq2[run] receives its key2.
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
                                DeviceBuffer& scratch, hipStream_t s, const uint64_t* origin = nullptr,
-                               uint32_t* rank_out = nullptr);
+                               uint32_t* rank_out = nullptr, const uint64_t* key2 = nullptr,
+                               uint64_t* uniq2 = nullptr);
+// cand_pos[i] (a k-mer start position of the batch) -> the sketch group of the record holding it
+void launch_pos_to_group(uint64_t* pos, uint64_t n, const uint64_t* rec_starts, uint32_t nrec,
+                         const uint32_t* group_of_rec, hipStream_t s);
 // reduces the first `nruns` of `total_runs` runs (run u ends at starts[u+1], the last one at n)
 void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t total_runs, uint32_t n,
                 const uint64_t* weights, const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos,

@@ -182,9 +182,10 @@ struct DnaSource : HashSource {
   uint64_t seed = 0;
   Device* dev = nullptr;
   uint64_t positions() const override { return b.len; }
+  const uint64_t* thr_rec = nullptr;   // per-record thresholds (grouped bottom-num batches)
   void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
     HashParams p;
-    p.ksize = ksize; p.seed = seed; p.thr = thr; p.range_lo = lo; p.range_hi = hi;
+    p.ksize = ksize; p.seed = seed; p.thr = thr; p.thr_rec = thr_rec; p.range_lo = lo; p.range_hi = hi;
     launch_dna_hash(b, p, sink, *dev, s);
   }
 };
@@ -562,6 +563,38 @@ bool utf8_valid(const uint8_t* s, size_t n) {
 
 }  // namespace
 
+namespace {
+// force == false: where each record stops being valid DNA.  The windows before that byte are
+// added, the first window holding it is the error (reference src/lib.rs:261-273, quirk Q1);
+// the first such record in order is reported.  Leaves the cut points in b.vends / b.vend0.
+void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, uint32_t nrec, uint32_t ksize, Engine& E,
+                  hipStream_t s, bool* have_error, Error* err) {
+  std::vector<uint64_t> vends(h_offsets + 1, h_offsets + nrec + 1);
+  E.vendbuf.ensure((size_t)nrec * 8);
+  HIP_CHECK(hipMemcpyAsync(E.vendbuf.ptr, vends.data(), (size_t)nrec * 8, hipMemcpyHostToDevice, s));
+  launch_first_invalid(b, E.vendbuf.as<uint64_t>(), s);
+  HIP_CHECK(hipMemcpyAsync(vends.data(), E.vendbuf.ptr, (size_t)nrec * 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  for (uint32_t r = 0; r < nrec && !*have_error; r++) {
+    const uint64_t st = h_offsets[r], en = h_offsets[r + 1], bad = vends[r];
+    if (bad >= en || en - st < ksize) continue;
+    const uint64_t ws = bad + 1 >= st + ksize ? bad + 1 - ksize : st;  // first window holding `bad`
+    std::vector<uint8_t> kmer(ksize);
+    HIP_CHECK(hipMemcpyAsync(kmer.data(), d_seq + ws, ksize, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (auto& c : kmer) if (c >= 'a' && c <= 'z') c -= 32;
+    *have_error = true;
+    if (!utf8_valid(kmer.data(), kmer.size()))
+      *err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: FromUtf8Error");
+    else
+      *err = Error(kInvalidDNA, "invalid DNA character in input k-mer: " + std::string(kmer.begin(), kmer.end()));
+  }
+  // records shorter than ksize must not lose anything: they add nothing either way
+  if (nrec > 1) b.vends = E.vendbuf.as<uint64_t>();
+  else b.vend0 = vends[0];
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------
 // add_sequence front ends
 
@@ -593,35 +626,7 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
 
   if (!is_protein) {
     if (ksize == 0) throw_panic("window size must be non-zero");  // slice::windows(0)
-    std::vector<uint64_t> vends;
-    if (!force) {
-      // where each record stops being valid DNA: the windows before that byte are added, the
-      // first window holding it is the error (reference src/lib.rs:261-273, quirk Q1)
-      vends.assign(h_offsets + 1, h_offsets + nrec + 1);
-      E.vendbuf.ensure((size_t)nrec * 8);
-      HIP_CHECK(hipMemcpyAsync(E.vendbuf.ptr, vends.data(), (size_t)nrec * 8, hipMemcpyHostToDevice, s));
-      launch_first_invalid(b, E.vendbuf.as<uint64_t>(), s);
-      HIP_CHECK(hipMemcpyAsync(vends.data(), E.vendbuf.ptr, (size_t)nrec * 8, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipStreamSynchronize(s));
-      for (uint32_t r = 0; r < nrec && !have_error; r++) {
-        const uint64_t st = h_offsets[r], en = h_offsets[r + 1], bad = vends[r];
-        if (bad >= en || en - st < ksize) continue;
-        const uint64_t ws = bad + 1 >= st + ksize ? bad + 1 - ksize : st;  // first window holding `bad`
-        std::vector<uint8_t> kmer(ksize);
-        HIP_CHECK(hipMemcpyAsync(kmer.data(), d_seq + ws, ksize, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        for (auto& c : kmer) if (c >= 'a' && c <= 'z') c -= 32;
-        have_error = true;
-        if (!utf8_valid(kmer.data(), kmer.size()))
-          err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: FromUtf8Error");
-        else
-          err = Error(kInvalidDNA, "invalid DNA character in input k-mer: " +
-                                       std::string(kmer.begin(), kmer.end()));
-      }
-      // records shorter than ksize must not lose anything: they add nothing either way
-      if (nrec > 1) b.vends = E.vendbuf.as<uint64_t>();
-      else b.vend0 = vends[0];
-    }
+    if (!force) dna_validate(b, d_seq, h_offsets, nrec, ksize, E, s, &have_error, &err);
     DnaSource src;
     src.b = b; src.ksize = ksize; src.seed = seed; src.dev = &dev;
     ingest(*this, src, s);
@@ -670,6 +675,210 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
     ingest(*this, src, s);
   }
 
+  if (have_error) {
+    if (first_error) *first_error = err;
+    else throw err;
+  }
+}
+
+void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t* d_seq, uint64_t total_len,
+                           const uint64_t* h_offsets, const uint32_t* grp, uint32_t nrec, bool force, hipStream_t stream,
+                           Error* first_error) {
+  if (nrec == 0 || total_len == 0) return;
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  Engine& E = Engine::get();
+  hipStream_t s = stream ? stream : dev.stream();
+  for (uint32_t r = 0; r < nrec; r++)
+    if (grp[r] >= n_mh) throw_internal("record group out of range");
+  bool have_error = false;
+  Error err(kNoError, "");
+
+  // every maximal run of consecutive records of one group
+  struct RecRun { uint32_t r0, r1; };
+  std::vector<RecRun> runs;
+  for (uint32_t r0 = 0; r0 < nrec;) {
+    uint32_t r1 = r0 + 1;
+    while (r1 < nrec && grp[r1] == grp[r0]) r1++;
+    runs.push_back({r0, r1});
+    r0 = r1;
+  }
+  // sketch by sketch: each run is one batch for its sketch (any parameters, any mode)
+  std::vector<uint64_t> offs;
+  auto serve_run = [&](const RecRun& rr) {
+    offs.assign(h_offsets + rr.r0, h_offsets + rr.r1 + 1);
+    const uint64_t base = offs[0];
+    for (auto& o : offs) o -= base;
+    Error e(kNoError, "");
+    mhs[grp[rr.r0]]->add_sequences_device(d_seq + base, offs.back(), offs.data(), rr.r1 - rr.r0, force, s, &e);
+    if (e.code != kNoError && !have_error) { have_error = true; err = e; }
+  };
+
+  // Shared-launch paths: DNA sketches with equal (ksize, seed), all scaled with one max_hash, or
+  // all bottom-num without abundance tracking (per-record thresholds).
+  enum { kSlow, kSharedScaled, kSharedNum } path = kSlow;
+  const KmerMinHash& m0 = *mhs[0];
+  if (!m0.is_protein && m0.ksize > 0 && runs.size() > 1) {
+    bool same = true, all_scaled = true, all_num = true;
+    for (uint32_t g = 0; g < n_mh && same; g++) {
+      mhs[g]->materialize();
+      const KmerMinHash& m = *mhs[g];
+      same = !m.is_protein && m.ksize == m0.ksize && m.seed == m0.seed;
+      const int mode = mode_of(m);
+      all_scaled &= mode == kScaled && m.max_hash == m0.max_hash;
+      all_num &= mode == kNum && !m.has_abunds;
+    }
+    if (same && n_mh <= 65536) {
+      // one sketch listed twice is served in order instead
+      std::vector<const KmerMinHash*> sorted(mhs, mhs + n_mh);
+      std::sort(sorted.begin(), sorted.end());
+      same = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
+    }
+    if (same && all_scaled) path = kSharedScaled;
+    else if (same && all_num) path = kSharedNum;
+  }
+  if (path == kSlow) {
+    for (const RecRun& rr : runs) serve_run(rr);
+    if (have_error) { if (first_error) *first_error = err; else throw err; }
+    return;
+  }
+
+  const uint32_t ksize = m0.ksize;
+  bool any_long = false;
+  for (uint32_t r = 0; r < nrec; r++) any_long |= (h_offsets[r + 1] - h_offsets[r]) >= ksize;
+  if (!any_long) return;
+  E.offbuf.ensure((size_t)(nrec + 1) * 8);
+  E.grpbuf.ensure((size_t)nrec * 4);
+  HIP_CHECK(hipMemcpyAsync(E.offbuf.ptr, h_offsets, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(E.grpbuf.ptr, grp, (size_t)nrec * 4, hipMemcpyHostToDevice, s));
+  SeqBatch b;
+  b.seq = d_seq; b.len = total_len; b.starts = E.offbuf.as<uint64_t>(); b.nrec = nrec; b.vend0 = total_len;
+  if (!force) dna_validate(b, d_seq, h_offsets, nrec, ksize, E, s, &have_error, &err);
+  DnaSource src;
+  src.b = b; src.ksize = ksize; src.seed = m0.seed; src.dev = &dev;
+  const uint64_t P = src.positions();
+  bool any_track = false;
+  for (uint32_t g = 0; g < n_mh; g++) any_track |= mhs[g]->has_abunds;
+
+  // n candidates (hash, position) in cand_hash[0] / cand_pos[0] -> per group: its distinct hashes
+  // ascending (+ run starts when some sketch tracks abundance), handed to per_group(g, hashes,
+  // count, starts_or_null, end_of_last_run)
+  auto fold_groups = [&](uint64_t n, auto&& per_group) {
+    if (n == 0) return;
+    // (hash, position) -> (hash, group); sort by hash, then stably by group: (group, hash) order
+    launch_pos_to_group(E.cand_pos[0].as<uint64_t>(), n, E.offbuf.as<uint64_t>(), nrec, E.grpbuf.as<uint32_t>(), s);
+    const int c1 = radix_sort_u64(E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(), E.cand_pos[0].as<uint64_t>(),
+                                  E.cand_pos[1].as<uint64_t>(), n, dev.scratch, s);
+    const int c2 = radix_sort_u64(E.cand_pos[c1].as<uint64_t>(), E.cand_pos[c1 ^ 1].as<uint64_t>(),
+                                  E.cand_hash[c1].as<uint64_t>(), E.cand_hash[c1 ^ 1].as<uint64_t>(), n, dev.scratch, s);
+    const int cur = c1 ^ c2;
+    E.uniq.ensure(n * 8); E.uniq2.ensure(n * 8); E.starts.ensure((n + 1) * 4);
+    const uint32_t nruns = run_length_encode_u64(E.cand_hash[cur].as<uint64_t>(), n, E.uniq.as<uint64_t>(),
+                                                 E.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr,
+                                                 E.cand_pos[cur].as<uint64_t>(), E.uniq2.as<uint64_t>());
+    if (nruns == 0) return;
+    // group boundaries in run space: collapse the per-run group ids once more
+    E.red_b.ensure((size_t)nruns * 8); E.misc.ensure(((size_t)nruns + 1) * 4);
+    const uint32_t ngr = run_length_encode_u64(E.uniq2.as<uint64_t>(), nruns, E.red_b.as<uint64_t>(), E.misc.as<uint32_t>(),
+                                               dev.scratch, s);
+    E.pin_a.ensure((size_t)nruns * 8);
+    E.pin_b.ensure((size_t)nruns * 4 + (size_t)ngr * 12 + 16);
+    uint64_t* h_uniq = E.pin_a.as<uint64_t>();
+    uint32_t* h_starts = E.pin_b.as<uint32_t>();                       // [nruns]   (only when some sketch tracks)
+    uint32_t* h_gstart = h_starts + nruns;                             // [ngr]
+    uint64_t* h_gid = reinterpret_cast<uint64_t*>(E.pin_b.as<char>() + (((size_t)nruns + ngr) * 4 + 7) / 8 * 8);  // [ngr]
+    HIP_CHECK(hipMemcpyAsync(h_uniq, E.uniq.ptr, (size_t)nruns * 8, hipMemcpyDeviceToHost, s));
+    if (any_track) HIP_CHECK(hipMemcpyAsync(h_starts, E.starts.ptr, (size_t)nruns * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(h_gstart, E.misc.ptr, (size_t)ngr * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(h_gid, E.red_b.ptr, (size_t)ngr * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (uint32_t q = 0; q < ngr; q++) {
+      const size_t a = h_gstart[q], e = q + 1 < ngr ? h_gstart[q + 1] : nruns;
+      per_group((uint32_t)h_gid[q], h_uniq + a, e - a, any_track ? h_starts + a : nullptr,
+                e < nruns && any_track ? h_starts[e] : (uint32_t)n);
+    }
+  };
+
+  Delta d;
+  if (path == kSharedScaled) {
+    long double frac = ((long double)m0.max_hash + 1.0L) / 18446744073709551616.0L;
+    long double span_ld = (long double)(1ull << 30) / frac;
+    const uint64_t CH = span_ld > 4.0e12L ? (uint64_t)4e12 : (span_ld < 16777216.0L ? (1ull << 24) : (uint64_t)span_ld);
+    for (uint64_t lo = 0; lo < P; lo += CH) {
+      const uint64_t hi = std::min(P, lo + CH);
+      const uint64_t n = E.run_chunk(&src, lo, hi, m0.max_hash, true, s);
+      fold_groups(n, [&](uint32_t g, const uint64_t* hashes, size_t cnt, const uint32_t* starts, uint32_t end) {
+        KmerMinHash& mh = *mhs[g];
+        d.uniq.assign(hashes, hashes + cnt);
+        if (mh.has_abunds) {
+          d.run_start.assign(starts, starts + cnt);
+          d.run_start.push_back(end);
+        }
+        apply_scaled(mh, d);
+      });
+    }
+  } else {
+    // Bottom-num sketches: group g keeps hashes <= thr[g], chosen so that about 2 num + 64 of its
+    // windows pass (a full sketch's own maximum when that is lower).  A group that still shows
+    // fewer than num distinct hashes under a finite threshold (a repetitive genome) is served
+    // again on its own afterwards; nothing was applied to it here.
+    std::vector<uint64_t> windows(n_mh, 0), thr(n_mh, UINT64_MAX);
+    for (uint32_t r = 0; r < nrec; r++) {
+      const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+      if (len >= ksize) windows[grp[r]] += len - ksize + 1;
+    }
+    long double expect = 0;
+    for (uint32_t g = 0; g < n_mh; g++) {
+      const KmerMinHash& m = *mhs[g];
+      const long double want = 2.0L * m.num + 64.0L;
+      if (windows[g] > 0 && want < 0.5L * windows[g]) thr[g] = (uint64_t)(want / windows[g] * 18446744073709551616.0L);
+      if (m.mins.size() >= (size_t)m.num && m.mins.back() < thr[g]) thr[g] = m.mins.back();
+      expect += (long double)windows[g] * (((long double)thr[g] + 1.0L) / 18446744073709551616.0L);
+    }
+    uint64_t cap = (uint64_t)(expect * 1.25L) + 65536;
+    // one launch over the whole batch: the kernel looks the threshold up per record
+    std::vector<uint64_t> thr_of_rec(nrec);
+    for (uint32_t r = 0; r < nrec; r++) thr_of_rec[r] = thr[grp[r]];
+    E.vendbuf2.ensure((size_t)nrec * 8);
+    HIP_CHECK(hipMemcpyAsync(E.vendbuf2.ptr, thr_of_rec.data(), (size_t)nrec * 8, hipMemcpyHostToDevice, s));
+    src.thr_rec = E.vendbuf2.as<uint64_t>();
+    const long double favg = expect / (long double)(P ? P : 1);
+    const uint64_t thr_avg = favg >= 1.0L ? UINT64_MAX : (uint64_t)(favg * 18446744073709551616.0L);   // sizes the LDS stage only
+    uint64_t n = 0;
+    for (int attempt = 0;; attempt++) {
+      if (cap >= (1ull << 31)) throw_internal("candidate set of one grouped batch exceeds 2^31 entries");
+      E.cand_hash[0].ensure(cap * 8); E.cand_hash[1].ensure(cap * 8);
+      E.cand_pos[0].ensure(cap * 8); E.cand_pos[1].ensure(cap * 8);
+      E.counter.ensure(8);
+      HIP_CHECK(hipMemsetAsync(E.counter.ptr, 0, 8, s));
+      CandSink sink;
+      sink.hash = E.cand_hash[0].as<uint64_t>(); sink.pos = E.cand_pos[0].as<uint64_t>();
+      sink.count = E.counter.as<unsigned long long>(); sink.capacity = cap;
+      src.launch(0, P, thr_avg, sink, s);
+      unsigned long long got = 0;
+      HIP_CHECK(hipMemcpyAsync(&got, E.counter.ptr, 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      n = got;
+      if (n <= cap) break;
+      if (attempt) throw_internal("candidate buffer overflow after re-run");
+      cap = n;   // the counter kept counting: exact size for the re-run
+    }
+    std::vector<uint8_t> resolved(n_mh, 0);
+    fold_groups(n, [&](uint32_t g, const uint64_t* hashes, size_t cnt, const uint32_t*, uint32_t) {
+      KmerMinHash& mh = *mhs[g];
+      if (cnt < (size_t)mh.num && thr[g] != UINT64_MAX && !(mh.mins.size() >= (size_t)mh.num && thr[g] == mh.mins.back()))
+        return;
+      resolved[g] = 1;
+      d.uniq.assign(hashes, hashes + std::min(cnt, (size_t)mh.num));
+      apply_num(mh, d, E, s);
+    });
+    // groups with no candidate at all under an exhaustive threshold have nothing to add
+    for (uint32_t g = 0; g < n_mh; g++)
+      if (thr[g] == UINT64_MAX || (mhs[g]->mins.size() >= (size_t)mhs[g]->num && thr[g] == mhs[g]->mins.back())) resolved[g] = 1;
+    // (validation above already holds the batch's first error; serve_run keeps the earliest)
+    for (const RecRun& rr : runs)
+      if (!resolved[grp[rr.r0]] && windows[grp[rr.r0]] > 0) serve_run(rr);
+  }
   if (have_error) {
     if (first_error) *first_error = err;
     else throw err;

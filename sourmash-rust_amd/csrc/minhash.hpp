@@ -82,6 +82,14 @@ struct KmerMinHash {
                             uint32_t nrec, bool force, hipStream_t stream, Error* first_error);
 };
 
+// Many sketches from one batch (additive C ABI smh_add_sequences_grouped): record r feeds
+// sketches[group_of_rec[r]].  Semantics per sketch: add_sequences_device over its records in
+// order.  Scaled DNA sketches with equal (ksize, seed, max_hash) share one hashing launch and one
+// sort; anything else is served sketch by sketch.
+void add_sequences_grouped(KmerMinHash* const* sketches, uint32_t n_sketches, const uint8_t* d_seq, uint64_t total_len,
+                           const uint64_t* h_offsets, const uint32_t* group_of_rec, uint32_t nrec, bool force,
+                           hipStream_t stream, Error* first_error);
+
 // One process-wide workspace: candidate buffers, sort ping-pong, small staging areas.
 // Entry points take the Device mutex (recursive).
 using HashSourceRef = void*;  // HashSource* of minhash.cpp
@@ -104,7 +112,8 @@ class Engine {
                     const uint32_t* row_nums_host, uint32_t num, uint64_t* common, uint64_t* size,
                     double* jaccard, uint64_t* count_common, double* containment);
 
-  DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, starts, red_b, misc, seqbuf, offbuf, vendbuf;
+  DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, uniq2, starts, red_b, misc, seqbuf, offbuf, vendbuf, vendbuf2, grpbuf;
+  PinnedBuffer pin_a, pin_b;
   DeviceBuffer resbuf, segbuf, badbuf, cmp_a, cmp_b, cmp_oa, cmp_ob, cmp_out;
 
  private:

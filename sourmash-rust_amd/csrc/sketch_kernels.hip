@@ -165,7 +165,9 @@ __device__ __forceinline__ uint64_t murmur_kmer(const uint32_t (&D)[4 * L], int 
 // L = 32-bit limbs of a packed window: 2 for ksize <= 32, 4 for ksize <= 64, 8 for ksize <= 128.
 // THREADS lanes per workgroup share one LUT; HB = hashes computed together in one straight-line
 // block (independent murmur chains the scheduler can interleave).
-template <int KT, int THREADS, int HB, int L>
+// PR: thresholds are looked up per record (hp.thr_rec; grouped bottom-num batches) instead of the
+// launch-uniform hp.thr
+template <int KT, int THREADS, int HB, int L, bool PR = false>
 __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
                                                          int logR, uint32_t stage_cap) {
   // LDS: [LUT 16 KiB][staged candidates: count, hashes, positions][sequence tile]
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
 
   for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const uint64_t T0 = hp.range_lo + tix * TILE;
-    const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+    const uint64_t thr = hp.thr;
+    uint64_t lthr = hp.thr;   // PR: threshold of the record the lane is in
 
     // ---- stage [T0, T0 + TILE + K - 1) in LDS: aligned 16-byte loads, one pad dword per R bytes
     const uintptr_t g0 = (uintptr_t)(b.seq + T0);
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     if (multi) {
       rec = find_record(b.starts, b.nrec, p0);
       cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+      if (PR) lthr = hp.thr_rec[rec];
     }
     uint32_t lim = 0;
     if (cur_end > p0) lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
       for (int g0b = 0; g0b < 4; g0b += HB) {
         uint32_t X[HB][L];
         bool ok[HB];
+        uint64_t tq[PR ? HB : 1];   // PR: the threshold in force at each of the HB bases
 #pragma unroll
         for (int q = 0; q < HB; q++) {
           const int bb = g0b + q;
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
             if (multi) {
               while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vrun = 0; }
               cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+              if (PR) lthr = hp.thr_rec[rec];
             }
             if (qpos >= cur_end) { bad = 1; lim = i + 1; }
             else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
 #pragma unroll
           for (int li = 0; li < L; li++) X[q][li] = fwd ? fle[li] : ~fbe[li];  // chosen strand, first base low
           ok[q] = (vrun >= (uint32_t)K) && (i + 1 >= (uint32_t)K) && (i + 1 - (uint32_t)K < nk);
+          if (PR) tq[q] = lthr;
         }
         if (i0 + g0b + HB >= (uint32_t)K) {  // uniform: past the warm-up bases
           uint64_t h[HB];
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
           }
 #pragma unroll
           for (int q = 0; q < HB; q++)
-            if (ok[q] && h[q] <= thr)
+            if (ok[q] && h[q] <= (PR ? tq[q] : thr))
               stage_emit(stage, sink, h[q], hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K));
         }
       }
@@ -349,13 +356,13 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
 __global__ __launch_bounds__(256) void k_dna_generic(SeqBatch b, HashParams hp, CandSink sink) {
   const uint64_t K = hp.ksize;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
   for (uint64_t p = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < hp.range_hi;
        p += stride) {
-    uint64_t end = b.vend0;
+    uint64_t end = b.vend0, thr = hp.thr;
     if (b.starts) {
       uint32_t r = find_record(b.starts, b.nrec, p);
       end = b.vends ? b.vends[r] : b.starts[r + 1];
+      if (hp.thr_rec) thr = hp.thr_rec[r];
     }
     if (p + K > end || p + K < p) continue;
     const uint8_t* s = b.seq + p;
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict_
   if (threadIdx.x == 0) wsm[0] = 0;
   __syncthreads();
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * kWinRun;
-  const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+  const uint64_t thr = hp.thr;
   const bool aligned = ((hp.range_lo | (uintptr_t)res) & 7) == 0 && win <= 32 && win >= 1;
   // the loop bound is the same for every lane of the workgroup: the flush inside synchronises
   for (uint64_t b0 = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x * kWinRun; b0 < hp.range_hi; b0 += stride) {
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(256) void k_hash_segments(const uint8_t* __restrict
 // the append remain; the stream position of hash i is i.
 __global__ __launch_bounds__(256) void k_filter_hashes(const uint64_t* __restrict__ hashes, HashParams hp, CandSink sink) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t thr = hp.thr_ptr ? *hp.thr_ptr : hp.thr;
+  const uint64_t thr = hp.thr;
   for (uint64_t i = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hp.range_hi; i += stride) {
     const uint64_t h = hashes[i];
     if (h <= thr) emit(sink, h, hp.pos_base + i);
@@ -715,6 +722,10 @@ template <int KT, int L>
 static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSink& sink, int grid, size_t lds,
                            int logR, uint32_t stage_cap, const DnaCfg& c, hipStream_t s) {
 #define SMH_LAUNCH(T, H) hipLaunchKernelGGL((k_dna_rolling<KT, T, H, L>), dim3(grid), dim3(T), lds, s, b, p, sink, logR, stage_cap)
+  if (p.thr_rec) {   // per-record thresholds: default geometry only
+    hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
+    return;
+  }
   if (c.threads == 512) { if (c.hb == 4) SMH_LAUNCH(512, 4); else if (c.hb == 2) SMH_LAUNCH(512, 2); else SMH_LAUNCH(512, 1); }
   else { if (c.hb == 4) SMH_LAUNCH(256, 4); else if (c.hb == 2) SMH_LAUNCH(256, 2); else SMH_LAUNCH(256, 1); }
 #undef SMH_LAUNCH
@@ -728,7 +739,7 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
   if (p.ksize >= 1 && p.ksize <= 128 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
-    const DnaCfg c = dna_cfg();
+    const DnaCfg c = p.thr_rec ? DnaCfg{512, 6, 2} : dna_cfg();   // the per-record variant exists in one geometry
     int logR = c.logR;
     while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * c.threads * 2) logR--;
     const uint64_t tile = (uint64_t)c.threads << logR;

@@ -110,6 +110,29 @@ class KmerMinHash:
         call(self._L.smh_add_sequences_dev, self._p, C.c_void_p(dev_ptr), total_len, off.ctypes.data_as(u64p),
              off.size - 1, bool(force), C.c_void_p(stream or 0))
 
+    @staticmethod
+    def add_sequences_grouped(sketches, records, groups, force=False):
+        """records[r] feeds sketches[groups[r]]: many signatures from one device pass
+        (additive ABI smh_add_sequences_grouped)."""
+        L = sketches[0]._L
+        records = [bytes(r) for r in records]
+        off = np.zeros(len(records) + 1, dtype=np.uint64)
+        for i, r in enumerate(records):
+            off[i + 1] = off[i] + len(r)
+        grp = np.ascontiguousarray(groups, dtype=np.uint32)
+        arr = (C.c_void_p * len(sketches))(*[m._p for m in sketches])
+        call(L.smh_add_sequences_grouped, arr, len(sketches), b"".join(records), off.ctypes.data_as(u64p),
+             grp.ctypes.data_as(C.POINTER(C.c_uint32)), len(records), bool(force))
+
+    @staticmethod
+    def add_sequences_grouped_dev(sketches, dev_ptr, total_len, offsets, groups, force=False, stream=None):
+        L = sketches[0]._L
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        grp = np.ascontiguousarray(groups, dtype=np.uint32)
+        arr = (C.c_void_p * len(sketches))(*[m._p for m in sketches])
+        call(L.smh_add_sequences_grouped_dev, arr, len(sketches), C.c_void_p(dev_ptr), total_len, off.ctypes.data_as(u64p),
+             grp.ctypes.data_as(C.POINTER(C.c_uint32)), off.size - 1, bool(force), C.c_void_p(stream or 0))
+
     def merge(self, other): call(self._L.kmerminhash_merge, self._p, other._p)
     def add_from(self, other): call(self._L.kmerminhash_add_from, self._p, other._p)
 

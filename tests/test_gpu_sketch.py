@@ -465,3 +465,73 @@ def test_read_at_a_time_through_the_legacy_abi(pkg, coracle):
         o.add_sequence(r, True)
     assert g.mins == o.mins and n == len(o.mins)
     assert dt < 2.0, "per-read calls must not pay a device launch each (took %.2f s)" % dt
+
+
+def _grouped_case(pkg, coracle, cases, recs, groups, force, prefill=None):
+    gs = [pkg.KmerMinHash(*c) for c in cases]
+    os_ = [coracle.MinHash(*c) for c in cases]
+    if prefill:
+        for g, o in zip(gs, os_):
+            g.add_sequence(prefill, True); o.add_sequence(prefill, True)
+    first = None
+    for r, grp in zip(recs, groups):
+        try:
+            os_[grp].add_sequence(r, force)
+        except coracle.OracleError as e:
+            first = first or e.message
+    if first is None:
+        pkg.KmerMinHash.add_sequences_grouped(gs, recs, groups, force)
+    else:
+        with pytest.raises(pkg.SourmashError) as ei:
+            pkg.KmerMinHash.add_sequences_grouped(gs, recs, groups, force)
+        assert ei.value.code == 1101 and ei.value.message.endswith(first)
+    for g, o in zip(gs, os_):
+        same_state(g, o)
+
+
+def test_grouped_sketching(pkg, coracle):
+    """smh_add_sequences_grouped: record r feeds sketches[groups[r]].  One launch + one (group, hash)
+    sort for scaled DNA sketches with equal parameters; sketch-by-sketch service for the rest.  Each
+    sketch must equal the oracle fed its own records in order."""
+    rng = random.Random(77)
+    n_groups = 23
+    recs = [rand_seq(rng, rng.choice([0, 5, 20, 21, 22, 100, 151, 2000, 30000]), bad=rng.choice([0, 0, 0.002]))
+            for _ in range(400)]
+    interleaved = [rng.randrange(n_groups) for _ in recs]
+    contiguous = sorted(interleaved)
+    scaled = (0, 21, False, 42, 1 << 58, True)
+    for groups in (interleaved, contiguous):
+        _grouped_case(pkg, coracle, [scaled] * n_groups, recs, groups, True)                      # shared launch
+        _grouped_case(pkg, coracle, [scaled[:5] + (False,)] * n_groups, recs, groups, True, prefill=recs[-1])
+        _grouped_case(pkg, coracle, [scaled] * n_groups, recs, groups, False)                     # first error reported
+        # tracking differs per sketch: still one launch
+        _grouped_case(pkg, coracle, [scaled[:5] + (g % 2 == 0,) for g in range(n_groups)], recs, groups, True)
+    # bottom-num sketches without abundance: per-group thresholds, one launch per run of records,
+    # repetitive groups (fewer than num distinct hashes under the threshold) re-served on their own
+    rep = list(recs)
+    rep[5] = b"ACGTTGCA" * 6000
+    rep[9] = b"A" * 40000
+    rep[11] = rand_seq(rng, 300, 0) * 200
+    for groups in (interleaved, contiguous):
+        _grouped_case(pkg, coracle, [(50, 21, False, 42, 0, False)] * n_groups, rep, groups, True)
+        _grouped_case(pkg, coracle, [(3 + 40 * g, 21, False, 42, 0, False) for g in range(n_groups)], rep, groups, True,
+                      prefill=recs[-2])
+        _grouped_case(pkg, coracle, [(500, 16, False, 7, 0, False)] * n_groups, rep, groups, False)
+    # parameter combinations the shared launch does not serve
+    _grouped_case(pkg, coracle, [(50, 21, False, 42, 0, True)] * n_groups, recs, interleaved, True)
+    _grouped_case(pkg, coracle, [(0, 21, False, 42, (1 << 58) + g, False) for g in range(n_groups)], recs, contiguous, True)
+    _grouped_case(pkg, coracle, [(0, 21, True, 42, 1 << 60, True)] * n_groups, recs[:60], interleaved[:60], True)
+    _grouped_case(pkg, coracle, [(5, 5, False, 42, 1 << 62, True)] * n_groups, recs[:100], interleaved[:100], True)
+    # a group without records stays empty; group ids out of range are rejected
+    gs = [pkg.KmerMinHash(*scaled) for _ in range(3)]
+    pkg.KmerMinHash.add_sequences_grouped(gs, [rand_seq(rng, 5000, 0), rand_seq(rng, 5000, 0)], [2, 0], True)
+    assert gs[1].mins == [] and gs[0].mins and gs[2].mins
+    with pytest.raises(pkg.SourmashError) as ei:
+        pkg.KmerMinHash.add_sequences_grouped(gs, [b"ACGT" * 50], [3], True)
+    assert ei.value.code == 2
+    # the same sketch listed for two groups receives both
+    a = pkg.KmerMinHash(*scaled); o = coracle.MinHash(*scaled)
+    pkg.KmerMinHash.add_sequences_grouped([a, a], [recs[3], recs[5], recs[8]], [0, 1, 0], True)
+    for r in (recs[3], recs[5], recs[8]):
+        o.add_sequence(r, True)
+    same_state(a, o)

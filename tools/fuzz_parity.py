@@ -78,7 +78,47 @@ while time.time() < t_end:
     if time.time() - t_print > 30:
         t_print = time.time()
         print("... %d sketch cases, %d compare blocks so far" % (n_sk, n_cmp), flush=True)
-    if rng.random() < 0.75:
+    if rng.random() < 0.12:
+        # grouped sketching: record r feeds sketch groups[r]; each sketch must equal the oracle fed its records
+        ng = rng.randint(2, 12)
+        k = rng.choice([4, 9, 16, 21, 31, 32, 33, 51, 70])
+        kind = rng.choice(["scaled", "scaled", "num", "num", "mixed"])
+        seedv = rng.choice([42, 7])
+        def params(gi):
+            if kind == "scaled":
+                return (0, k, False, seedv, 1 << 60, gi % 2 == 0)
+            if kind == "num":
+                return (rng.choice([1, 5, 50, 300]), k, False, seedv, 0, False)
+            return rng.choice([(0, k, False, seedv, 1 << 60, True), (20, k, False, seedv, 0, True), (20, k, False, seedv, 0, False),
+                               (5, k, False, seedv, 1 << 62, False), (0, max(k, 6), True, seedv, 1 << 61, False)])
+        cases = [params(gi) for gi in range(ng)]
+        gs, os2 = [pkg.KmerMinHash(*c) for c in cases], [coracle.MinHash(*c) for c in cases]
+        for _ in range(rng.randint(1, 2)):
+            force = rng.random() < 0.7
+            recs = [rand_seq(rng.choice([0, 1, k - 1, k, k + 1, 50, 151, 400, 400, 3000, 40000])) for _ in range(rng.randint(2, 60))]
+            if rng.random() < 0.3:
+                recs[rng.randrange(len(recs))] = rand_seq(rng.choice([8, 50])) * 800     # repetitive: few distinct k-mers
+            groups = [rng.randrange(ng) for _ in recs]
+            if rng.random() < 0.5:
+                groups.sort()
+            eg = eo = None
+            try:
+                pkg.KmerMinHash.add_sequences_grouped(gs, recs, groups, force)
+            except pkg.SourmashError as e:
+                eg = (e.code, gmsg(e))
+            for r, gi in zip(recs, groups):
+                try:
+                    os2[gi].add_sequence(r, force)
+                except coracle.OracleError as e:
+                    if eo is None:
+                        eo = (e.code, omsg(e))
+            if eg != eo or any(state(a) != state(b) for a, b in zip(gs, os2)):
+                print("GROUPED MISMATCH kind", kind, "k", k, "cases", cases, "errors", eg, eo)
+                import pickle
+                pickle.dump((cases, recs, groups, force), open("gpurun_out/fuzz_fail_grouped.pkl", "wb"))
+                sys.exit(1)
+        n_sk += 1
+    elif rng.random() < 0.72:
         prot = rng.random() < 0.25
         k = rng.choice([1, 2, 3, 4, 5, 7, 9, 11, 15, 16, 17, 20, 21, 24, 25, 27, 30, 31, 32, 33, 40, 48, 51, 63, 64, 65, 70, 96, 127, 128, 129, 150])
         if prot and k < 3:
