@@ -651,7 +651,9 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
     E.resbuf.ensure(total + 64);  // k_hash_windows reads whole 8-byte words past the last start
     HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemsetAsync(E.badbuf.ptr, 0, (size_t)nseg * 4, s));
+    dev.prof_begin(s);
     launch_translate(b, E.segbuf.as<uint64_t>(), nseg, total, ksize, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);
+    dev.prof_end("translate", s);
     std::vector<uint32_t> bad(nseg);
     HIP_CHECK(hipMemcpyAsync(bad.data(), E.badbuf.ptr, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));

@@ -443,9 +443,11 @@ __device__ __forceinline__ bool utf8_ok3(uint32_t a, uint32_t c, uint32_t d) {
 // from the five bytes p-2 .. p+2, served from an LDS tile that the workgroup loaded with coalesced
 // 16-byte reads.  Segment order in the residue buffer: reference src/lib.rs:280-300.
 constexpr int kTrThreads = 256;
-// 3 consecutive bases per lane: at a given q all lanes of a wave are in the same frame and their
-// residue indices are consecutive, so the byte stores of a wave fall in one contiguous run per frame
-constexpr int kTrPerThread = 3;
+// 12 consecutive bases per lane: every frame gets 4 consecutive residues from a lane (forward:
+// ascending, reverse: descending), written as ONE unaligned 4-byte store; consecutive lanes write
+// consecutive dwords of the same frame.  (One byte store per residue -- 25 G of them for 12.5 GB
+// of DNA -- is what bounded the first version, not HBM.)
+constexpr int kTrPerThread = 12;
 constexpr int kTrTile = kTrThreads * kTrPerThread;  // bases per workgroup tile
 
 __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint64_t* __restrict__ seg_off,
@@ -465,8 +467,18 @@ __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint
   }
   const uint64_t ntiles = (b.len + kTrTile - 1) / kTrTile;
   const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
-  for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+  // a workgroup owns a CONTIGUOUS run of tiles: the record holding the tile start is found by
+  // binary search once and then walked forward (a search per lane per tile is a chain of ~14
+  // dependent loads for 10^4 records -- it used to dominate this bandwidth-bound kernel)
+  const uint64_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+  const uint64_t t_begin = (uint64_t)blockIdx.x * per_wg;
+  const uint64_t t_end = t_begin + per_wg < ntiles ? t_begin + per_wg : ntiles;
+  uint32_t rec0 = 0;
+  if (b.starts && t_begin < t_end) rec0 = find_record(b.starts, b.nrec, t_begin * kTrTile);
+  for (uint64_t tix = t_begin; tix < t_end; tix++) {
     const uint64_t T0 = tix * kTrTile;
+    if (b.starts)
+      while (rec0 + 1 < b.nrec && T0 >= b.starts[rec0 + 1]) rec0++;   // uniform
     // tile bytes [T0 - 16, T0 + kTrTile + 16) relative to an aligned base (a halo of 2 each side is needed)
     const uintptr_t g0 = (uintptr_t)(b.seq + T0);
     const uintptr_t ga = (g0 & ~(uintptr_t)15) - 16;
@@ -490,10 +502,54 @@ __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint
     uint64_t rs = 0, re = b.len;
     const uint64_t pfirst = T0 + (uint64_t)tid * kTrPerThread;
     if (b.starts && pfirst < b.len) {
-      rec = find_record(b.starts, b.nrec, pfirst);
+      rec = rec0;
+      // many tiny records inside one tile: search instead of walking
+      if (rec0 + 8 < b.nrec && pfirst >= b.starts[rec0 + 8]) rec = find_record(b.starts, b.nrec, pfirst);
       rs = b.starts[rec]; re = b.starts[rec + 1];
     }
+    // fast path: the lane's 12 bases and their 2-base halos lie inside one record that is long enough
+    bool packed = false;
+    if (pfirst < b.len) {
+      while (pfirst >= re) { rec++; rs = b.starts[rec]; re = b.starts[rec + 1]; }
+      const uint64_t rl = re - rs, o = pfirst - rs;
+      packed = rl >= ksize && o >= 2 && o + kTrPerThread + 2 <= rl;
+      if (packed) {
+        const uint32_t x0 = m + (uint32_t)(pfirst - T0);
+        uint32_t k[kTrPerThread + 4];   // codes of bases pfirst-2 .. pfirst+13
+        uint32_t anybad = 0;
 #pragma unroll
+        for (int i = 0; i < kTrPerThread + 4; i++) { k[i] = code[x0 - 2 + i]; anybad |= k[i]; }
+        if (anybad & 0x80u) packed = false;   // a non-base byte: the per-base path sorts out dropped codons / UTF-8
+        if (packed) {
+          const uint32_t of = (uint32_t)(o % 3);
+          const uint64_t back0 = rl - 1 - o;          // reverse index of the lane's first base
+          const uint32_t bf = (uint32_t)(back0 % 3);
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            // forward codons starting at bases c, c+3, c+6, c+9 of the run: frame (o+c)%3, residues (o+c)/3 ..+3
+            uint32_t v = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const int i = 2 + c + 3 * t;
+              v |= (uint32_t)lut_aa[(k[i] << 4) | (k[i + 1] << 2) | k[i + 2]] << (8 * t);
+            }
+            uint32_t fr = of + c; fr = fr >= 3 ? fr - 3 : fr;
+            __builtin_memcpy(res + seg_off[6 * rec + 2 * fr] + (o + c) / 3, &v, 4);
+            // reverse codons whose first base is base c, c+3, c+6, c+9: reverse index back0-c-3t,
+            // frame (back0-c)%3, residues (back0-c)/3 down to (back0-c)/3-3
+            uint32_t w = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const int i = 2 + c + 3 * t;
+              w |= (uint32_t)lut_aa[((k[i] << 4) | (k[i - 1] << 2) | k[i - 2]) ^ 0x2a] << (8 * (3 - t));
+            }
+            uint32_t br = bf + 3 - c; br = br >= 3 ? br - 3 : br;
+            __builtin_memcpy(res + seg_off[6 * rec + 2 * br + 1] + (back0 - c) / 3 - 3, &w, 4);
+          }
+        }
+      }
+    }
+    if (!packed) {
     for (int q = 0; q < kTrPerThread; q++) {
       const uint64_t p = pfirst + q;
       if (p >= b.len) break;
@@ -526,6 +582,7 @@ __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint
         res[seg_off[seg] + back / 3] = bad ? (uint8_t)kDropped : lut_aa[(((k0 << 4) | (k1 << 2) | k2)) ^ 0x2a];
       }
     }
+    }
   }
 }
 
@@ -547,11 +604,15 @@ __device__ __forceinline__ void hash_window_slow(const uint8_t* __restrict__ res
 }
 
 constexpr int kWinRun = 8;
+// W: compile-time window length (0 = run-time `win_rt`): with W known the loads, the byte shifts and
+// murmur's block / tail structure are all static
+template <int W>
 __device__ __forceinline__ void hash_run(const uint8_t* __restrict__ res, const uint64_t* __restrict__ seg_off,
-                                         uint32_t nseg, uint32_t win, const HashParams& hp, uint64_t thr,
+                                         uint32_t nseg, uint32_t win_rt, const HashParams& hp, uint64_t thr,
                                          const CandSink& sink, const Stage& stage, bool aligned, uint64_t g0,
                                          uint64_t blk_seg_end) {
   {
+    const uint32_t win = W ? (uint32_t)W : win_rt;
     // the workgroup's first segment was looked up once with uniform (scalar) loads; only lanes
     // past its end search for their own
     uint64_t end = blk_seg_end;
@@ -617,6 +678,7 @@ __device__ __forceinline__ void hash_run(const uint8_t* __restrict__ res, const 
 // (aligned 8-byte loads).  When that stretch lies inside one segment and holds no dropped codon --
 // the normal case -- every window is a byte-shifted view of those registers; otherwise the lane
 // falls back to the residue-by-residue walk.  win <= 32 for the fast path.
+template <int W>
 __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict__ res,
                                                       const uint64_t* __restrict__ seg_off,
                                                       uint32_t nseg, uint32_t win, HashParams hp,
@@ -625,14 +687,24 @@ __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict_
   const Stage stage{wsm, reinterpret_cast<uint64_t*>(wsm + 4), reinterpret_cast<uint64_t*>(wsm + 4) + stage_cap, stage_cap};
   if (threadIdx.x == 0) wsm[0] = 0;
   __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * kWinRun;
   const uint64_t thr = hp.thr;
   const bool aligned = ((hp.range_lo | (uintptr_t)res) & 7) == 0 && win <= 32 && win >= 1;
+  // a workgroup owns a contiguous run of passes (2048 window starts each): the segment of the
+  // pass start is searched once and then walked forward with uniform loads
+  const uint64_t pass = (uint64_t)blockDim.x * kWinRun;
+  const uint64_t npass = (hp.range_hi - hp.range_lo + pass - 1) / pass;
+  const uint64_t per_wg = (npass + gridDim.x - 1) / gridDim.x;
+  const uint64_t p_begin = (uint64_t)blockIdx.x * per_wg;
+  const uint64_t p_end = p_begin + per_wg < npass ? p_begin + per_wg : npass;
+  uint32_t seg = 0;
+  if (p_begin < p_end) seg = find_record(seg_off, nseg, hp.range_lo + p_begin * pass);
   // the loop bound is the same for every lane of the workgroup: the flush inside synchronises
-  for (uint64_t b0 = hp.range_lo + (uint64_t)blockIdx.x * blockDim.x * kWinRun; b0 < hp.range_hi; b0 += stride) {
+  for (uint64_t ps = p_begin; ps < p_end; ps++) {
+    const uint64_t b0 = hp.range_lo + ps * pass;
     const uint64_t g0 = b0 + (uint64_t)threadIdx.x * kWinRun;
-    const uint64_t blk_seg_end = seg_off[find_record(seg_off, nseg, b0) + 1];   // b0 is uniform
-    if (g0 < hp.range_hi) hash_run(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0, blk_seg_end);
+    while (seg + 1 < nseg && b0 >= seg_off[seg + 1]) seg++;   // b0 is uniform
+    const uint64_t blk_seg_end = seg_off[seg + 1];
+    if (g0 < hp.range_hi) hash_run<W>(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0, blk_seg_end);
     // a pass covers only 2048 windows: flushing (a returning global atomic) every pass would cost
     // more than the hashing; wait until the stage is half full
     stage_flush(stage, sink, threadIdx.x, blockDim.x, stage_cap / 2);
@@ -793,8 +865,11 @@ void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* s
   if (p.range_hi <= p.range_lo) return;
   const uint32_t stage_cap = 1024;
   const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1);
-  hipLaunchKernelGGL(k_hash_windows, dim3(grid_for((p.range_hi - p.range_lo + kWinRun - 1) / kWinRun, 256, 16384)),
-                     dim3(256), lds, s, bytes, seg_offsets, nseg, win, p, sink, stage_cap);
+  const dim3 grid(grid_for((p.range_hi - p.range_lo + kWinRun - 1) / kWinRun, 256, 16384));
+#define SMH_HW(W_) hipLaunchKernelGGL(k_hash_windows<W_>, grid, dim3(256), lds, s, bytes, seg_offsets, nseg, win, p, sink, stage_cap)
+  // the usual protein k-mer sizes (ksize 21 / 27 / 30 nucleotides) get static instantiations
+  if (win == 7) SMH_HW(7); else if (win == 9) SMH_HW(9); else if (win == 10) SMH_HW(10); else SMH_HW(0);
+#undef SMH_HW
   HIP_CHECK(hipGetLastError());
 }
 
