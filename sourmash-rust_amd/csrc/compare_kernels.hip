@@ -511,6 +511,9 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // that the launch still covers the chip several times
   // geometry "rpw,wpb,minw" (experiments: SOURMASH_AMD_CMP_GEO)
   int rpw = 4, wpb = 4, minw = 8;
+  // fewer than ~4 rounds of 16-row tiles over the chip: 8-row tiles keep all wave slots busy
+  // (1000 x 1000: 2.47 -> 2.20 ms, profiles/r01_compare_small_geometry.txt)
+  if ((uint64_t)((rows.n + 15) / 16) * ((cols.n + kTB - 1) / kTB) < (uint64_t)dev.cu_count() * 32) rpw = 2;
   if (const char* e = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(e, "%d,%d,%d", &rpw, &wpb, &minw);
   const uint32_t tr = (uint32_t)(rpw * wpb);
   const uint32_t tiles = ((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
@@ -523,7 +526,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     else hipLaunchKernelGGL((k_compare_tiled<false, R_, W_, M_>), dim3(tiles), dim3(64 * W_), lds, s, a);        \
   }
   SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
-  SMH_CT(4, 4, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
+  SMH_CT(4, 4, 8) SMH_CT(2, 4, 8) SMH_CT(1, 4, 8) SMH_CT(1, 8, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
 #undef SMH_CT
   if (!launched) throw_internal("compare geometry not instantiated");
   HIP_CHECK(hipGetLastError());

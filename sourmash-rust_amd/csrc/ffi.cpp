@@ -581,28 +581,21 @@ SmhIndex* smh_index_new(KmerMinHash* const* nodes, uint32_t n_nodes) {
     if (n_nodes) require(nodes, "nodes");
     auto idx = std::make_unique<SmhIndex>();
     idx->n = n_nodes;
-    idx->h_offsets.assign(n_nodes + 1, 0);
     idx->h_nums.resize(n_nodes);
+    std::vector<const smh::KmerMinHash*> v(n_nodes);
     for (uint32_t i = 0; i < n_nodes; i++) {
       require(nodes[i], "nodes[i]");
-      nodes[i]->materialize();
-      idx->h_offsets[i + 1] = idx->h_offsets[i] + nodes[i]->mins.size();
+      v[i] = nodes[i];
       idx->h_nums[i] = nodes[i]->num;
-      idx->max_len = std::max<uint32_t>(idx->max_len, (uint32_t)nodes[i]->mins.size());
       smh::KmerMinHash p(nodes[i]->num, nodes[i]->ksize, nodes[i]->is_protein, nodes[i]->seed, nodes[i]->max_hash, false);
       idx->params.push_back(p);
     }
     auto& dev = smh::Device::get();
     std::lock_guard<std::recursive_mutex> lock(dev.mutex());
     hipStream_t s = dev.stream();
-    idx->hashes.ensure(idx->h_offsets.back() * 8 + 8);
-    idx->offsets.ensure((size_t)(n_nodes + 1) * 8);
+    smh::SketchSet set;
+    smh::Engine::get().pack_sketches(v, idx->hashes, idx->offsets, &set, &idx->max_len, &idx->h_offsets, s);
     idx->nums.ensure((size_t)n_nodes * 4 + 4);
-    for (uint32_t i = 0; i < n_nodes; i++)
-      if (!nodes[i]->mins.empty())
-        HIP_CHECK(hipMemcpyAsync(idx->hashes.as<uint64_t>() + idx->h_offsets[i], nodes[i]->mins.data(),
-                                 nodes[i]->mins.size() * 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(idx->offsets.ptr, idx->h_offsets.data(), (size_t)(n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
     if (n_nodes) HIP_CHECK(hipMemcpyAsync(idx->nums.ptr, idx->h_nums.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));
     return idx.release();

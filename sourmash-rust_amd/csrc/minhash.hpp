@@ -112,6 +112,10 @@ class Engine {
                     const uint32_t* row_nums_host, uint32_t num, uint64_t* common, uint64_t* size,
                     double* jaccard, uint64_t* count_common, double* containment);
 
+  // CSR upload of host-resident sketches (materialises them; gathers through pinned staging)
+  void pack_sketches(const std::vector<const KmerMinHash*>& v, DeviceBuffer& data, DeviceBuffer& offs, SketchSet* out,
+                     uint32_t* maxlen, std::vector<uint64_t>* h_off, hipStream_t s);
+
   DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, uniq2, starts, red_b, misc, seqbuf, offbuf, vendbuf, vendbuf2, grpbuf;
   PinnedBuffer pin_a, pin_b;
   DeviceBuffer resbuf, segbuf, badbuf, cmp_a, cmp_b, cmp_oa, cmp_ob, cmp_out;

@@ -1,0 +1,5 @@
+for g in 4,4,8 2,4,8 1,4,8 1,8,8 2,8,8; do
+  for n in 1000 2500; do
+    echo "GEO $g n=$n: $(SOURMASH_AMD_CMP_GEO=$g timeout -k 10 120 python tools/prof_compare_1000.py $n 2>/dev/null | tail -1)"
+  done
+done

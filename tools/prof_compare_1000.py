@@ -1,0 +1,17 @@
+"""C3: 1000 x 1000 num=2000 matrix on device-resident signatures, repeated; for rocprofv3 --kernel-trace --stats."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import torch
+from __graft_entry__ import load_package
+pkg = load_package()
+from sourmash_rust_amd import synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+sigs = synth.family_signatures(0, n, num=2000, seed=3)
+t = torch.from_numpy(sigs.view(np.int64)).cuda()
+off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
+for it in range(12):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard",))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("n=%d: %.3f ms per matrix (%.1f M pairs/s)" % (n, dt * 1e3, n * n / dt / 1e6))
