@@ -5,7 +5,9 @@
  * sketches per call.  These symbols add what a GPU needs: explicit lengths, many records per
  * call, device-resident buffers, and an N x M compare block.  None of them changes or shadows
  * a reference symbol.  Plain pointers and sizes only; `stream` is a hipStream_t passed as
- * void* (NULL = the library's own stream).  "dev" pointers are HIP device pointers.
+ * void*.  NULL = the library's own stream, which is first ordered after everything already queued
+ * on the legacy default stream (where a caller without streams of its own produced the inputs);
+ * every entry point returns with its device work complete.  "dev" pointers are HIP device pointers.
  *
  * Error convention: same thread-local slot as sourmash.h; functions returning int return 0 on
  * success and the SourmashErrorCode otherwise.

@@ -56,6 +56,15 @@ Device::Device() {
   HIP_CHECK(hipGetDeviceProperties(&p, device_));
   cus_ = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&fence_, hipEventDisableTiming));
+}
+
+hipStream_t Device::user_stream(void* given) {
+  if (given) return (hipStream_t)given;
+  std::lock_guard<std::recursive_mutex> lock(mu_);
+  HIP_CHECK(hipEventRecord(fence_, nullptr));
+  HIP_CHECK(hipStreamWaitEvent(stream_, fence_, 0));
+  return stream_;
 }
 
 Device& Device::get() {

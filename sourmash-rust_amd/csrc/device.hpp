@@ -63,6 +63,11 @@ class Device {
   int id() const { return device_; }
   int cu_count() const { return cus_; }
   hipStream_t stream() const { return stream_; }
+  // The stream an entry point with a `void *stream` argument works on.  Non-null: the caller's.
+  // Null: the library's own (non-blocking) stream, first ordered after everything already queued
+  // on the legacy default stream -- a caller whose "current stream" is the default one (torch's
+  // usual state, handle 0) may have produced the inputs there, e.g. an all-gather it just waited on.
+  hipStream_t user_stream(void* given);
   std::recursive_mutex& mutex() { return mu_; }
 
   // scratch shared by the fold / sort primitives (guarded by mutex())
@@ -81,6 +86,7 @@ class Device {
   int device_ = 0;
   int cus_ = 256;
   hipStream_t stream_ = nullptr;
+  hipEvent_t fence_ = nullptr;
   std::recursive_mutex mu_;
   bool profiling_ = false;
   struct Pending { std::string name; hipEvent_t a, b; };

@@ -427,8 +427,8 @@ int smh_add_sequences_dev(KmerMinHash* ptr, const void* seq_dev, uint64_t total_
                           uint32_t n_records, bool force, void* stream) {
   return pad_code([&] {
     require(ptr, "ptr"); require(seq_dev, "seq_dev"); require(offsets, "offsets");
-    ptr->add_sequences_device((const uint8_t*)seq_dev, total_len, offsets, n_records, force, (hipStream_t)stream,
-                              nullptr);
+    ptr->add_sequences_device((const uint8_t*)seq_dev, total_len, offsets, n_records, force,
+                              smh::Device::get().user_stream(stream), nullptr);
   });
 }
 
@@ -461,7 +461,7 @@ int smh_add_sequences_grouped_dev(KmerMinHash* const* sketches, uint32_t n_sketc
     for (uint32_t g = 0; g < n_sketches; g++) require(sketches[g], "sketches[g]");
     std::vector<smh::KmerMinHash*> mhs(sketches, sketches + n_sketches);
     smh::add_sequences_grouped(mhs.data(), n_sketches, (const uint8_t*)seq_dev, total_len, offsets, groups, n_records, force,
-                               (hipStream_t)stream, nullptr);
+                               smh::Device::get().user_stream(stream), nullptr);
   });
 }
 
@@ -502,7 +502,7 @@ int smh_compare_block_dev(const uint64_t* row_hashes_dev, const uint64_t* row_of
     auto& dev = smh::Device::get();
     auto& E = smh::Engine::get();
     std::lock_guard<std::recursive_mutex> lock(dev.mutex());
-    hipStream_t s = stream ? (hipStream_t)stream : dev.stream();
+    hipStream_t s = dev.user_stream(stream);
     uint32_t mr = 0, mc = 0;
     for (uint32_t i = 0; i < n_rows; i++) mr = std::max<uint32_t>(mr, (uint32_t)(row_offsets[i + 1] - row_offsets[i]));
     for (uint32_t j = 0; j < n_cols; j++) mc = std::max<uint32_t>(mc, (uint32_t)(col_offsets[j + 1] - col_offsets[j]));
@@ -713,7 +713,9 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
   return pad_code([&] {
     require(out_dev, "out_dev");
     auto& dev = smh::Device::get();
-    smh::launch_synth_dna((uint8_t*)out_dev, start, len, seed, n_every, stream ? (hipStream_t)stream : dev.stream());
+    hipStream_t s = dev.user_stream(stream);
+    smh::launch_synth_dna((uint8_t*)out_dev, start, len, seed, n_every, s);
+    if (!stream) HIP_CHECK(hipStreamSynchronize(s));   // own stream: the buffer is complete on return
   });
 }
 

@@ -328,3 +328,28 @@ def test_few_vs_many_kernel(few_is_row, pkg, coracle):
     out2 = pkg.matrix.compare_block(list(R), list(C_), want=("jaccard", "common", "size"))
     for k in ("jaccard", "common", "size"):
         assert (out2[k] == out[k]).all()
+
+
+def test_inputs_produced_on_the_default_stream_are_ordered(pkg):
+    """A caller without streams of its own (torch's current stream is the legacy default one, handle 0 =
+    'no stream given') may still have asynchronous work in flight that produces the inputs -- an
+    all-gather it has just waited on, a non-blocking copy.  The library's own stream must run after it."""
+    import torch
+    from sourmash_rust_amd import synth
+    n = 700
+    sigs = synth.family_signatures(0, n, num=2000, seed=9)
+    good = torch.from_numpy(sigs.view(np.int64)).pin_memory()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
+    ref = None
+    for trial in range(3):
+        dev = torch.zeros((n, 2000), dtype=torch.int64, device="cuda")
+        busy = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+        for _ in range(4):
+            busy.random_()                          # keeps the default stream busy ahead of the copy
+        dev.copy_(good, non_blocking=True)          # asynchronous: pinned source
+        out = pkg.matrix.compare_block_dev(dev, off, dev, off, 2000, want=("jaccard",))["jaccard"]
+        torch.cuda.synchronize()
+        assert bool((out.diagonal() == 1.0).all())
+        if ref is None:
+            ref = out.clone()
+        assert bool((out == ref).all())
