@@ -1,0 +1,39 @@
+"""The N>1 path of bench.py on real hardware: two ranks that share the one GPU of the test box
+(BENCH_SHARE_GPU=1) with gloo standing in for RCCL.  Exercises what the world-size-1 run never
+reaches: record sharding by rank, the all-gather of the signatures, row-block compare against the
+gathered columns, the cross-rank reductions of the timing and of the per-rank diagonal check."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bench_two_ranks_sharing_the_gpu(pkg):
+    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
+           "--gb", "0.2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--compare-n", "601"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["retained_hashes"] > 0
+    c = d["compare"]
+    assert c["n_signatures"] == 601 and c["self_jaccard_is_1"] is True   # 601: the last row block is short
+    assert d["cpu_baseline"] is None                                      # reported at N=1 only
