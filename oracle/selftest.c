@@ -43,6 +43,22 @@ int main(void) {
   uint64_t cc = 0;
   CHECK(omh_count_common(q, q, &cc) == OMH_OK && cc == 100);
   free(seq);
+  /* Q5: after a merge of full bottom-num sketches the abundance vector is longer than the mins
+   * (never truncated); merging such a sketch again, and compare() (which merges clones), must
+   * size their buffers from the abundance lengths */
+  {
+    omh_t *m1 = omh_new(50, 21, 0, 42, 0, 1), *m2 = omh_new(50, 21, 0, 42, 0, 1);
+    uint64_t x = 88172645463325252ULL;
+    for (int i = 0; i < 400; i++) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      if (i < 300) omh_add_hash(m1, x >> 3);
+      if (i >= 100) omh_add_hash(m2, x >> 3);
+    }
+    CHECK(omh_merge(m2, m1) == OMH_OK && omh_size(m2) == 50 && omh_abunds_size(m2) > 50);
+    CHECK(omh_merge(m2, m1) == OMH_OK && omh_merge(m1, m2) == OMH_OK);
+    CHECK(omh_compare(m1, m2, &j) == OMH_OK && omh_compare(m2, m1, &j) == OMH_OK);
+    omh_free(m1); omh_free(m2);
+  }
   omh_free(a); omh_free(b); omh_free(c); omh_free(d); omh_free(p); omh_free(q);
   printf("oracle selftest ok\n");
   return 0;

@@ -362,7 +362,10 @@ int omh_merge(omh_t *mh, const omh_t *other) {
   if (st != OMH_OK) return st;
   size_t max_size = mh->n + other->n;
   uint64_t *merged = (uint64_t *)malloc((max_size ? max_size : 1) * sizeof(uint64_t));
-  uint64_t *mab = (uint64_t *)malloc((max_size ? max_size : 1) * sizeof(uint64_t));
+  /* the abundance vectors may be LONGER than the mins (Q5: a merge never truncates them), and
+   * every push below consumes at least one entry of one of them */
+  size_t max_ab = mh->an + other->an;
+  uint64_t *mab = (uint64_t *)malloc((max_ab ? max_ab : 1) * sizeof(uint64_t));
   size_t mn = 0, man = 0;
   size_t si = 0, oi = 0;       /* positions in the two mins */
   size_t sai = 0, oai = 0;     /* positions in the two abundance iterators */
@@ -400,7 +403,7 @@ int omh_merge(omh_t *mh, const omh_t *other) {
   free(mh->mins);
   mh->mins = merged; mh->n = keep; mh->cap = max_size ? max_size : 1;
   free(mh->abunds);
-  mh->abunds = mab; mh->an = man; mh->acap = max_size ? max_size : 1;
+  mh->abunds = mab; mh->an = man; mh->acap = max_ab ? max_ab : 1;
   mh->has_abunds = 1;          /* Q5: always Some(..) afterwards, never truncated */
   return OMH_OK;
 }

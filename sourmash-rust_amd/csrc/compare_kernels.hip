@@ -119,6 +119,80 @@ __global__ __launch_bounds__(64) void k_compare_wave(SketchSet rows, SketchSet c
 }
 
 // ---------------------------------------------------------------------------------
+// One ordered pair from plain pointers (the pairwise reference API on mirrored sketches): no CSR
+// tables to upload, the counts come back in one small struct and the host derives every output.
+//   k_pair_block  one workgroup: merge path over all its lanes, workgroup scan of the per-lane
+//                 union counts for the truncation point n = self.num.
+//   k_pair_grid   no truncation (n == 0, scaled sketches of any size): the merged sequence is cut
+//                 over the whole grid, every wave adds its census with two atomics.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pair_block(const uint64_t* __restrict__ A, uint32_t la,
+                                                        const uint64_t* __restrict__ B, uint32_t lb, uint64_t n,
+                                                        PairOut* __restrict__ out) {
+  constexpr int NW = THREADS / 64;
+  __shared__ unsigned long long w_u[NW], w_c[NW], w_m[NW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t total = la + lb;
+  const uint32_t D = (total + THREADS - 1) / THREADS;
+  const uint32_t t0 = min((uint32_t)tid * D, total), t1 = min(t0 + D, total);
+  uint32_t lo = t0 > lb ? t0 - lb : 0, hi = min(t0, la);
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (A[mid] <= B[t0 - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  const uint32_t pa = lo, pb = t0 - lo;
+  const PairCounts c = walk<false>(A, la, B, lb, pa, pb, t1 - t0, 0, 0);
+  // workgroup exclusive scan of uni: wave scan + wave totals through LDS
+  const uint64_t wave_excl = wave_excl_scan64(c.uni, lane);
+  const uint64_t wave_u = wave_sum64(c.uni), wave_c = wave_sum64(c.com);
+  if (lane == 0) { w_u[w] = wave_u; w_c[w] = wave_c; }
+  __syncthreads();
+  uint64_t before = 0, tot_u = 0, tot_c = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    if (i < w) before += w_u[i];
+    tot_u += w_u[i]; tot_c += w_c[i];
+  }
+  const uint64_t u0 = before + wave_excl;
+  uint64_t mine = c.com;
+  if (n != 0 && tot_u > n) {
+    if (u0 + c.uni <= n) mine = c.com;
+    else if (u0 <= n) mine = walk<true>(A, la, B, lb, pa, pb, t1 - t0, u0, n).com;
+    else mine = 0;
+  }
+  const uint64_t wave_m = wave_sum64(mine);
+  if (lane == 0) w_m[w] = wave_m;
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t common = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) common += w_m[i];
+    out->tot_u = tot_u; out->tot_c = tot_c; out->common = common;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pair_grid(const uint64_t* __restrict__ A, uint32_t la,
+                                                   const uint64_t* __restrict__ B, uint32_t lb,
+                                                   PairOut* __restrict__ out) {
+  const uint64_t T = (uint64_t)gridDim.x * 256;
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t total = (uint64_t)la + lb;
+  const uint64_t D = (total + T - 1) / T;
+  const uint64_t t0 = min(g * D, total), t1 = min(t0 + D, total);
+  uint32_t lo = t0 > lb ? (uint32_t)(t0 - lb) : 0, hi = (uint32_t)min(t0, (uint64_t)la);
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (A[mid] <= B[t0 - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  const PairCounts c = walk<false>(A, la, B, lb, lo, (uint32_t)(t0 - lo), (uint32_t)(t1 - t0), 0, 0);
+  const uint64_t wu = wave_sum64(c.uni), wc = wave_sum64(c.com);
+  if ((threadIdx.x & 63) == 0) {
+    if (wu) atomicAdd(&out->tot_u, (unsigned long long)wu);
+    if (wc) atomicAdd(&out->tot_c, (unsigned long long)wc);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // k_compare_few: a few sketches against many (LinearIndex::find, the scaffold arg-max, a query
 // against a resident index).  blockIdx.y picks the "few" sketch Q, kept in LDS by the workgroup;
 // each wave streams whole "many" sketches A from HBM, 64 consecutive elements per step (one
@@ -531,6 +605,26 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   if (!launched) throw_internal("compare geometry not instantiated");
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_tiled", s);
+}
+
+void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
+                         Device& dev, hipStream_t s) {
+  const uint64_t total = (uint64_t)la + lb;
+  dev.prof_begin(s);
+  if (n == 0 && total > 32768) {
+    HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(PairOut), s));
+    // about 64 merged elements per lane, at most 16 workgroups per CU
+    uint64_t blocks = (total / 64 + 255) / 256;
+    const uint64_t cap = (uint64_t)dev.cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_pair_grid, dim3((unsigned)blocks), dim3(256), 0, s, A, la, B, lb, out_dev);
+  } else if (total <= 8192) {
+    hipLaunchKernelGGL(k_pair_block<256>, dim3(1), dim3(256), 0, s, A, la, B, lb, n, out_dev);
+  } else {
+    hipLaunchKernelGGL(k_pair_block<1024>, dim3(1), dim3(1024), 0, s, A, la, B, lb, n, out_dev);
+  }
+  HIP_CHECK(hipGetLastError());
+  dev.prof_end("compare_pair", s);
 }
 
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,

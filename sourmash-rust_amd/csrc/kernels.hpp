@@ -111,6 +111,11 @@ struct CompareOut {
 // rows x cols block; num = truncation length of the union walk (row's `num`; 0 = unbounded),
 // row_nums (device, nullable) overrides it per row.
 // max_row_len / max_col_len: longest sketch on each side (decides LDS staging).
+// one ordered pair from plain device pointers; out = {|A u B|, |A n B|, common within the first n of the union}
+struct PairOut { unsigned long long tot_u, tot_c, common; };
+void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
+                         Device& dev, hipStream_t s);
+
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
                           hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,

@@ -10,6 +10,8 @@
 #include "minhash.hpp"
 
 #include <algorithm>
+#include <mutex>
+#include <map>
 #include <cstring>
 
 namespace smh {
@@ -36,8 +38,61 @@ KmerMinHash& KmerMinHash::operator=(const KmerMinHash& o) {
   o.materialize();
   pend_seq.clear(); pend_off.clear();
   num = o.num; ksize = o.ksize; is_protein = o.is_protein; seed = o.seed; max_hash = o.max_hash;
-  has_abunds = o.has_abunds; mins = o.mins; abunds = o.abunds; dev.reset();
+  has_abunds = o.has_abunds; mins = o.mins; abunds = o.abunds; dev.reset(); mirror.reset();
   return *this;
+}
+
+// Mirror buffers come from a small pool keyed by power-of-two size: a sketch that is created,
+// compared once and dropped must not pay a hipMalloc + hipFree per compare.
+namespace {
+std::mutex g_pool_mu;
+std::map<size_t, std::vector<void*>> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolLimit = 256u << 20;
+
+void mirror_alloc(size_t need, void** ptr, size_t* cap) {
+  size_t c = 4096;
+  while (c < need) c <<= 1;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto it = g_pool.find(c);
+    if (it != g_pool.end() && !it->second.empty()) {
+      *ptr = it->second.back();
+      it->second.pop_back();
+      g_pool_bytes -= c;
+      *cap = c;
+      return;
+    }
+  }
+  HIP_CHECK(hipMalloc(ptr, c));
+  *cap = c;
+}
+}  // namespace
+
+DeviceMirror::~DeviceMirror() {
+  if (!ptr) return;
+  const bool pow2 = (cap & (cap - 1)) == 0 && cap >= 4096;
+  if (pow2) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (g_pool_bytes + cap <= kPoolLimit) {
+      g_pool[cap].push_back(ptr);
+      g_pool_bytes += cap;
+      return;
+    }
+  }
+  (void)hipFree(ptr);
+}
+
+// order-sensitive 64-bit checksum of a word array, four independent lanes
+static uint64_t words_checksum(const uint64_t* p, size_t n) {
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4)
+    for (int k = 0; k < 4; k++) h[k] = (h[k] ^ p[i + k]) * 0xFF51AFD7ED558CCDull + 0x2545F4914F6CDD1Dull;
+  for (; i < n; i++) h[0] = (h[0] ^ p[i]) * 0xFF51AFD7ED558CCDull + 0x2545F4914F6CDD1Dull;
+  uint64_t r = 0;
+  for (int k = 0; k < 4; k++) { r = (r ^ h[k]) * 0xC4CEB9FE1A85EC53ull; r ^= r >> 29; }
+  return r;
 }
 
 void KmerMinHash::materialize() const {
@@ -59,6 +114,13 @@ void KmerMinHash::materialize() const {
     abunds.resize(n);
     for (size_t k = 0; k < n; k++) abunds[k] = (k + 1 < n ? st[k + 1] : (uint32_t)dev->total) - st[k];
   }
+  // the device copy stays on as the mirror of the host vector: a compare right after needs no upload
+  auto m = std::make_shared<DeviceMirror>();
+  std::swap(m->ptr, dev->uniq.ptr);
+  std::swap(m->cap, dev->uniq.bytes);
+  m->n = n;
+  m->sum = words_checksum(mins.data(), n);
+  mirror = m;
   dev.reset();
 }
 
@@ -439,6 +501,30 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
     // The first chunk is small because every hash passes while the sketch is not full; after it
     // the sketch's own maximum is the filter and chunks grow geometrically.
     const bool track = mh.has_abunds;
+    {
+      // One pass when the input behaves like random sequence: keep hashes under the value below
+      // which about 2 num + 64 of the P windows are expected (or under the full sketch's own
+      // maximum when that is lower).  If at least num distinct hashes show up, they are the
+      // bottom-num of the whole input; otherwise (few distinct k-mers) nothing has been applied
+      // yet and the growing-chunk loop below takes over.
+      const bool full = mh.mins.size() >= (size_t)mh.num;
+      const uint64_t natural = full ? mh.mins.back() : UINT64_MAX;
+      const long double want = 2.0L * mh.num + 64.0L;
+      uint64_t thr = natural;
+      if (want < 0.5L * (long double)P) {
+        const uint64_t est = (uint64_t)(want / (long double)P * 18446744073709551616.0L);
+        if (est < thr) thr = est;
+      }
+      if (P < (1ull << 40)) {
+        const uint64_t n = E.run_chunk(&src, 0, P, thr, track, s);
+        Delta d;
+        E.reduce_chunk(n, mh.num, track, track, s, &d);
+        if (thr == natural || d.uniq.size() >= (size_t)mh.num) {
+          apply_num(mh, d, E, s);
+          return;
+        }
+      }
+    }
     uint64_t chunk = std::max<uint64_t>(1u << 16, (uint64_t)mh.num * 64);
     for (uint64_t lo = 0; lo < P;) {
       const uint64_t hi = std::min(P, lo + chunk);
@@ -1044,6 +1130,16 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   Device& dev = Device::get();
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
   hipStream_t s = dev.stream();
+  if (rows.size() == 1 && cols.size() == 1) {   // one pair: mirrored copies, no CSR upload
+    PairResult r;
+    compare_pair(*rows[0], *cols[0], row_nums_host ? row_nums_host[0] : num, &r);
+    if (common) *common = r.common;
+    if (size) *size = r.size;
+    if (jaccard) *jaccard = r.jaccard;
+    if (count_common) *count_common = r.count_common;
+    if (containment) *containment = r.containment;
+    return;
+  }
   SketchSet R, C;
   uint32_t mr = 0, mc = 0;
   pack_sketches(rows, cmp_a, cmp_oa, &R, &mr, nullptr, s);
@@ -1075,23 +1171,64 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// The device copy of mh.mins: reused while (length, checksum) still match the host vector,
+// re-created (never overwritten: a published mirror is immutable) otherwise.
+const uint64_t* Engine::mirror_of(const KmerMinHash& mh, hipStream_t s) {
+  mh.materialize();
+  const size_t n = mh.mins.size();
+  const uint64_t sum = words_checksum(mh.mins.data(), n);
+  if (!mh.mirror || mh.mirror->n != n || mh.mirror->sum != sum) {
+    auto m = std::make_shared<DeviceMirror>();
+    mirror_alloc(n * 8 + 8, &m->ptr, &m->cap);
+    if (n) HIP_CHECK(hipMemcpyAsync(m->ptr, mh.mins.data(), n * 8, hipMemcpyHostToDevice, s));  // pageable source: staged before return
+    m->n = n;
+    m->sum = sum;
+    mh.mirror = m;
+  }
+  return reinterpret_cast<const uint64_t*>(mh.mirror->ptr);
+}
+
+void Engine::compare_pair(const KmerMinHash& a, const KmerMinHash& b, uint32_t num, PairResult* out) {
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  hipStream_t s = dev.stream();
+  const uint64_t* A = mirror_of(a, s);
+  const uint64_t* B = mirror_of(b, s);
+  const uint32_t la = (uint32_t)a.mins.size(), lb = (uint32_t)b.mins.size();
+  pair_out.ensure(sizeof(PairOut));
+  pin_pair.ensure(sizeof(PairOut));
+  launch_compare_pair(A, la, B, lb, num, pair_out.as<PairOut>(), dev, s);
+  PairOut* h = pin_pair.as<PairOut>();
+  HIP_CHECK(hipMemcpyAsync(h, pair_out.ptr, sizeof(PairOut), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  const bool cut = num != 0 && h->tot_u > num;
+  out->count_common = h->tot_c;
+  out->size = cut ? num : h->tot_u;
+  out->common = cut ? h->common : h->tot_c;
+  out->jaccard = (double)out->common / (double)(out->size > 1 ? out->size : 1);
+  out->containment = (double)h->tot_c / (double)la;
+}
+
 uint64_t KmerMinHash::count_common(const KmerMinHash& other) const {
   check_compatible(other);
-  uint64_t cc = 0;
-  Engine::get().compare_host({this}, {&other}, nullptr, num, nullptr, nullptr, nullptr, &cc, nullptr);
-  return cc;
+  Engine::PairResult r;
+  Engine::get().compare_pair(*this, other, num, &r);
+  return r.count_common;
 }
 
 void KmerMinHash::intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const {
   check_compatible(other);
-  Engine::get().compare_host({this}, {&other}, nullptr, num, common, size, nullptr, nullptr, nullptr);
+  Engine::PairResult r;
+  Engine::get().compare_pair(*this, other, num, &r);
+  if (common) *common = r.common;
+  if (size) *size = r.size;
 }
 
 double KmerMinHash::compare(const KmerMinHash& other) const {
   check_compatible(other);
-  double j = 0.0;
-  Engine::get().compare_host({this}, {&other}, nullptr, num, nullptr, nullptr, &j, nullptr, nullptr);
-  return j;
+  Engine::PairResult r;
+  Engine::get().compare_pair(*this, other, num, &r);
+  return r.jaccard;
 }
 
 }  // namespace smh

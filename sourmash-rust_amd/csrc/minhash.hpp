@@ -37,6 +37,21 @@ struct DeviceSketch {
   bool has_runs = false;
 };
 
+// Device copy of a host-resident sketch's `mins`, kept between pairwise calls: compare / count_common
+// through the one-pair-per-call ABI would otherwise upload both sketches every time.  Validated by
+// (length, checksum of the words) against the host vector before every use, so no mutation site can
+// leave it stale; never modified in place once published.
+struct DeviceMirror {
+  void* ptr = nullptr;   // from mirror_alloc() (pooled by power-of-two size) or adopted from a DeviceSketch
+  size_t cap = 0;
+  size_t n = 0;
+  uint64_t sum = 0;
+  DeviceMirror() = default;
+  DeviceMirror(const DeviceMirror&) = delete;
+  DeviceMirror& operator=(const DeviceMirror&) = delete;
+  ~DeviceMirror();
+};
+
 struct KmerMinHash {
   uint32_t num = 1000;
   uint32_t ksize = 21;
@@ -47,6 +62,7 @@ struct KmerMinHash {
   bool has_abunds = false;         // Option<Vec<u64>>::is_some()
   mutable std::vector<uint64_t> abunds;
   mutable std::shared_ptr<DeviceSketch> dev;  // non-null: the state lives here, mins/abunds are empty
+  mutable std::shared_ptr<DeviceMirror> mirror;  // see DeviceMirror (not copied by Clone)
   // Small add_sequence calls (a read at a time through the legacy ABI) are queued here and hashed
   // in one device batch when the state is next observed or the queue is large: same result as one
   // launch per call, without the per-launch latency.  Errors are still raised by the call itself.
@@ -107,6 +123,11 @@ class Engine {
   // murmur64 of whole byte strings on the device (host pointers in, host pointer out)
   void hash_words(const uint8_t* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out);
 
+  // one ordered pair (self = a) on mirrored device copies: what the pairwise reference API needs
+  struct PairResult { uint64_t common, size, count_common; double jaccard, containment; };
+  void compare_pair(const KmerMinHash& a, const KmerMinHash& b, uint32_t num, PairResult* out);
+  const uint64_t* mirror_of(const KmerMinHash& mh, hipStream_t s);
+
   // block compare of host-resident sketches (uploads them); outputs are row-major rows x cols
   void compare_host(const std::vector<const KmerMinHash*>& rows, const std::vector<const KmerMinHash*>& cols,
                     const uint32_t* row_nums_host, uint32_t num, uint64_t* common, uint64_t* size,
@@ -117,7 +138,8 @@ class Engine {
                      uint32_t* maxlen, std::vector<uint64_t>* h_off, hipStream_t s);
 
   DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, uniq2, starts, red_b, misc, seqbuf, offbuf, vendbuf, vendbuf2, grpbuf;
-  PinnedBuffer pin_a, pin_b;
+  PinnedBuffer pin_a, pin_b, pin_pair;
+  DeviceBuffer pair_out;
   DeviceBuffer resbuf, segbuf, badbuf, cmp_a, cmp_b, cmp_oa, cmp_ob, cmp_out;
 
  private:

@@ -353,3 +353,46 @@ def test_inputs_produced_on_the_default_stream_are_ordered(pkg):
         if ref is None:
             ref = out.clone()
         assert bool((out == ref).all())
+
+
+def test_pairwise_calls_see_every_mutation(pkg, coracle):
+    """The pairwise entry points keep a device copy of each sketch between calls; it is validated
+    against the host vector before every use, so a change through ANY route must show."""
+    rng = random.Random(3)
+    pool = [rng.getrandbits(60) for _ in range(6000)]
+    for num, mx in ((500, 0), (0, 1 << 61), (20000, 0)):
+        ga, oa = pkg.KmerMinHash(num, 21, False, 42, mx, True), coracle.MinHash(num, 21, False, 42, mx, True)
+        gb, ob = pkg.KmerMinHash(num, 21, False, 42, mx, True), coracle.MinHash(num, 21, False, 42, mx, True)
+
+        def check():
+            assert ga.compare(gb) == oa.compare(ob)
+            assert gb.compare(ga) == ob.compare(oa)
+            assert ga.count_common(gb) == oa.count_common(ob)
+            assert ga.intersection_size(gb) == oa.intersection_size(ob)
+            assert ga.compare(ga) == oa.compare(oa)
+
+        check()                                                   # both empty
+        for h in pool[:3000]:
+            ga.add_hash(h); oa.add_hash(h)
+        check()
+        for h in pool[1500:4500]:
+            gb.add_hash(h); ob.add_hash(h)
+        check()
+        ga.add_hash(pool[5000]); oa.add_hash(pool[5000])          # one more hash
+        check()
+        gb.merge(ga); ob.merge(oa)                                # merge
+        check()
+        seq = bytes(rng.choice(b"ACGT") for _ in range(40000))
+        ga.add_sequence(seq, True); oa.add_sequence(seq, True)    # device ingest
+        check()
+        big = max(ga.mins) + 12345
+        if num == 0 and big <= mx:
+            ga.mins_push(big); oa.mins_push(big)                  # raw ABI push (keeps the vector ascending)
+            ga.abunds_push(1); oa.abunds_push(1)
+            check()
+        gc = pkg.KmerMinHash(num, 21, False, 42, mx, True)        # created, compared once, dropped
+        gc.add_many(np.array(pool[:100], dtype=np.uint64))
+        oc = coracle.MinHash(num, 21, False, 42, mx, True)
+        for h in pool[:100]:
+            oc.add_hash(h)
+        assert gc.compare(ga) == oc.compare(oa)

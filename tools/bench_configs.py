@@ -49,6 +49,7 @@ for name, params in cases:
         def run():
             mh = pkg.KmerMinHash(500, 31)
             mh.add_sequence(host1m, True)
+            len(mh)          # observing the sketch runs the queued batch
             return mh
         dt = timeit(run, 10)
         mh = run()

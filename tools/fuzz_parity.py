@@ -160,6 +160,20 @@ while time.time() < t_end:
                 import pickle
                 pickle.dump((case, steps), open("gpurun_out/fuzz_fail.pkl", "wb"))
                 sys.exit(1)
+        # pairwise entry points (mirrored device copies): against itself, against a partner, after a merge
+        g2, o2 = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        s2_ = rand_seq(rng.choice([k, 200, 3000]))
+        run_both(g2, o2, lambda m: m.add_sequence(s2_, True))
+        for step in range(2):
+            got = (g.compare(g), g.compare(g2), g2.compare(g), g.count_common(g2), g.intersection_size(g2))
+            exp = (o.compare(o), o.compare(o2), o2.compare(o), o.count_common(o2), o.intersection_size(o2))
+            if got != exp and not (all(x != x for x in (got[0], exp[0]))):
+                print("PAIRWISE MISMATCH case", case, "step", step, got, exp)
+                sys.exit(1)
+            eg, eo = run_both(g, o, lambda m: m.merge(g2 if m is g else o2))
+            if eg != eo or state(g) != state(o):
+                print("MERGE MISMATCH case", case, eg, eo)
+                sys.exit(1)
         n_sk += 1
     else:
         uni = np.unique(np.array([rng.getrandbits(63) for _ in range(rng.choice([50, 2000, 20000]))], dtype=np.uint64))
