@@ -56,6 +56,7 @@ Device::Device() {
   HIP_CHECK(hipGetDeviceProperties(&p, device_));
   cus_ = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&fence_, hipEventDisableTiming));
 }
 

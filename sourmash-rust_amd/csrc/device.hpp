@@ -63,6 +63,7 @@ class Device {
   int id() const { return device_; }
   int cu_count() const { return cus_; }
   hipStream_t stream() const { return stream_; }
+  hipStream_t copy_stream() const { return copy_stream_; }   // host->device chunks that overlap the hashing
   // The stream an entry point with a `void *stream` argument works on.  Non-null: the caller's.
   // Null: the library's own (non-blocking) stream, first ordered after everything already queued
   // on the legacy default stream -- a caller whose "current stream" is the default one (torch's
@@ -86,6 +87,7 @@ class Device {
   int device_ = 0;
   int cus_ = 256;
   hipStream_t stream_ = nullptr;
+  hipStream_t copy_stream_ = nullptr;
   hipEvent_t fence_ = nullptr;
   std::recursive_mutex mu_;
   bool profiling_ = false;

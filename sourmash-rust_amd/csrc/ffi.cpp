@@ -411,15 +411,10 @@ int smh_add_sequences(KmerMinHash* ptr, const char* seq, const uint64_t* offsets
   return pad_code([&] {
     require(ptr, "ptr"); require(seq, "seq"); require(offsets, "offsets");
     if (n_records == 0) return;
-    auto& dev = smh::Device::get();
-    auto& E = smh::Engine::get();
-    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
     const uint64_t base = offsets[0], total = offsets[n_records] - base;
     std::vector<uint64_t> rel(n_records + 1);
     for (uint32_t i = 0; i <= n_records; i++) rel[i] = offsets[i] - base;
-    E.seqbuf.ensure(total + 64);
-    if (total) HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq + base, total, hipMemcpyHostToDevice, dev.stream()));
-    ptr->add_sequences_device(E.seqbuf.as<uint8_t>(), total, rel.data(), n_records, force, dev.stream(), nullptr);
+    ptr->add_sequences_host((const uint8_t*)seq + base, total, rel.data(), n_records, force);
   });
 }
 

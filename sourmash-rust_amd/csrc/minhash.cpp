@@ -769,6 +769,92 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
   }
 }
 
+void KmerMinHash::add_sequences_host(const uint8_t* h_seq, uint64_t total, const uint64_t* h_offsets, uint32_t nrec,
+                                     bool force) {
+  if (nrec == 0 || total == 0) return;
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  Engine& E = Engine::get();
+  hipStream_t s = dev.stream();
+  materialize();
+  E.seqbuf.ensure(total + 64);
+  uint8_t* d_seq = E.seqbuf.as<uint8_t>();
+
+  constexpr uint64_t kChunk = 128ull << 20;
+  bool pipelined = force && !is_protein && ksize >= 1 && total >= 2 * kChunk && mode_of(*this) == kScaled;
+  if (pipelined) {
+    // the whole batch must be one hashing pass (as in ingest(): candidates under 2^30)
+    long double frac = ((long double)max_hash + 1.0L) / 18446744073709551616.0L;
+    pipelined = (long double)total * frac < (long double)(1ull << 30);
+  }
+  if (!pipelined) {
+    HIP_CHECK(hipMemcpyAsync(d_seq, h_seq, total, hipMemcpyHostToDevice, s));
+    add_sequences_device(d_seq, total, h_offsets, nrec, force, s, nullptr);
+    return;
+  }
+
+  bool any_long = false;
+  for (uint32_t r = 0; r < nrec; r++) any_long |= (h_offsets[r + 1] - h_offsets[r]) >= ksize;
+  if (!any_long) return;
+  SeqBatch b;
+  b.seq = d_seq; b.len = total; b.nrec = nrec; b.vend0 = total;
+  if (nrec > 1) {
+    E.offbuf.ensure((size_t)(nrec + 1) * 8);
+    HIP_CHECK(hipMemcpyAsync(E.offbuf.ptr, h_offsets, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, s));
+    b.starts = E.offbuf.as<uint64_t>();
+  }
+  DnaSource src;
+  src.b = b; src.ksize = ksize; src.seed = seed; src.dev = &dev;
+  const uint64_t P = total;
+  uint64_t cap = estimate_capacity(P, max_hash);
+  E.cand_hash[0].ensure(cap * 8); E.cand_hash[1].ensure(cap * 8);
+  E.counter.ensure(8);
+  HIP_CHECK(hipMemsetAsync(E.counter.ptr, 0, 8, s));
+  CandSink sink;
+  sink.hash = E.cand_hash[0].as<uint64_t>(); sink.pos = nullptr;
+  sink.count = E.counter.as<unsigned long long>(); sink.capacity = cap;
+
+  // chunk c is copied on the copy stream; the hashing stream waits for its event and hashes the
+  // k-mer starts whose last base is already on the device: [done, copied - (k-1))
+  const uint32_t nchunks = (uint32_t)((total + kChunk - 1) / kChunk);
+  std::vector<hipEvent_t> ev(nchunks, nullptr);
+  hipStream_t cs = dev.copy_stream();
+  uint64_t done = 0;
+  try {
+    for (uint32_t c = 0; c < nchunks; c++) {
+      const uint64_t lo = (uint64_t)c * kChunk, hi = std::min(total, lo + kChunk);
+      HIP_CHECK(hipEventCreateWithFlags(&ev[c], hipEventDisableTiming));
+      HIP_CHECK(hipMemcpyAsync(d_seq + lo, h_seq + lo, hi - lo, hipMemcpyHostToDevice, cs));
+      HIP_CHECK(hipEventRecord(ev[c], cs));
+      HIP_CHECK(hipStreamWaitEvent(s, ev[c], 0));
+      const uint64_t upto = (c + 1 == nchunks) ? P : (hi >= ksize ? hi - (ksize - 1) : 0);
+      if (upto > done) {
+        src.launch(done, upto, max_hash, sink, s);
+        done = upto;
+      }
+    }
+    unsigned long long n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, E.counter.ptr, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (n > cap) n = E.run_chunk(&src, 0, P, max_hash, false, s);   // rare: hash again into an exact-size buffer
+    Delta d;
+    if (mins.empty() && !this->dev && n > 0) {
+      auto ds = std::make_shared<DeviceSketch>();
+      E.reduce_chunk(n, 0, false, false, s, &d, ds.get());
+      this->dev = ds;
+    } else {
+      E.reduce_chunk(n, 0, false, false, s, &d);
+      apply_scaled(*this, d);
+    }
+  } catch (...) {
+    (void)hipStreamSynchronize(cs);
+    (void)hipStreamSynchronize(s);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    throw;
+  }
+}
+
 void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t* d_seq, uint64_t total_len,
                            const uint64_t* h_offsets, const uint32_t* grp, uint32_t nrec, bool force, hipStream_t stream,
                            Error* first_error) {
@@ -1032,11 +1118,8 @@ void KmerMinHash::add_sequence(const uint8_t* seq, size_t len, bool force) {
   if (direct) {
     std::lock_guard<std::recursive_mutex> lock(dev.mutex());
     flush_pending();
-    Engine& E = Engine::get();
-    E.seqbuf.ensure(len + 64);
-    HIP_CHECK(hipMemcpyAsync(E.seqbuf.ptr, seq, len, hipMemcpyHostToDevice, dev.stream()));
     const uint64_t off[2] = {0, (uint64_t)len};
-    add_sequences_device(E.seqbuf.as<uint8_t>(), len, off, 1, force, dev.stream(), nullptr);
+    add_sequences_host(seq, len, off, 1, force);
     return;
   }
   if (use >= ksize) {

@@ -96,6 +96,10 @@ struct KmerMinHash {
   // returned Err is reported through *first_error (nullable) after all records were processed.
   void add_sequences_device(const uint8_t* d_seq, uint64_t total_len, const uint64_t* h_offsets,
                             uint32_t nrec, bool force, hipStream_t stream, Error* first_error);
+  // Records in HOST memory (what the reference's boundary hands over): uploads them and calls the
+  // above; large scaled-DNA batches with force=true are uploaded in chunks on a second stream while
+  // the chunks already there are being hashed.
+  void add_sequences_host(const uint8_t* h_seq, uint64_t total_len, const uint64_t* h_offsets, uint32_t nrec, bool force);
 };
 
 // Many sketches from one batch (additive C ABI smh_add_sequences_grouped): record r feeds

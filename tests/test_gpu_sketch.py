@@ -535,3 +535,29 @@ def test_grouped_sketching(pkg, coracle):
     for r in (recs[3], recs[5], recs[8]):
         o.add_sequence(r, True)
     same_state(a, o)
+
+
+def test_large_host_input_is_pipelined_and_identical(pkg):
+    """Host bytes of 256 MB and more (scaled DNA, force=true) are uploaded in chunks on a second stream
+    while earlier chunks are hashed.  Same sketch as the device-resident path, with records that do
+    not line up with the chunks, invalid bytes, and a second call that merges into existing state."""
+    import ctypes as C
+    import torch
+    L = pkg.lib()
+    n = 300_000_017
+    buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    assert L.smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, n, 12, 99991, None) == 0
+    torch.cuda.synchronize()
+    host = buf[:n].cpu().numpy()
+    u64p = C.POINTER(C.c_uint64)
+    for nrec, track in ((1, False), (977, True)):
+        off = (np.arange(nrec + 1, dtype=np.uint64) * np.uint64(n // nrec)); off[-1] = n
+        a = pkg.KmerMinHash(0, 31, False, 42, (1 << 64) // 500, track)
+        b = pkg.KmerMinHash(0, 31, False, 42, (1 << 64) // 500, track)
+        for rep in range(2):                       # the second pass merges into a non-empty sketch
+            assert L.smh_add_sequences(a._p, host.ctypes.data_as(C.c_char_p), off.ctypes.data_as(u64p), nrec, True) == 0
+            b.add_sequences_dev(buf.data_ptr(), n, off, True)
+            assert np.array_equal(a.mins_np(), b.mins_np())
+            if track:
+                assert np.array_equal(a.abunds_np(), b.abunds_np())
+        assert len(a) > 500_000
