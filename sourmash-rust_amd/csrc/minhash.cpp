@@ -679,6 +679,53 @@ void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, 
   if (nrec > 1) b.vends = E.vendbuf.as<uint64_t>();
   else b.vend0 = vends[0];
 }
+// Protein arm set-up (reference src/lib.rs:277-301): segment table (6 frames per record), six-frame
+// translation into E.resbuf, and the reference's UTF-8 panic: a codon chunk that is not UTF-8 makes
+// from_utf8().unwrap() panic in that frame -- frames before it were added, it and the rest of the
+// record were not.  Returns false when there is nothing to hash.
+bool prepare_protein(const SeqBatch& b, const uint64_t* h_offsets, uint32_t nrec, uint32_t ksize, uint64_t seed, Engine& E,
+                     Device& dev, hipStream_t s, ProteinSource* src, bool* have_error, Error* err) {
+  const uint32_t aa_k = ksize / 3;
+  const uint32_t nseg = 6 * nrec;
+  std::vector<uint64_t> seg(nseg + 1, 0);
+  for (uint32_t r = 0; r < nrec; r++) {
+    const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+    for (uint32_t f = 0; f < 6; f++) {
+      const uint32_t frame = f >> 1;
+      uint64_t nres = (len >= ksize && len >= frame) ? (len - frame) / 3 : 0;
+      seg[6 * r + f + 1] = seg[6 * r + f] + nres;
+    }
+  }
+  const uint64_t total = seg[nseg];
+  if (aa_k == 0) throw_panic("window size must be non-zero");  // aa.windows(0), quirk Q8
+  if (total == 0) return false;
+  E.segbuf.ensure((size_t)(nseg + 1) * 8);
+  E.badbuf.ensure((size_t)nseg * 4);
+  E.resbuf.ensure(total + 64);  // k_hash_windows reads whole 8-byte words past the last start
+  HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemsetAsync(E.badbuf.ptr, 0, (size_t)nseg * 4, s));
+  dev.prof_begin(s);
+  launch_translate(b, E.segbuf.as<uint64_t>(), nseg, total, ksize, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);
+  dev.prof_end("translate", s);
+  std::vector<uint32_t> bad(nseg);
+  HIP_CHECK(hipMemcpyAsync(bad.data(), E.badbuf.ptr, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  for (uint32_t r = 0; r < nrec; r++) {
+    for (uint32_t f = 0; f < 6; f++) {
+      if (!bad[6 * r + f]) continue;
+      const uint64_t lo = seg[6 * r + f], hi = seg[6 * r + 6];
+      if (hi > lo) HIP_CHECK(hipMemsetAsync(E.resbuf.as<uint8_t>() + lo, 0xFF, hi - lo, s));
+      if (!*have_error) {
+        *have_error = true;
+        *err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: Utf8Error");
+      }
+      break;
+    }
+  }
+  src->res = E.resbuf.as<uint8_t>(); src->seg_off = E.segbuf.as<uint64_t>(); src->nseg = nseg;
+  src->total = total; src->win = aa_k; src->seed = seed; src->dev = &dev;
+  return true;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -717,49 +764,8 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
     src.b = b; src.ksize = ksize; src.seed = seed; src.dev = &dev;
     ingest(*this, src, s);
   } else {
-    // six-frame translation (reference src/lib.rs:277-301)
-    const uint32_t aa_k = ksize / 3;
-    const uint32_t nseg = 6 * nrec;
-    std::vector<uint64_t> seg(nseg + 1, 0);
-    for (uint32_t r = 0; r < nrec; r++) {
-      const uint64_t len = h_offsets[r + 1] - h_offsets[r];
-      for (uint32_t f = 0; f < 6; f++) {
-        const uint32_t frame = f >> 1;
-        uint64_t nres = (len >= ksize && len >= frame) ? (len - frame) / 3 : 0;
-        seg[6 * r + f + 1] = seg[6 * r + f] + nres;
-      }
-    }
-    const uint64_t total = seg[nseg];
-    if (aa_k == 0) throw_panic("window size must be non-zero");  // aa.windows(0), quirk Q8
-    if (total == 0) return;
-    E.segbuf.ensure((size_t)(nseg + 1) * 8);
-    E.badbuf.ensure((size_t)nseg * 4);
-    E.resbuf.ensure(total + 64);  // k_hash_windows reads whole 8-byte words past the last start
-    HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemsetAsync(E.badbuf.ptr, 0, (size_t)nseg * 4, s));
-    dev.prof_begin(s);
-    launch_translate(b, E.segbuf.as<uint64_t>(), nseg, total, ksize, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);
-    dev.prof_end("translate", s);
-    std::vector<uint32_t> bad(nseg);
-    HIP_CHECK(hipMemcpyAsync(bad.data(), E.badbuf.ptr, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    for (uint32_t r = 0; r < nrec; r++) {
-      for (uint32_t f = 0; f < 6; f++) {
-        if (!bad[6 * r + f]) continue;
-        // from_utf8(chunk).unwrap() panics in frame f: frames before it were added, it and the
-        // rest of this record were not
-        const uint64_t lo = seg[6 * r + f], hi = seg[6 * r + 6];
-        if (hi > lo) HIP_CHECK(hipMemsetAsync(E.resbuf.as<uint8_t>() + lo, 0xFF, hi - lo, s));
-        if (!have_error) {
-          have_error = true;
-          err = Error(kPanic, "sourmash panicked: called `Result::unwrap()` on an `Err` value: Utf8Error");
-        }
-        break;
-      }
-    }
     ProteinSource src;
-    src.res = E.resbuf.as<uint8_t>(); src.seg_off = E.segbuf.as<uint64_t>(); src.nseg = nseg;
-    src.total = total; src.win = aa_k; src.seed = seed; src.dev = &dev;
+    if (!prepare_protein(b, h_offsets, nrec, ksize, seed, E, dev, s, &src, &have_error, &err)) return;
     ingest(*this, src, s);
   }
 
@@ -888,16 +894,16 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
     if (e.code != kNoError && !have_error) { have_error = true; err = e; }
   };
 
-  // Shared-launch paths: DNA sketches with equal (ksize, seed), all scaled with one max_hash, or
+  // Shared-launch paths: sketches of one molecule type with equal (ksize, seed), all scaled with one max_hash, or
   // all bottom-num without abundance tracking (per-record thresholds).
   enum { kSlow, kSharedScaled, kSharedNum } path = kSlow;
   const KmerMinHash& m0 = *mhs[0];
-  if (!m0.is_protein && m0.ksize > 0 && runs.size() > 1) {
-    bool same = true, all_scaled = true, all_num = true;
+  if (m0.ksize > 0 && (!m0.is_protein || m0.ksize >= 3) && runs.size() > 1) {
+    bool same = true, all_scaled = true, all_num = !m0.is_protein;   // per-record thresholds exist in the DNA kernel only
     for (uint32_t g = 0; g < n_mh && same; g++) {
       mhs[g]->materialize();
       const KmerMinHash& m = *mhs[g];
-      same = !m.is_protein && m.ksize == m0.ksize && m.seed == m0.seed;
+      same = m.is_protein == m0.is_protein && m.ksize == m0.ksize && m.seed == m0.seed;
       const int mode = mode_of(m);
       all_scaled &= mode == kScaled && m.max_hash == m0.max_hash;
       all_num &= mode == kNum && !m.has_abunds;
@@ -927,9 +933,28 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
   HIP_CHECK(hipMemcpyAsync(E.grpbuf.ptr, grp, (size_t)nrec * 4, hipMemcpyHostToDevice, s));
   SeqBatch b;
   b.seq = d_seq; b.len = total_len; b.starts = E.offbuf.as<uint64_t>(); b.nrec = nrec; b.vend0 = total_len;
-  if (!force) dna_validate(b, d_seq, h_offsets, nrec, ksize, E, s, &have_error, &err);
-  DnaSource src;
-  src.b = b; src.ksize = ksize; src.seed = m0.seed; src.dev = &dev;
+  DnaSource dna;
+  ProteinSource prot;
+  HashSource* srcp = &dna;
+  // candidate positions -> groups: DNA positions are bases (table = record starts), protein positions
+  // are residues of the six-frame buffer (table = segment starts, six segments per record)
+  const uint64_t* pos_table = E.offbuf.as<uint64_t>();
+  uint32_t pos_entries = nrec;
+  const uint32_t* pos_groups = E.grpbuf.as<uint32_t>();
+  if (!m0.is_protein) {
+    if (!force) dna_validate(b, d_seq, h_offsets, nrec, ksize, E, s, &have_error, &err);
+    dna.b = b; dna.ksize = ksize; dna.seed = m0.seed; dna.dev = &dev;
+  } else {
+    if (!prepare_protein(b, h_offsets, nrec, ksize, m0.seed, E, dev, s, &prot, &have_error, &err)) return;
+    srcp = &prot;
+    std::vector<uint32_t> g6((size_t)nrec * 6);
+    for (uint32_t r = 0; r < nrec; r++) for (int f = 0; f < 6; f++) g6[(size_t)6 * r + f] = grp[r];
+    E.grpbuf.ensure(g6.size() * 4);
+    HIP_CHECK(hipMemcpyAsync(E.grpbuf.ptr, g6.data(), g6.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));   // g6 is a stack-lifetime staging vector
+    pos_table = E.segbuf.as<uint64_t>(); pos_entries = 6 * nrec; pos_groups = E.grpbuf.as<uint32_t>();
+  }
+  HashSource& src = *srcp;
   const uint64_t P = src.positions();
   bool any_track = false;
   for (uint32_t g = 0; g < n_mh; g++) any_track |= mhs[g]->has_abunds;
@@ -940,7 +965,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
   auto fold_groups = [&](uint64_t n, auto&& per_group) {
     if (n == 0) return;
     // (hash, position) -> (hash, group); sort by hash, then stably by group: (group, hash) order
-    launch_pos_to_group(E.cand_pos[0].as<uint64_t>(), n, E.offbuf.as<uint64_t>(), nrec, E.grpbuf.as<uint32_t>(), s);
+    launch_pos_to_group(E.cand_pos[0].as<uint64_t>(), n, pos_table, pos_entries, pos_groups, s);
     const int c1 = radix_sort_u64(E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(), E.cand_pos[0].as<uint64_t>(),
                                   E.cand_pos[1].as<uint64_t>(), n, dev.scratch, s);
     const int c2 = radix_sort_u64(E.cand_pos[c1].as<uint64_t>(), E.cand_pos[c1 ^ 1].as<uint64_t>(),
@@ -1015,7 +1040,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
     for (uint32_t r = 0; r < nrec; r++) thr_of_rec[r] = thr[grp[r]];
     E.vendbuf2.ensure((size_t)nrec * 8);
     HIP_CHECK(hipMemcpyAsync(E.vendbuf2.ptr, thr_of_rec.data(), (size_t)nrec * 8, hipMemcpyHostToDevice, s));
-    src.thr_rec = E.vendbuf2.as<uint64_t>();
+    dna.thr_rec = E.vendbuf2.as<uint64_t>();
     const long double favg = expect / (long double)(P ? P : 1);
     const uint64_t thr_avg = favg >= 1.0L ? UINT64_MAX : (uint64_t)(favg * 18446744073709551616.0L);   // sizes the LDS stage only
     uint64_t n = 0;
