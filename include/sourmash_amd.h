@@ -43,7 +43,7 @@ int smh_add_sequences_dev(KmerMinHash *ptr, const void *seq_dev, uint64_t total_
  * contigs; the loop of reference src/lib.rs:252-305 callers that build one signature per input
  * file).  Per sketch the result is that of smh_add_sequences over its records in order.  Sketches
  * of one molecule type with equal (ksize, seed) share ONE hashing launch and ONE sort when they
- * are all scaled with one max_hash, or (DNA) all bottom-num without abundance tracking; other
+ * are all scaled with one max_hash, or (DNA) all bottom-num; other
  * parameter combinations are served sketch by sketch. */
 int smh_add_sequences_grouped(KmerMinHash *const *sketches, uint32_t n_sketches, const char *seq,
                               const uint64_t *offsets, const uint32_t *groups, uint32_t n_records, bool force);

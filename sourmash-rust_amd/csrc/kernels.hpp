@@ -76,8 +76,10 @@ void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed,
 
 // --- sort.hip -----------------------------------------------------------------------
 // LSD radix sort, ping-pong between (k0,v0) and (k1,v1); returns which pair holds the result.
+// Only the byte passes [first_pass, last_pass) are run (default: all eight): a stable sort by a bit
+// field of the key.
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s);
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8);
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).
 // origin / rank_out (optional): also write rank_out[origin[i]] = run id of sorted position i.
 // key2 / uniq2 (optional): a more significant second key (array sorted by (key2, keys)); a run
@@ -85,10 +87,11 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
                                DeviceBuffer& scratch, hipStream_t s, const uint64_t* origin = nullptr,
                                uint32_t* rank_out = nullptr, const uint64_t* key2 = nullptr,
-                               uint64_t* uniq2 = nullptr);
+                               uint64_t* uniq2 = nullptr, int key2_shift = 0);   // key2 is compared as key2 >> key2_shift
 // cand_pos[i] (a k-mer start position of the batch) -> the sketch group of the record holding it
+// keep_bits != 0: the position is kept in the low keep_bits bits, the group goes above them
 void launch_pos_to_group(uint64_t* pos, uint64_t n, const uint64_t* rec_starts, uint32_t nrec,
-                         const uint32_t* group_of_rec, hipStream_t s);
+                         const uint32_t* group_of_rec, hipStream_t s, int keep_bits = 0);
 // reduces the first `nruns` of `total_runs` runs (run u ends at starts[u+1], the last one at n)
 void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t total_runs, uint32_t n,
                 const uint64_t* weights, const uint64_t* pos, uint64_t* out_sum, uint64_t* out_minpos,

@@ -459,7 +459,7 @@ void apply_num(KmerMinHash& mh, const Delta& d, Engine& E, hipStream_t s) {
       HIP_CHECK(hipMemcpyAsync(pos.data(), E.cand_pos[d.sorted_buf].as<uint64_t>() + lo, (size_t)(hi - lo) * 8,
                                hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
-      for (uint64_t p : pos) c += p <= tstar;
+      for (uint64_t p : pos) c += (p & d.pos_mask) <= tstar;
     }
     na.back() = (last_old ? last_old_ab : 0) + c;
   }
@@ -906,7 +906,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
       same = m.is_protein == m0.is_protein && m.ksize == m0.ksize && m.seed == m0.seed;
       const int mode = mode_of(m);
       all_scaled &= mode == kScaled && m.max_hash == m0.max_hash;
-      all_num &= mode == kNum && !m.has_abunds;
+      all_num &= mode == kNum;
     }
     if (same && n_mh <= 65536) {
       // one sketch listed twice is served in order instead
@@ -915,7 +915,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
       same = std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end();
     }
     if (same && all_scaled) path = kSharedScaled;
-    else if (same && all_num) path = kSharedNum;
+    else if (same && all_num && total_len < (1ull << 40)) path = kSharedNum;   // positions share a word with the group tag
   }
   if (path == kSlow) {
     for (const RecRun& rr : runs) serve_run(rr);
@@ -962,20 +962,37 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
   // n candidates (hash, position) in cand_hash[0] / cand_pos[0] -> per group: its distinct hashes
   // ascending (+ run starts when some sketch tracks abundance), handed to per_group(g, hashes,
   // count, starts_or_null, end_of_last_run)
-  auto fold_groups = [&](uint64_t n, auto&& per_group) {
+  // keep_pos: the payload becomes (group << 40 | position) so that the stream positions survive
+  // the two sorts (quirk Q3 of abundance-tracking bottom-num sketches needs them); the second sort
+  // then runs over the group bytes only
+  constexpr int kPosBits = 40;
+  int fold_cur = 0;   // which ping-pong half holds the sorted candidates after a fold
+  auto fold_groups = [&](uint64_t n, bool keep_pos, auto&& per_group) {
     if (n == 0) return;
     // (hash, position) -> (hash, group); sort by hash, then stably by group: (group, hash) order
-    launch_pos_to_group(E.cand_pos[0].as<uint64_t>(), n, pos_table, pos_entries, pos_groups, s);
+    launch_pos_to_group(E.cand_pos[0].as<uint64_t>(), n, pos_table, pos_entries, pos_groups, s, keep_pos ? kPosBits : 0);
     const int c1 = radix_sort_u64(E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(), E.cand_pos[0].as<uint64_t>(),
                                   E.cand_pos[1].as<uint64_t>(), n, dev.scratch, s);
     const int c2 = radix_sort_u64(E.cand_pos[c1].as<uint64_t>(), E.cand_pos[c1 ^ 1].as<uint64_t>(),
-                                  E.cand_hash[c1].as<uint64_t>(), E.cand_hash[c1 ^ 1].as<uint64_t>(), n, dev.scratch, s);
+                                  E.cand_hash[c1].as<uint64_t>(), E.cand_hash[c1 ^ 1].as<uint64_t>(), n, dev.scratch, s,
+                                  keep_pos ? kPosBits / 8 : 0, 8);
     const int cur = c1 ^ c2;
+    fold_cur = cur;
     E.uniq.ensure(n * 8); E.uniq2.ensure(n * 8); E.starts.ensure((n + 1) * 4);
     const uint32_t nruns = run_length_encode_u64(E.cand_hash[cur].as<uint64_t>(), n, E.uniq.as<uint64_t>(),
                                                  E.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr,
-                                                 E.cand_pos[cur].as<uint64_t>(), E.uniq2.as<uint64_t>());
+                                                 E.cand_pos[cur].as<uint64_t>(), E.uniq2.as<uint64_t>(), keep_pos ? kPosBits : 0);
     if (nruns == 0) return;
+    const uint64_t* h_minpos = nullptr;
+    if (keep_pos) {
+      // first stream position of every run (the group tag is the same within a run: min keeps it)
+      E.cmp_out.ensure((size_t)nruns * 8);
+      run_reduce(E.starts.as<uint32_t>(), nruns, nruns, (uint32_t)n, nullptr, E.cand_pos[cur].as<uint64_t>(), nullptr,
+                 E.cmp_out.as<uint64_t>(), s);
+      E.pin_pair.ensure((size_t)nruns * 8);
+      HIP_CHECK(hipMemcpyAsync(E.pin_pair.ptr, E.cmp_out.ptr, (size_t)nruns * 8, hipMemcpyDeviceToHost, s));
+      h_minpos = E.pin_pair.as<uint64_t>();
+    }
     // group boundaries in run space: collapse the per-run group ids once more
     E.red_b.ensure((size_t)nruns * 8); E.misc.ensure(((size_t)nruns + 1) * 4);
     const uint32_t ngr = run_length_encode_u64(E.uniq2.as<uint64_t>(), nruns, E.red_b.as<uint64_t>(), E.misc.as<uint32_t>(),
@@ -994,7 +1011,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
     for (uint32_t q = 0; q < ngr; q++) {
       const size_t a = h_gstart[q], e = q + 1 < ngr ? h_gstart[q + 1] : nruns;
       per_group((uint32_t)h_gid[q], h_uniq + a, e - a, any_track ? h_starts + a : nullptr,
-                e < nruns && any_track ? h_starts[e] : (uint32_t)n);
+                e < nruns && any_track ? h_starts[e] : (uint32_t)n, h_minpos ? h_minpos + a : nullptr);
     }
   };
 
@@ -1006,7 +1023,8 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
     for (uint64_t lo = 0; lo < P; lo += CH) {
       const uint64_t hi = std::min(P, lo + CH);
       const uint64_t n = E.run_chunk(&src, lo, hi, m0.max_hash, true, s);
-      fold_groups(n, [&](uint32_t g, const uint64_t* hashes, size_t cnt, const uint32_t* starts, uint32_t end) {
+      fold_groups(n, false, [&](uint32_t g, const uint64_t* hashes, size_t cnt, const uint32_t* starts, uint32_t end,
+                                const uint64_t*) {
         KmerMinHash& mh = *mhs[g];
         d.uniq.assign(hashes, hashes + cnt);
         if (mh.has_abunds) {
@@ -1063,12 +1081,23 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
       cap = n;   // the counter kept counting: exact size for the re-run
     }
     std::vector<uint8_t> resolved(n_mh, 0);
-    fold_groups(n, [&](uint32_t g, const uint64_t* hashes, size_t cnt, const uint32_t*, uint32_t) {
+    fold_groups(n, any_track, [&](uint32_t g, const uint64_t* hashes, size_t cnt, const uint32_t* starts, uint32_t end,
+                                  const uint64_t* minpos) {
       KmerMinHash& mh = *mhs[g];
       if (cnt < (size_t)mh.num && thr[g] != UINT64_MAX && !(mh.mins.size() >= (size_t)mh.num && thr[g] == mh.mins.back()))
         return;
       resolved[g] = 1;
-      d.uniq.assign(hashes, hashes + std::min(cnt, (size_t)mh.num));
+      const size_t kept = std::min(cnt, (size_t)mh.num);
+      d.uniq.assign(hashes, hashes + kept);
+      if (mh.has_abunds) {
+        // run k of the group is [starts[k], starts[k+1]) in the sorted candidate arrays
+        d.run_start.assign(starts, starts + kept);
+        d.run_start.push_back(kept < cnt ? starts[kept] : end);
+        d.minpos.resize(kept);
+        for (size_t k = 0; k < kept; k++) d.minpos[k] = minpos[k] & ((1ull << kPosBits) - 1);
+        d.sorted_buf = fold_cur;
+        d.pos_mask = (1ull << kPosBits) - 1;
+      }
       apply_num(mh, d, E, s);
     });
     // groups with no candidate at all under an exhaustive threshold have nothing to add

@@ -23,6 +23,7 @@ struct Delta {
   std::vector<uint32_t> run_start;  // uniq.size()+1 entries: run k is [run_start[k], run_start[k+1])
   std::vector<uint64_t> minpos;     // first stream position of each (empty when not requested)
   int sorted_buf = 0;               // which candidate ping-pong half holds the sorted chunk
+  uint64_t pos_mask = ~0ull;        // positions in cand_pos carry a tag above these bits (grouped batches)
   uint64_t n = 0;                   // candidates in the chunk
 };
 

@@ -201,19 +201,19 @@ constexpr int kRleItems = 8;
 constexpr int kRleTile = kRleThreads * kRleItems;
 
 // key2 (optional): a second, more significant key; a run ends where either key changes
-__device__ __forceinline__ bool is_head(const uint64_t* keys, const uint64_t* key2, size_t i) {
-  return i == 0 || keys[i] != keys[i - 1] || (key2 && key2[i] != key2[i - 1]);
+__device__ __forceinline__ bool is_head(const uint64_t* keys, const uint64_t* key2, int sh2, size_t i) {
+  return i == 0 || keys[i] != keys[i - 1] || (key2 && (key2[i] >> sh2) != (key2[i - 1] >> sh2));
 }
 
 __global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __restrict__ keys,
-                                                           const uint64_t* __restrict__ key2,
+                                                           const uint64_t* __restrict__ key2, int sh2,
                                                            size_t n, uint32_t* __restrict__ bc) {
   __shared__ uint32_t wsum[kRleThreads / 64];
   size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < kRleItems; i++)
-    if (base + i < n && is_head(keys, key2, base + i)) c++;
+    if (base + i < n && is_head(keys, key2, sh2, base + i)) c++;
   for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __res
 // element came from (rank_out[origin[i]] = run of sorted position i): the dictionary encoding of
 // the compare pre-pass, fused here instead of a second pass over the runs.
 __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __restrict__ keys,
-                                                           const uint64_t* __restrict__ key2,
+                                                           const uint64_t* __restrict__ key2, int sh2,
                                                            uint64_t* __restrict__ uniq2,
                                                            size_t n,
                                                            const uint32_t* __restrict__ bscan,
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
   uint32_t flags = 0, c = 0;
 #pragma unroll
   for (int i = 0; i < kRleItems; i++)
-    if (base + i < n && is_head(keys, key2, base + i)) { flags |= 1u << i; c++; }
+    if (base + i < n && is_head(keys, key2, sh2, base + i)) { flags |= 1u << i; c++; }
   uint32_t incl = c;
   const int lane = threadIdx.x & 63;
   for (int off = 1; off < 64; off <<= 1) {
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
   for (int i = 0; i < kRleItems; i++) {
     if (flags & (1u << i)) {
       uniq[o] = keys[base + i];
-      if (key2) uniq2[o] = key2[base + i];
+      if (key2) uniq2[o] = key2[base + i] >> sh2;
       starts[o] = (uint32_t)(base + i);
       o++;
     }
@@ -306,7 +306,7 @@ static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, uint32_t*
 static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanChunk + 1; }
 
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s) {
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
   const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
@@ -330,7 +330,7 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
   int cur = 0;
   uint64_t* kk[2] = {k0, k1};
   uint64_t* vv[2] = {v0, v1};
-  for (int p = 0; p < 8; p++) {
+  for (int p = first_pass; p < last_pass; p++) {
     bool trivial = false;
     for (int d = 0; d < 256; d++)
       if (hh[p * 256 + d] == n) { trivial = true; break; }
@@ -352,15 +352,15 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
 
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
                                DeviceBuffer& scratch, hipStream_t s, const uint64_t* origin, uint32_t* rank_out,
-                               const uint64_t* key2, uint64_t* uniq2) {
+                               const uint64_t* key2, uint64_t* uniq2, int key2_shift) {
   if (n == 0) return 0;
   if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
   const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
   scratch.ensure((size_t)(nblocks + 1 + scan_tmp_entries(nblocks)) * sizeof(uint32_t));
   auto* bc = (uint32_t*)scratch.ptr;
-  hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, n, bc);
+  hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, n, bc);
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
-  hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, uniq2, n, bc, uniq,
+  hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, uniq2, n, bc, uniq,
                      starts, origin, rank_out);
   HIP_CHECK(hipGetLastError());
   uint32_t nruns = 0;
@@ -372,7 +372,7 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
 // positions -> group ids, in place: record = last r with rec_starts[r] <= pos
 __global__ __launch_bounds__(256) void k_pos_to_group(uint64_t* __restrict__ pos, uint64_t n,
                                                       const uint64_t* __restrict__ rec_starts, uint32_t nrec,
-                                                      const uint32_t* __restrict__ group_of_rec) {
+                                                      const uint32_t* __restrict__ group_of_rec, int keep_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t p = pos[i];
@@ -381,13 +381,13 @@ __global__ __launch_bounds__(256) void k_pos_to_group(uint64_t* __restrict__ pos
     const uint32_t mid = (lo + hi) >> 1;
     if (rec_starts[mid] <= p) lo = mid; else hi = mid;
   }
-  pos[i] = group_of_rec[lo];
+  pos[i] = keep_bits ? (((uint64_t)group_of_rec[lo] << keep_bits) | p) : (uint64_t)group_of_rec[lo];
 }
 void launch_pos_to_group(uint64_t* pos, uint64_t n, const uint64_t* rec_starts, uint32_t nrec,
-                         const uint32_t* group_of_rec, hipStream_t s) {
+                         const uint32_t* group_of_rec, hipStream_t s, int keep_bits) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_pos_to_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pos, n, rec_starts, nrec,
-                     group_of_rec);
+                     group_of_rec, keep_bits);
   HIP_CHECK(hipGetLastError());
 }
 

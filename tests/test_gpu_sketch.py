@@ -517,6 +517,10 @@ def test_grouped_sketching(pkg, coracle):
         _grouped_case(pkg, coracle, [(3 + 40 * g, 21, False, 42, 0, False) for g in range(n_groups)], rep, groups, True,
                       prefill=recs[-2])
         _grouped_case(pkg, coracle, [(500, 16, False, 7, 0, False)] * n_groups, rep, groups, False)
+        # with abundance tracking the stream positions ride along (quirk Q3: the last element of a full sketch)
+        _grouped_case(pkg, coracle, [(50, 21, False, 42, 0, True)] * n_groups, rep, groups, True)
+        _grouped_case(pkg, coracle, [(7 + 30 * g, 21, False, 42, 0, g % 2 == 0) for g in range(n_groups)], rep, groups, True,
+                      prefill=recs[-2])
     # parameter combinations the shared launch does not serve
     _grouped_case(pkg, coracle, [(50, 21, False, 42, 0, True)] * n_groups, recs, interleaved, True)
     _grouped_case(pkg, coracle, [(0, 21, False, 42, (1 << 58) + g, False) for g in range(n_groups)], recs, contiguous, True)

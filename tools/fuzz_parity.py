@@ -82,13 +82,15 @@ while time.time() < t_end:
         # grouped sketching: record r feeds sketch groups[r]; each sketch must equal the oracle fed its records
         ng = rng.randint(2, 12)
         k = rng.choice([4, 9, 16, 21, 31, 32, 33, 51, 70])
-        kind = rng.choice(["scaled", "scaled", "num", "num", "mixed", "protein"])
+        kind = rng.choice(["scaled", "scaled", "num", "num", "numtrack", "numtrack", "mixed", "protein"])
         seedv = rng.choice([42, 7])
         def params(gi):
             if kind == "scaled":
                 return (0, k, False, seedv, 1 << 60, gi % 2 == 0)
             if kind == "protein":
                 return (0, max(k, 6), True, seedv, 1 << 61, gi % 3 == 0)
+            if kind == "numtrack":
+                return (rng.choice([1, 5, 50, 300]), k, False, seedv, 0, gi % 3 != 0)
             if kind == "num":
                 return (rng.choice([1, 5, 50, 300]), k, False, seedv, 0, False)
             return rng.choice([(0, k, False, seedv, 1 << 60, True), (20, k, False, seedv, 0, True), (20, k, False, seedv, 0, False),
