@@ -109,6 +109,11 @@ int smh_index_compare(SmhIndex *rows, SmhIndex *cols, double *jaccard, uint64_t 
 int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       void *stream);
 
+/* The library keeps its device workspace (candidate buffers, the six-frame residue buffer, sort
+ * scratch) between calls and only ever grows it; a long-running process can hand the memory back
+ * after a large batch.  Sketches, resident indexes and their device copies are not touched. */
+int smh_release_workspace(void);
+
 /* HIP-event timing of the library's kernels, on the stream they run on.
  * name: "dna_rolling", "dna_generic", "hash_windows", "compare_wave", "compare_tiled". */
 void smh_profile_enable(int on);

@@ -519,17 +519,30 @@ TiledScratch& tiled_scratch() {
 
 }  // namespace
 
+void release_compare_scratch() {
+  TiledScratch& T = tiled_scratch();
+  for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart})
+    b->release();
+}
+
 static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
                          uint32_t max_len, uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
                          hipStream_t s) {
   TiledScratch& T = tiled_scratch();
   const bool same = rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
-  const uint64_t n = same ? nr_elems : nr_elems + nc_elems;
+  // a row block that is a slice of the column set (one rank's rows of the gathered signatures):
+  // its ranks are a slice of the columns' ranks, nothing extra to sort
+  const bool inside = !same && rows.hashes >= cols.hashes && rows.hashes + nr_elems <= cols.hashes + nc_elems;
+  const uint64_t n = same ? nr_elems : (inside ? nc_elems : nr_elems + nc_elems);
   if (n >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
   // ---- dictionary-encode: sort (hash, origin), run ids -> rank[origin]
   T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 8); T.org1.ensure(n * 8);
-  HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, rows.hashes, nr_elems * 8, hipMemcpyDeviceToDevice, s));
-  if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
+  if (inside) {
+    HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, rows.hashes, nr_elems * 8, hipMemcpyDeviceToDevice, s));
+    if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
+  }
   hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint64_t>(), n);
   int cur = radix_sort_u64(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint64_t>(), T.org1.as<uint64_t>(), n,
                            dev.scratch, s);
@@ -553,6 +566,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
                      T.bound.as<uint32_t>());
   const uint32_t* rrank = T.rank.as<uint32_t>();
   const uint32_t* crank = same ? rrank : rrank + nr_elems;
+  if (inside) { crank = T.rank.as<uint32_t>(); rrank = crank + (rows.hashes - cols.hashes); }
   T.rpart.ensure((size_t)rows.n * (R + 1) * 4);
   hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)rows.n * (R + 1) + 255) / 256)), dim3(256), 0, s, rrank, rows.offsets,
                      rows.n, T.bound.as<uint32_t>(), R, T.rpart.as<uint32_t>());

@@ -714,6 +714,10 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
   });
 }
 
+int smh_release_workspace(void) {
+  return pad_code([&] { smh::Engine::get().release_workspace(); });
+}
+
 void smh_profile_enable(int on) {
   (void)pad_code([&] { smh::Device::get().profile_enable(on != 0); });
 }

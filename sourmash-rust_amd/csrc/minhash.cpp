@@ -1217,6 +1217,23 @@ void KmerMinHash::add_word(const uint8_t* w, size_t len) {
 // ------------------------------------------------------------------------------------
 // comparisons of host-resident sketches
 
+void Engine::release_workspace() {
+  Device& dev = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+  HIP_CHECK(hipDeviceSynchronize());
+  for (DeviceBuffer* b : {&cand_hash[0], &cand_hash[1], &cand_pos[0], &cand_pos[1], &counter, &uniq, &uniq2, &starts, &red_b,
+                          &misc, &seqbuf, &offbuf, &vendbuf, &vendbuf2, &grpbuf, &resbuf, &segbuf, &badbuf, &cmp_a, &cmp_b,
+                          &cmp_oa, &cmp_ob, &cmp_out, &pair_out, &dev.scratch})
+    b->release();
+  release_compare_scratch();
+  {
+    std::lock_guard<std::mutex> pl(g_pool_mu);
+    for (auto& kv : g_pool) for (void* p : kv.second) (void)hipFree(p);
+    g_pool.clear();
+    g_pool_bytes = 0;
+  }
+}
+
 void Engine::pack_sketches(const std::vector<const KmerMinHash*>& v, DeviceBuffer& data, DeviceBuffer& offs,
                          SketchSet* out, uint32_t* maxlen, std::vector<uint64_t>* h_off, hipStream_t s) {
   std::vector<uint64_t> off(v.size() + 1, 0);

@@ -138,6 +138,9 @@ class Engine {
                     const uint32_t* row_nums_host, uint32_t num, uint64_t* common, uint64_t* size,
                     double* jaccard, uint64_t* count_common, double* containment);
 
+  // frees every grow-only workspace buffer (they are re-created on demand)
+  void release_workspace();
+
   // CSR upload of host-resident sketches (materialises them; gathers through pinned staging)
   void pack_sketches(const std::vector<const KmerMinHash*>& v, DeviceBuffer& data, DeviceBuffer& offs, SketchSet* out,
                      uint32_t* maxlen, std::vector<uint64_t>* h_off, hipStream_t s);

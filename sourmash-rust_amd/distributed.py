@@ -46,7 +46,10 @@ def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), compute_
     else:
         allsigs = local_sigs
     fn = compute_block or _hip_compute_block
-    return fn(local_sigs, hi - lo, allsigs, n_total, num, want)
+    # the row block as a VIEW of the gathered set: the block compare then sees that its rows are a
+    # slice of its columns and encodes the columns only
+    rows = allsigs[lo:lo + per] if world > 1 else local_sigs
+    return fn(rows, hi - lo, allsigs, n_total, num, want)
 
 
 def shard_records(n_records, world, rank):

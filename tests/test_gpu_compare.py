@@ -396,3 +396,25 @@ def test_pairwise_calls_see_every_mutation(pkg, coracle):
         for h in pool[:100]:
             oc.add_hash(h)
         assert gc.compare(ga) == oc.compare(oa)
+
+
+def test_row_block_that_is_a_slice_of_the_columns(pkg, coracle):
+    """One rank's row block passed as a VIEW of the gathered signature set: the tiled pre-pass encodes
+    the columns only and takes the rows' ranks from the same array."""
+    import torch
+    rng = np.random.RandomState(17)
+    pool = np.unique(rng.randint(0, 1 << 62, size=5000, dtype=np.int64).astype(np.uint64))
+    n, width = 240, 300
+    sigs = np.stack([np.sort(rng.choice(pool, width, replace=False)) for _ in range(n)])
+    allt = torch.from_numpy(sigs.view(np.int64)).cuda()
+    for lo, hi in ((0, 80), (80, 160), (170, 240)):
+        rows = allt[lo:hi]
+        ro = np.arange(hi - lo + 1, dtype=np.uint64) * np.uint64(width)
+        co = np.arange(n + 1, dtype=np.uint64) * np.uint64(width)
+        out = pkg.matrix.compare_block_dev(rows, ro, allt, co, width, want=("jaccard", "common", "size", "count_common"))
+        torch.cuda.synchronize()
+        common, size, jac = coracle.compare_matrix(list(sigs[lo:hi]), list(sigs), width, 31, 0)
+        assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
+        assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
+        assert (out["jaccard"].cpu().numpy() == jac).all()
+        assert (out["jaccard"].cpu().numpy()[np.arange(hi - lo), np.arange(lo, hi)] == 1.0).all()

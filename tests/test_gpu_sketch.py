@@ -565,3 +565,21 @@ def test_large_host_input_is_pipelined_and_identical(pkg):
             if track:
                 assert np.array_equal(a.abunds_np(), b.abunds_np())
         assert len(a) > 500_000
+
+
+def test_release_workspace_then_continue(pkg, coracle):
+    """smh_release_workspace frees the grow-only device buffers; the next calls re-create them."""
+    rng = random.Random(4)
+    seq = rand_seq(rng, 200000, 0)
+    L = pkg.lib()
+    for case in ((0, 21, False, 42, 1 << 60, True), (100, 27, True, 42, 0, False)):
+        g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+        g.add_sequence(seq, True); o.add_sequence(seq, True)
+        assert g.compare(g) == 1.0
+        assert L.smh_release_workspace() == 0
+        g.add_sequence(seq[::-1], True); o.add_sequence(seq[::-1], True)
+        same_state(g, o)
+        assert g.compare(g) == o.compare(o)
+        out = pkg.matrix.compare_block([g] * 20, [g] * 70, want=("jaccard",))
+        assert (out["jaccard"] == 1.0).all()
+        assert L.smh_release_workspace() == 0
