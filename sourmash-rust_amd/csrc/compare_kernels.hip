@@ -16,7 +16,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 #include <cstdlib>
 
 #include "device.hpp"
@@ -282,6 +284,9 @@ struct TiledArgs {
   const uint32_t* crank; const uint64_t* coff; const uint32_t* cpart; uint32_t ncols;
   uint32_t R, num;
   const uint32_t* row_nums;
+  const uint32_t* tiles;   // (row tile, column tile) of every workgroup: only tiles that can hold sharing pairs
+  const uint32_t* rperm;   // row slot -> row; column slot -> column: sketches of one component are adjacent
+  const uint32_t* cperm;
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
   uint32_t dbg;          // timing experiments only: 1 = stage but do not merge
   CompareOut out;
@@ -301,14 +306,21 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
   uint32_t* gB = sm + 256;        // [64]
   uint32_t* ctl = sm + 320;       // [0], [1] overflow flags
   uint32_t* nrowL = sm + 328;     // [64] truncation length of each row (0xffffffff = none, 0 = no row)
-  uint32_t* poolA = sm + 392;
+  uint32_t* rowid = sm + 392;     // [64] row of each row slot of the tile (0xffffffff = none)
+  uint32_t* colid = sm + 456;     // [64] column of each column slot
+  uint32_t* poolA = sm + 520;
   uint32_t* Bt = poolA + a.capA;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint32_t tiles_c = (a.ncols + kTB - 1) / kTB;
-  const uint32_t bi = blockIdx.x / tiles_c, bj = blockIdx.x % tiles_c;
-  const uint32_t col = bj * kTB + lane;
-  const bool col_ok = col < a.ncols;
+  const uint32_t bi = a.tiles[2 * blockIdx.x], bj = a.tiles[2 * blockIdx.x + 1];
+  if (tid < 64) {
+    const uint32_t rs = bi * kTR + tid, cs = bj * kTB + tid;
+    rowid[tid] = (tid < kTR && rs < a.nrows) ? a.rperm[rs] : 0xffffffffu;
+    colid[tid] = cs < a.ncols ? a.cperm[cs] : 0xffffffffu;
+  }
+  __syncthreads();
+  const uint32_t col = colid[lane];
+  const bool col_ok = col != 0xffffffffu;
 
   // per-pair running counts live in registers: every loop over q below is fully unrolled so
   // that the indices are static
@@ -319,9 +331,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
     if (WantCC) cc[q] = 0;
   }
   if (tid < 64) {
-    const uint32_t row = bi * kTR + tid;
+    const uint32_t row = rowid[tid];
     uint32_t n = 0;
-    if (tid < kTR && row < a.nrows) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : 0xffffffffu; }
+    if (row != 0xffffffffu) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : 0xffffffffu; }
     nrowL[tid] = n;
   }
 
@@ -337,9 +349,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
     while (true) {
     // ---- segment table of ranges [r, r + mt)
     if (tid < 64) {
-      const uint32_t row = bi * kTR + tid;
+      const uint32_t row = rowid[tid];
       uint32_t lo = 0, hi = 0, g = 0;
-      if (tid < kTR && row < a.nrows) {
+      if (row != 0xffffffffu) {
         lo = a.rpart[(size_t)row * (a.R + 1) + r];
         hi = a.rpart[(size_t)row * (a.R + 1) + r + mt];
         g = (uint32_t)a.roff[row] + lo;
@@ -355,9 +367,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       const uint32_t totA = __shfl(incl, 63);
       if (tid == 0) ctl[0] = totA > a.capA ? 1u : 0u;
     } else if (tid < 128) {
-      const uint32_t c = bj * kTB + (tid - 64);
+      const uint32_t c = colid[tid - 64];
       uint32_t lo = 0, hi = 0, g = 0;
-      if (c < a.ncols) {
+      if (c != 0xffffffffu) {
         lo = a.cpart[(size_t)c * (a.R + 1) + r];
         hi = a.cpart[(size_t)c * (a.R + 1) + r + mt];
         g = (uint32_t)a.coff[c] + lo;
@@ -453,8 +465,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 
 #pragma unroll
   for (int q = 0; q < kRowsPerWave; q++) {
-    const uint32_t row = bi * kTR + w * kRowsPerWave + q;
-    if (row < a.nrows && col_ok) {
+    const uint32_t row = rowid[w * kRowsPerWave + q];
+    if (row != 0xffffffffu && col_ok) {
       const size_t pid = (size_t)row * a.ncols + col;
       const uint32_t nq = nrowL[w * kRowsPerWave + q];
       const uint64_t size = ucount[q] < nq ? ucount[q] : nq;
@@ -509,8 +521,101 @@ __global__ void k_partition(const uint32_t* __restrict__ rank, const uint64_t* _
   part[g] = lo;
 }
 
+
+// ---- components of the "shares a hash" graph ------------------------------------------------
+// Two sketches in different connected components have no hash in common: common = 0 and size =
+// min(n, |A| + |B|) without looking at them.  The pre-pass below finds the components with a
+// lock-free union-find over the runs of the sorted pooled hashes; rows and columns are then
+// visited component by component and only tiles that hold same-component pairs are launched
+// (the rest of the matrix is filled by k_fill_disjoint).  All-vs-all over unrelated genomes is
+// mostly such pairs; a collection that is one big component costs what it did before.
+__device__ __forceinline__ uint32_t uf_load(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // past the per-CU cache
+}
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+  uint32_t p = uf_load(parent + x);
+  while (p != x) {
+    const uint32_t gp = uf_load(parent + p);
+    if (gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // halving: gp is an ancestor
+    x = p; p = gp;
+  }
+  return x;
+}
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t x, uint32_t y) {
+  while (true) {
+    x = uf_find(parent, x); y = uf_find(parent, y);
+    if (x == y) return;
+    if (x > y) { const uint32_t t = x; x = y; y = t; }
+    if (atomicCAS(parent + y, y, x) == y) return;   // the larger root goes under the smaller: parent[v] <= v always
+  }
+}
+// node of pooled element e (rows' elements first, then columns'; `split` = number of row elements)
+__global__ __launch_bounds__(256) void k_elem_node(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t n_elems,
+                                                   uint32_t base_id, uint32_t* __restrict__ node) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_elems) return;
+  const uint64_t v = off[0] + e;
+  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= v
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= v) lo = mid; else hi = mid;
+  }
+  node[e] = base_id + lo;
+}
+__global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) parent[i] = i;
+}
+// sorted position i continues the run of i-1 (same hash): their sketches are connected
+// Related sketches meet as neighbours in thousands of runs; `seen` (a direct-mapped table of the
+// pairs already united, racy on purpose: a lost or stale entry only repeats a union) keeps those
+// repeats away from the few hot parent words.
+constexpr int kSeenBits = 20;
+__global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ origin,
+                                                 const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent,
+                                                 unsigned long long* seen) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 || i >= n) return;
+  if (keys[i] != keys[i - 1]) return;
+  const uint32_t a = node[origin[i]], b = node[origin[i - 1]];
+  if (a == b) return;
+  const unsigned long long pair = ((unsigned long long)a << 32) | b;
+  const uint32_t slot = ((a * 0x9E3779B1u) ^ (b * 0x85EBCA77u)) >> (32 - kSeenBits);
+  if (seen[slot] == pair) return;
+  seen[slot] = pair;
+  uf_union(parent, a, b);
+}
+// a row block that is a slice of the column set: row element t IS column element delta + t
+__global__ __launch_bounds__(256) void k_uf_alias(const uint32_t* __restrict__ row_node, const uint32_t* __restrict__ col_node,
+                                                  uint64_t n_row_elems, uint64_t delta, uint32_t* parent) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_row_elems) return;
+  uf_union(parent, row_node[t], col_node[delta + t]);
+}
+__global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, uint32_t* __restrict__ root) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) root[i] = uf_find(parent, i);
+}
+// every pair as if it shared nothing; the tiled kernel then overwrites the tiles it visits
+__global__ __launch_bounds__(256) void k_fill_disjoint(const uint64_t* __restrict__ roff, uint32_t nrows,
+                                                       const uint64_t* __restrict__ coff, uint32_t ncols, uint32_t num,
+                                                       const uint32_t* __restrict__ row_nums, CompareOut out) {
+  const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= (uint64_t)nrows * ncols) return;
+  const uint32_t i = (uint32_t)(pid / ncols), j = (uint32_t)(pid % ncols);
+  const uint64_t la = roff[i + 1] - roff[i], lb = coff[j + 1] - coff[j];
+  const uint64_t n = row_nums ? row_nums[i] : num;
+  const uint64_t tot = la + lb;
+  const uint64_t size = (n != 0 && tot > n) ? n : tot;
+  if (out.common) out.common[pid] = 0;
+  if (out.size) out.size[pid] = size;
+  if (out.jaccard) out.jaccard[pid] = 0.0 / (double)(size > 1 ? size : 1);
+  if (out.count_common) out.count_common[pid] = 0;
+  if (out.containment) out.containment[pid] = 0.0 / (double)la;
+}
+
 struct TiledScratch {
-  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart;
+  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, perm, seen;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -521,7 +626,8 @@ TiledScratch& tiled_scratch() {
 
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
-  for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart})
+  for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
+                          &T.node, &T.parent, &T.root, &T.tiles, &T.perm, &T.seen})
     b->release();
 }
 
@@ -593,7 +699,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   }
   a.out = out;
   a.dbg = std::getenv("SOURMASH_AMD_CMP_DBG") ? (uint32_t)std::atoi(std::getenv("SOURMASH_AMD_CMP_DBG")) : 0;
-  const size_t lds = (size_t)(392 + a.capA + a.capBt) * 4;
+  const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;
   const bool want_cc = out.count_common || out.containment;
   // rows per wave: 16 (64-row tiles) amortises staging best; small problems use shorter tiles so
   // that the launch still covers the chip several times
@@ -603,8 +709,91 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // (1000 x 1000: 2.47 -> 2.20 ms, profiles/r01_compare_small_geometry.txt)
   if ((uint64_t)((rows.n + 15) / 16) * ((cols.n + kTB - 1) / kTB) < (uint64_t)dev.cu_count() * 32) rpw = 2;
   if (const char* e = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(e, "%d,%d,%d", &rpw, &wpb, &minw);
-  const uint32_t tr = (uint32_t)(rpw * wpb);
-  const uint32_t tiles = ((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
+  // ---- components: which tiles can hold a pair that shares a hash
+  const uint32_t M = same ? cols.n : rows.n + cols.n;
+  T.node.ensure((size_t)(n + (inside ? nr_elems : 0)) * 4);
+  T.parent.ensure((size_t)M * 4); T.root.ensure((size_t)M * 4);
+  uint32_t* d_node = T.node.as<uint32_t>();
+  auto elem_nodes = [&](const SketchSet& set, uint64_t ne, uint32_t base, uint32_t* dst) {
+    if (ne) hipLaunchKernelGGL(k_elem_node, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, set.offsets, set.n, ne, base, dst);
+  };
+  if (same) elem_nodes(cols, nc_elems, 0, d_node);
+  else if (inside) { elem_nodes(cols, nc_elems, rows.n, d_node); elem_nodes(rows, nr_elems, 0, d_node + n); }
+  else { elem_nodes(rows, nr_elems, 0, d_node); elem_nodes(cols, nc_elems, rows.n, d_node + nr_elems); }
+  hipLaunchKernelGGL(k_uf_init, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M);
+  T.seen.ensure((size_t)8 << kSeenBits);
+  HIP_CHECK(hipMemsetAsync(T.seen.ptr, 0, (size_t)8 << kSeenBits, s));   // (0, 0) is never a pair: a != b
+  hipLaunchKernelGGL(k_uf_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sk, so, d_node, n, T.parent.as<uint32_t>(),
+                     T.seen.as<unsigned long long>());
+  if (inside && nr_elems)
+    hipLaunchKernelGGL(k_uf_alias, dim3((unsigned)((nr_elems + 255) / 256)), dim3(256), 0, s, d_node + n, d_node, nr_elems,
+                       (uint64_t)(rows.hashes - cols.hashes), T.parent.as<uint32_t>());
+  hipLaunchKernelGGL(k_uf_roots, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M, T.root.as<uint32_t>());
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> h_root(M);
+  HIP_CHECK(hipMemcpyAsync(h_root.data(), T.root.ptr, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  const uint32_t* comp_r = h_root.data();
+  const uint32_t* comp_c = same ? h_root.data() : h_root.data() + rows.n;
+  // sketches of one component become adjacent (stable: original order inside a component)
+  std::vector<uint32_t> rperm(rows.n), cperm(cols.n);
+  for (uint32_t i = 0; i < rows.n; i++) rperm[i] = i;
+  for (uint32_t j = 0; j < cols.n; j++) cperm[j] = j;
+  std::stable_sort(rperm.begin(), rperm.end(), [&](uint32_t x, uint32_t y) { return comp_r[x] < comp_r[y]; });
+  std::stable_sort(cperm.begin(), cperm.end(), [&](uint32_t x, uint32_t y) { return comp_c[x] < comp_c[y]; });
+  std::vector<uint32_t> tile_list;
+  auto build_tiles = [&](uint32_t tr) {
+    const uint32_t tiles_r = (rows.n + tr - 1) / tr, tiles_c = (cols.n + kTB - 1) / kTB;
+    tile_list.clear();
+    if ((uint64_t)tiles_r * tiles_c > (1ull << 28)) {   // too many to flag one by one: visit them all
+      for (uint32_t i = 0; i < tiles_r; i++) for (uint32_t j = 0; j < tiles_c; j++) { tile_list.push_back(i); tile_list.push_back(j); }
+      return;
+    }
+    std::vector<uint8_t> flag((size_t)tiles_r * tiles_c, 0);
+    // both slot sequences are sorted by component: walk them together
+    uint32_t i = 0, j = 0;
+    while (i < rows.n && j < cols.n) {
+      const uint32_t cr = comp_r[rperm[i]], cc = comp_c[cperm[j]];
+      if (cr < cc) { i++; continue; }
+      if (cc < cr) { j++; continue; }
+      uint32_t i1 = i, j1 = j;
+      while (i1 < rows.n && comp_r[rperm[i1]] == cr) i1++;
+      while (j1 < cols.n && comp_c[cperm[j1]] == cr) j1++;
+      for (uint32_t ti = i / tr; ti <= (i1 - 1) / tr; ti++)
+        for (uint32_t tj = j / kTB; tj <= (j1 - 1) / kTB; tj++) flag[(size_t)ti * tiles_c + tj] = 1;
+      i = i1; j = j1;
+    }
+    for (uint32_t ti = 0; ti < tiles_r; ti++)
+      for (uint32_t tj = 0; tj < tiles_c; tj++)
+        if (flag[(size_t)ti * tiles_c + tj]) { tile_list.push_back(ti); tile_list.push_back(tj); }
+  };
+  uint32_t tr = (uint32_t)(rpw * wpb);
+  build_tiles(tr);
+  if (std::getenv("SOURMASH_AMD_CMP_GEO") == nullptr && wpb == 4 && minw == 8) {
+    // few tiles left: shorter ones fill the chip better (the kernel is latency bound, a
+    // workgroup per CU leaves 7/8 of the wave slots empty)
+    while (rpw > 1 && tile_list.size() / 2 < (size_t)dev.cu_count() * 32) {
+      rpw >>= 1; tr = (uint32_t)(rpw * wpb);
+      build_tiles(tr);
+    }
+  }
+  const uint32_t tiles = (uint32_t)(tile_list.size() / 2);
+  const uint64_t all_tiles = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
+  T.perm.ensure(((size_t)rows.n + cols.n) * 4 + 8);
+  T.tiles.ensure(tile_list.size() * 4 + 8);
+  HIP_CHECK(hipMemcpyAsync(T.perm.ptr, rperm.data(), (size_t)rows.n * 4, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(T.perm.as<uint32_t>() + rows.n, cperm.data(), (size_t)cols.n * 4, hipMemcpyHostToDevice, s));
+  if (tiles) HIP_CHECK(hipMemcpyAsync(T.tiles.ptr, tile_list.data(), tile_list.size() * 4, hipMemcpyHostToDevice, s));
+  a.rperm = T.perm.as<uint32_t>(); a.cperm = T.perm.as<uint32_t>() + rows.n; a.tiles = T.tiles.as<uint32_t>();
+  if (tiles < all_tiles) {
+    const uint64_t np = (uint64_t)rows.n * cols.n;
+    dev.prof_begin(s);
+    hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
+                       cols.n, num, row_nums, out);
+    HIP_CHECK(hipGetLastError());
+    dev.prof_end("compare_fill", s);
+  }
+  if (tiles == 0) { HIP_CHECK(hipStreamSynchronize(s)); return; }
   dev.prof_begin(s);
   bool launched = false;
 #define SMH_CT(R_, W_, M_)                                                                              \
@@ -619,6 +808,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   if (!launched) throw_internal("compare geometry not instantiated");
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_tiled", s);
+  HIP_CHECK(hipStreamSynchronize(s));   // tile_list / rperm / cperm are stack-lifetime staging vectors
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,

@@ -418,3 +418,48 @@ def test_row_block_that_is_a_slice_of_the_columns(pkg, coracle):
         assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
         assert (out["jaccard"].cpu().numpy() == jac).all()
         assert (out["jaccard"].cpu().numpy()[np.arange(hi - lo), np.arange(lo, hi)] == 1.0).all()
+
+
+@pytest.mark.parametrize("same_set", [True, False])
+def test_components_and_disjoint_pairs(same_set, pkg, coracle):
+    """The tiled path visits only tiles that can hold sharing pairs (connected components of the
+    'shares a hash' graph) and fills the rest as disjoint.  Interleaved families, singletons, empty
+    sketches, per-row nums, rows != columns, every output, against the oracle pair by pair."""
+    rng = np.random.RandomState(23 + same_set)
+    n_fam = 7
+    pools = [np.unique(rng.randint(0, 1 << 62, size=900, dtype=np.int64).astype(np.uint64)) for _ in range(n_fam)]
+
+    def make(count, shift):
+        out = []
+        for i in range(count):
+            kind = (i + shift) % 11
+            if kind == 9:
+                out.append(np.zeros(0, dtype=np.uint64))                              # empty
+            elif kind == 10:
+                out.append(np.unique(rng.randint(0, 1 << 62, size=200, dtype=np.int64).astype(np.uint64)))  # singleton
+            else:
+                fam = (i * 3 + shift) % n_fam                                           # families interleaved
+                out.append(np.sort(rng.choice(pools[fam], rng.choice([50, 300, 600]), replace=False)))
+        return out
+
+    rows = make(150, 0)
+    cols = rows if same_set else make(210, 4)
+    nums = [0, 40, 300, 5000]
+    gr, orr = zip(*[_pair(pkg, coracle, nums[i % 4], r) for i, r in enumerate(rows)])
+    if same_set:
+        gc, oc = gr, orr
+    else:
+        gc, oc = zip(*[_pair(pkg, coracle, 77, c) for c in cols])
+    want = ("jaccard", "common", "size", "count_common", "containment")
+    out = pkg.matrix.compare_block(list(gr), list(gc), want=want)
+    for i in range(len(rows)):
+        for j in range(len(cols)):
+            assert (int(out["common"][i, j]), int(out["size"][i, j])) == orr[i].intersection_size(oc[j]), (i, j)
+            assert out["jaccard"][i, j] == orr[i].compare(oc[j])
+            assert int(out["count_common"][i, j]) == orr[i].count_common(oc[j])
+            if len(rows[i]):
+                assert out["containment"][i, j] == orr[i].containment(oc[j])
+            else:
+                assert np.isnan(out["containment"][i, j])
+    out2 = pkg.matrix.compare_block(list(gr), list(gc), want=("jaccard", "size"))
+    assert (out2["jaccard"] == out["jaccard"]).all() and (out2["size"] == out["size"]).all()
