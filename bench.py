@@ -172,14 +172,20 @@ def main():
         if world > 1:
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         diag_ok = bool(okt.item())
+        tv, tt, ppt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.smh_compare_last_stats(C.byref(tv), C.byref(tt), C.byref(ppt))
+        visited = min(tv.value * ppt.value, (hi - lo) * n_sig)          # pairs actually walked on this rank
+        eff = (visited * 32008 + ((hi - lo) * n_sig - visited) * 8) / cdt / 1e9
         compare = {"metric": "signature pairs compared/sec (ordered pairs, num=2000)", "value": n_sig * n_sig / cdt,
                    "unit": "pairs/s", "n_signatures": n_sig, "seconds": cdt, "self_jaccard_is_1": diag_ok,
-                   "effective_GBps": n_sig * n_sig * 32008 / cdt / 1e9,
-                   "roofline": {"bound": "hbm", "achieved": n_sig * n_sig * 32008 / cdt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": n_sig * n_sig * 32008 / cdt / 1e9 / HBM_PEAK_GBS,
-                                "label": "EFFECTIVE bytes (32 008 B per ordered pair, SURVEY.md 8d): tiles are served from LDS/L2, "
-                                         "compulsory HBM traffic is N*16 KB in + N^2*8 B out; the kernel is bound by VALU issue and "
-                                         "LDS latency (DESIGN.md 3.4)"}}
+                   "tiles_visited": tv.value, "tiles_total": tt.value, "pairs_per_tile": ppt.value,
+                   "collection": "50 families of related signatures (SURVEY.md 8d); pairs across families share no hash "
+                                 "and are filled without being read (DESIGN.md 3.4)",
+                   "roofline": {"bound": "hbm", "achieved": eff, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": eff / HBM_PEAK_GBS,
+                                "label": "rank 0's EFFECTIVE bytes: 32 008 B per ordered pair walked (SURVEY.md 8d) + 8 B per pair "
+                                         "filled as disjoint; tiles are served from LDS/L2, compulsory HBM traffic is N*16 KB in + "
+                                         "N^2*8 B out; the kernel is bound by VALU issue and LDS latency (DESIGN.md 3.4)"}}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None

@@ -109,6 +109,10 @@ int smh_index_compare(SmhIndex *rows, SmhIndex *cols, double *jaccard, uint64_t 
 int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       void *stream);
 
+/* Of the last block compare that took the tiled path: tiles launched (those that can hold pairs
+ * sharing a hash), tiles in the block, pairs per tile.  Measurement aid. */
+void smh_compare_last_stats(uint64_t *tiles_visited, uint64_t *tiles_total, uint64_t *pairs_per_tile);
+
 /* The library keeps its device workspace (candidate buffers, the six-frame residue buffer, sort
  * scratch) between calls and only ever grows it; a long-running process can hand the memory back
  * after a large batch.  Sketches, resident indexes and their device copies are not touched. */

@@ -624,6 +624,13 @@ TiledScratch& tiled_scratch() {
 
 }  // namespace
 
+static uint64_t g_last_tiles_visited = 0, g_last_tiles_total = 0, g_last_pairs_per_tile = 0;
+void compare_last_stats(uint64_t* visited, uint64_t* total, uint64_t* pairs_per_tile) {
+  if (visited) *visited = g_last_tiles_visited;
+  if (total) *total = g_last_tiles_total;
+  if (pairs_per_tile) *pairs_per_tile = g_last_pairs_per_tile;
+}
+
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
@@ -779,6 +786,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   }
   const uint32_t tiles = (uint32_t)(tile_list.size() / 2);
   const uint64_t all_tiles = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
+  g_last_tiles_visited = tiles; g_last_tiles_total = all_tiles; g_last_pairs_per_tile = (uint64_t)tr * kTB;
   T.perm.ensure(((size_t)rows.n + cols.n) * 4 + 8);
   T.tiles.ensure(tile_list.size() * 4 + 8);
   HIP_CHECK(hipMemcpyAsync(T.perm.ptr, rperm.data(), (size_t)rows.n * 4, hipMemcpyHostToDevice, s));

@@ -714,6 +714,10 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
   });
 }
 
+void smh_compare_last_stats(uint64_t* tiles_visited, uint64_t* tiles_total, uint64_t* pairs_per_tile) {
+  smh::compare_last_stats(tiles_visited, tiles_total, pairs_per_tile);
+}
+
 int smh_release_workspace(void) {
   return pad_code([&] { smh::Engine::get().release_workspace(); });
 }

@@ -119,6 +119,7 @@ struct PairOut { unsigned long long tot_u, tot_c, common; };
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
                          Device& dev, hipStream_t s);
 
+void compare_last_stats(uint64_t* visited, uint64_t* total, uint64_t* pairs_per_tile);   // of the last tiled launch
 void release_compare_scratch();   // frees the tiled kernel's pre-pass buffers
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
