@@ -287,6 +287,7 @@ struct TiledArgs {
   const uint32_t* tiles;   // (row tile, column tile) of every workgroup: only tiles that can hold sharing pairs
   const uint32_t* rperm;   // row slot -> row; column slot -> column: sketches of one component are adjacent
   const uint32_t* cperm;
+  uint32_t xcd_chunk;      // tiles per XCD stretch (0 = list order)
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
   uint32_t dbg;          // timing experiments only: 1 = stage but do not merge
   CompareOut out;
@@ -312,7 +313,11 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
   uint32_t* Bt = poolA + a.capA;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint32_t bi = a.tiles[2 * blockIdx.x], bj = a.tiles[2 * blockIdx.x + 1];
+  // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a
+  // contiguous stretch of the tile list, so that the tiles it works on share rows and columns
+  uint32_t tix = blockIdx.x;
+  if (tix < 8u * a.xcd_chunk) tix = (tix & 7u) * a.xcd_chunk + (tix >> 3);   // the tail (< 8 tiles) keeps list order
+  const uint32_t bi = a.tiles[2 * tix], bj = a.tiles[2 * tix + 1];
   if (tid < 64) {
     const uint32_t rs = bi * kTR + tid, cs = bj * kTB + tid;
     rowid[tid] = (tid < kTR && rs < a.nrows) ? a.rperm[rs] : 0xffffffffu;
@@ -756,7 +761,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
       for (uint32_t i = 0; i < tiles_r; i++) for (uint32_t j = 0; j < tiles_c; j++) { tile_list.push_back(i); tile_list.push_back(j); }
       return;
     }
-    std::vector<uint8_t> flag((size_t)tiles_r * tiles_c, 0);
+    std::vector<uint8_t> flag((size_t)tiles_r * tiles_c, std::getenv("SOURMASH_AMD_CMP_ALL_TILES") ? 1 : 0);
     // both slot sequences are sorted by component: walk them together
     uint32_t i = 0, j = 0;
     while (i < rows.n && j < cols.n) {
@@ -802,6 +807,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     dev.prof_end("compare_fill", s);
   }
   if (tiles == 0) { HIP_CHECK(hipStreamSynchronize(s)); return; }
+  a.xcd_chunk = (tiles >= 64 && std::getenv("SOURMASH_AMD_CMP_NO_XCD") == nullptr) ? tiles / 8 : 0;
   dev.prof_begin(s);
   bool launched = false;
 #define SMH_CT(R_, W_, M_)                                                                              \
