@@ -288,6 +288,7 @@ struct TiledArgs {
   const uint32_t* rperm;   // row slot -> row; column slot -> column: sketches of one component are adjacent
   const uint32_t* cperm;
   uint32_t xcd_chunk;      // tiles per XCD stretch (0 = list order)
+  uint32_t symmetric;      // rows and columns are the same sketches with one num: pair (i, j) also writes (j, i)
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
   uint32_t dbg;          // timing experiments only: 1 = stage but do not merge
   CompareOut out;
@@ -485,6 +486,21 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
           a.out.containment[pid] = (double)cc[q] / (double)la_full;
         }
       }
+      if (a.symmetric && row != col) {
+        // same sketches on both axes, one num: the walk is symmetric in its two inputs, so this is
+        // also pair (col, row) -- tiles below the diagonal are not launched
+        const size_t pid2 = (size_t)col * a.ncols + row;
+        if (a.out.common) a.out.common[pid2] = common[q];
+        if (a.out.size) a.out.size[pid2] = size;
+        if (a.out.jaccard) a.out.jaccard[pid2] = (double)common[q] / (double)(size > 1 ? size : 1);
+        if (WantCC) {
+          if (a.out.count_common) a.out.count_common[pid2] = cc[q];
+          if (a.out.containment) {
+            const uint64_t lb_full = a.coff[col + 1] - a.coff[col];
+            a.out.containment[pid2] = (double)cc[q] / (double)lb_full;
+          }
+        }
+      }
     }
   }
 }
@@ -645,9 +661,11 @@ void release_compare_scratch() {
 
 static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
                          uint32_t max_len, uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
-                         hipStream_t s) {
+                         hipStream_t s, bool same_sets) {
   TiledScratch& T = tiled_scratch();
-  const bool same = rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
+  // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
+  const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
+  const bool symmetric = same && row_nums == nullptr && std::getenv("SOURMASH_AMD_CMP_NO_SYM") == nullptr;
   // a row block that is a slice of the column set (one rank's rows of the gathered signatures):
   // its ranks are a slice of the columns' ranks, nothing extra to sort
   const bool inside = !same && rows.hashes >= cols.hashes && rows.hashes + nr_elems <= cols.hashes + nc_elems;
@@ -758,7 +776,11 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     const uint32_t tiles_r = (rows.n + tr - 1) / tr, tiles_c = (cols.n + kTB - 1) / kTB;
     tile_list.clear();
     if ((uint64_t)tiles_r * tiles_c > (1ull << 28)) {   // too many to flag one by one: visit them all
-      for (uint32_t i = 0; i < tiles_r; i++) for (uint32_t j = 0; j < tiles_c; j++) { tile_list.push_back(i); tile_list.push_back(j); }
+      for (uint32_t i = 0; i < tiles_r; i++)
+        for (uint32_t j = 0; j < tiles_c; j++) {
+          if (symmetric && (uint64_t)j * kTB + kTB - 1 < (uint64_t)i * tr) continue;
+          tile_list.push_back(i); tile_list.push_back(j);
+        }
       return;
     }
     std::vector<uint8_t> flag((size_t)tiles_r * tiles_c, std::getenv("SOURMASH_AMD_CMP_ALL_TILES") ? 1 : 0);
@@ -776,8 +798,12 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
       i = i1; j = j1;
     }
     for (uint32_t ti = 0; ti < tiles_r; ti++)
-      for (uint32_t tj = 0; tj < tiles_c; tj++)
+      for (uint32_t tj = 0; tj < tiles_c; tj++) {
+        // symmetric: a tile wholly below the diagonal (all its column slots < all its row slots) is
+        // produced by the mirrored writes of the tiles above it
+        if (symmetric && (uint64_t)tj * kTB + kTB - 1 < (uint64_t)ti * tr) continue;
         if (flag[(size_t)ti * tiles_c + tj]) { tile_list.push_back(ti); tile_list.push_back(tj); }
+      }
   };
   uint32_t tr = (uint32_t)(rpw * wpb);
   build_tiles(tr);
@@ -798,6 +824,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   HIP_CHECK(hipMemcpyAsync(T.perm.as<uint32_t>() + rows.n, cperm.data(), (size_t)cols.n * 4, hipMemcpyHostToDevice, s));
   if (tiles) HIP_CHECK(hipMemcpyAsync(T.tiles.ptr, tile_list.data(), tile_list.size() * 4, hipMemcpyHostToDevice, s));
   a.rperm = T.perm.as<uint32_t>(); a.cperm = T.perm.as<uint32_t>() + rows.n; a.tiles = T.tiles.as<uint32_t>();
+  a.symmetric = symmetric ? 1u : 0u;
   if (tiles < all_tiles) {
     const uint64_t np = (uint64_t)rows.n * cols.n;
     dev.prof_begin(s);
@@ -848,14 +875,14 @@ void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
                           hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,
-                          uint64_t nc_elems) {
+                          uint64_t nc_elems, bool same_sets) {
   const uint64_t npairs = (uint64_t)rows.n * cols.n;
   if (npairs == 0) return;
   // big blocks: dictionary-encode once, then the tiled kernel; small ones: one wavefront per pair
   if (npairs >= 4096 && rows.n >= 8 && cols.n >= 16 && nr_elems + nc_elems > 0 &&
       std::getenv("SOURMASH_AMD_NO_TILED") == nullptr) {
     launch_tiled(rows, cols, nr_elems, nc_elems, max_row_len > max_col_len ? max_row_len : max_col_len, num, row_nums, out,
-                 dev, s);
+                 dev, s, same_sets);
     return;
   }
   // a few against many: the few side sits in LDS, the many side streams

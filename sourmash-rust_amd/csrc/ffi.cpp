@@ -511,7 +511,10 @@ int smh_compare_block_dev(const uint64_t* row_hashes_dev, const uint64_t* row_of
     smh::CompareOut o;
     o.jaccard = jaccard_dev; o.common = common_dev; o.size = size_dev; o.count_common = count_common_dev;
     o.containment = containment_dev;
-    smh::launch_compare_block(R, C, num, nullptr, o, dev, s, mr, mc, row_offsets[n_rows] - row_offsets[0], col_offsets[n_cols] - col_offsets[0]);
+    const bool same_sets = row_hashes_dev == col_hashes_dev && n_rows == n_cols &&
+                           std::memcmp(row_offsets, col_offsets, (size_t)(n_rows + 1) * 8) == 0;
+    smh::launch_compare_block(R, C, num, nullptr, o, dev, s, mr, mc, row_offsets[n_rows] - row_offsets[0],
+                              col_offsets[n_cols] - col_offsets[0], same_sets);
     HIP_CHECK(hipStreamSynchronize(s));  // the offset staging buffers are reused by the next call
   });
 }
@@ -693,8 +696,11 @@ int smh_index_compare(SmhIndex* rows, SmhIndex* cols, double* jaccard, uint64_t*
     smh::CompareOut o;
     o.common = common ? d_common : nullptr; o.size = size ? d_size : nullptr; o.jaccard = jaccard ? d_jac : nullptr;
     o.count_common = count_common ? d_cc : nullptr; o.containment = containment ? d_cont : nullptr;
-    smh::launch_compare_block(R, C, 0, rows->nums.as<uint32_t>(), o, dev, s, rows->max_len, cols->max_len,
-                              rows->h_offsets.back(), cols->h_offsets.back());
+    // one num for every row: pass it as the launch-wide value (lets an index against itself use symmetry)
+    bool uniform = true;
+    for (uint32_t v : rows->h_nums) uniform &= v == rows->h_nums[0];
+    smh::launch_compare_block(R, C, uniform ? rows->h_nums[0] : 0, uniform ? nullptr : rows->nums.as<uint32_t>(), o, dev, s,
+                              rows->max_len, cols->max_len, rows->h_offsets.back(), cols->h_offsets.back(), rows == cols);
     if (common) HIP_CHECK(hipMemcpyAsync(common, d_common, np * 8, hipMemcpyDeviceToHost, s));
     if (size) HIP_CHECK(hipMemcpyAsync(size, d_size, np * 8, hipMemcpyDeviceToHost, s));
     if (jaccard) HIP_CHECK(hipMemcpyAsync(jaccard, d_jac, np * 8, hipMemcpyDeviceToHost, s));

@@ -124,6 +124,6 @@ void release_compare_scratch();   // frees the tiled kernel's pre-pass buffers
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
                           hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,
-                          uint64_t nc_elems);
+                          uint64_t nc_elems, bool same_sets = false);   // same_sets: rows and cols are one CSR
 
 }  // namespace smh

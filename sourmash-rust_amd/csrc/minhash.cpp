@@ -1296,8 +1296,11 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   }
   SketchSet R, C;
   uint32_t mr = 0, mc = 0;
+  // the same list on both axes (all-vs-all): one upload, and the block compare may use symmetry
+  const bool same_sets = rows.size() == cols.size() && std::equal(rows.begin(), rows.end(), cols.begin());
   pack_sketches(rows, cmp_a, cmp_oa, &R, &mr, nullptr, s);
-  pack_sketches(cols, cmp_b, cmp_ob, &C, &mc, nullptr, s);
+  if (same_sets) { C = R; mc = mr; }
+  else pack_sketches(cols, cmp_b, cmp_ob, &C, &mc, nullptr, s);
   uint64_t row_total = 0, col_total = 0;
   for (auto* m : rows) row_total += m->mins.size();
   for (auto* m : cols) col_total += m->mins.size();
@@ -1310,13 +1313,19 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   uint64_t* d_cc = reinterpret_cast<uint64_t*>(d_jac + np);
   double* d_cont = reinterpret_cast<double*>(d_cc + np);
   uint32_t* d_rownum = reinterpret_cast<uint32_t*>(d_cont + np);
+  // one num for every row: pass it as the launch-wide value
+  if (row_nums_host) {
+    bool uniform = true;
+    for (size_t i = 1; i < rows.size(); i++) uniform &= row_nums_host[i] == row_nums_host[0];
+    if (uniform) { num = row_nums_host[0]; row_nums_host = nullptr; }
+  }
   if (row_nums_host)
     HIP_CHECK(hipMemcpyAsync(d_rownum, row_nums_host, rows.size() * 4, hipMemcpyHostToDevice, s));
   CompareOut o;
   // only what the caller asked for: without count_common / containment the kernels may stop at the cut
   o.common = common ? d_common : nullptr; o.size = size ? d_size : nullptr; o.jaccard = jaccard ? d_jac : nullptr;
   o.count_common = count_common ? d_cc : nullptr; o.containment = containment ? d_cont : nullptr;
-  launch_compare_block(R, C, num, row_nums_host ? d_rownum : nullptr, o, dev, s, mr, mc, row_total, col_total);
+  launch_compare_block(R, C, num, row_nums_host ? d_rownum : nullptr, o, dev, s, mr, mc, row_total, col_total, same_sets);
   if (common) HIP_CHECK(hipMemcpyAsync(common, d_common, np * 8, hipMemcpyDeviceToHost, s));
   if (size) HIP_CHECK(hipMemcpyAsync(size, d_size, np * 8, hipMemcpyDeviceToHost, s));
   if (jaccard) HIP_CHECK(hipMemcpyAsync(jaccard, d_jac, np * 8, hipMemcpyDeviceToHost, s));

@@ -420,8 +420,8 @@ def test_row_block_that_is_a_slice_of_the_columns(pkg, coracle):
         assert (out["jaccard"].cpu().numpy()[np.arange(hi - lo), np.arange(lo, hi)] == 1.0).all()
 
 
-@pytest.mark.parametrize("same_set", [True, False])
-def test_components_and_disjoint_pairs(same_set, pkg, coracle):
+@pytest.mark.parametrize("same_set,uniform_num", [(True, False), (False, False), (True, True)])
+def test_components_and_disjoint_pairs(same_set, uniform_num, pkg, coracle):
     """The tiled path visits only tiles that can hold sharing pairs (connected components of the
     'shares a hash' graph) and fills the rest as disjoint.  Interleaved families, singletons, empty
     sketches, per-row nums, rows != columns, every output, against the oracle pair by pair."""
@@ -444,7 +444,8 @@ def test_components_and_disjoint_pairs(same_set, pkg, coracle):
 
     rows = make(150, 0)
     cols = rows if same_set else make(210, 4)
-    nums = [0, 40, 300, 5000]
+    # one num on every row + the same list on both axes: tiles below the diagonal are produced by mirrored writes
+    nums = [150] * 4 if uniform_num else [0, 40, 300, 5000]
     gr, orr = zip(*[_pair(pkg, coracle, nums[i % 4], r) for i, r in enumerate(rows)])
     if same_set:
         gc, oc = gr, orr

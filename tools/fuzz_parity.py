@@ -209,6 +209,8 @@ while time.time() < t_end:
             for h in c:
                 a.mins_push(int(h)); b.mins_push(int(h))
             gc.append(a); oc.append(b)
+        if rng.random() < 0.25:        # all-vs-all of one list (symmetric when the nums agree)
+            gc, oc, cols, ncol = gm, om, rows, nrow
         want_cc = rng.random() < 0.6   # without count_common the kernels take their early-exit instantiation
         out = pkg.matrix.compare_block(gm, gc, want=("jaccard", "common", "size") + (("count_common",) if want_cc else ()))
         for i in range(nrow):
