@@ -7,7 +7,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "lib", "libsourmash_amd.so")
+SO_PATH = os.environ.get("SOURMASH_AMD_LIB") or os.path.join(HERE, "lib", "libsourmash_amd.so")   # override: experiments
 
 u64p = C.POINTER(C.c_uint64)
 f64p = C.POINTER(C.c_double)

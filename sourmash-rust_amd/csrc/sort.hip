@@ -20,7 +20,10 @@ namespace smh {
 
 namespace {
 
-constexpr int kSortThreads = 256;
+#ifndef SMH_SORT_THREADS
+#define SMH_SORT_THREADS 256
+#endif
+constexpr int kSortThreads = SMH_SORT_THREADS;
 constexpr int kSortItems = 16;                       // keys per thread per tile
 constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 keys per workgroup
 constexpr int kWaves = kSortThreads / 64;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint64_t* __
                                                               uint32_t* __restrict__ blockhist,
                                                               uint32_t nblocks) {
   __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < 256) h[threadIdx.x] = 0;
   __syncthreads();
   size_t base = (size_t)blockIdx.x * kSortTile;
 #pragma unroll
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint64_t* __
     if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255], 1u);
   }
   __syncthreads();
-  blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < 256) blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // exclusive scan of a u32 array, three small launches: (1) every workgroup scans its chunk of
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     if (active && below == 0) wcount[w][d] = prior + (uint32_t)__popcll(m);
   }
   __syncthreads();
-  {
+  if (t < 256) {
     // thread d resolves digit d: base of this workgroup + counts of earlier waves
     uint32_t run = scanned[(size_t)t * nblocks + blockIdx.x];
 #pragma unroll
