@@ -767,10 +767,18 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   const uint32_t* comp_c = same ? h_root.data() : h_root.data() + rows.n;
   // sketches of one component become adjacent (stable: original order inside a component)
   std::vector<uint32_t> rperm(rows.n), cperm(cols.n);
-  for (uint32_t i = 0; i < rows.n; i++) rperm[i] = i;
-  for (uint32_t j = 0; j < cols.n; j++) cperm[j] = j;
-  std::stable_sort(rperm.begin(), rperm.end(), [&](uint32_t x, uint32_t y) { return comp_r[x] < comp_r[y]; });
-  std::stable_sort(cperm.begin(), cperm.end(), [&](uint32_t x, uint32_t y) { return comp_c[x] < comp_c[y]; });
+  {
+    // counting sort by root id (roots are node ids < M): O(N), stable
+    std::vector<uint32_t> cnt((size_t)M + 1);
+    auto order_by = [&](const uint32_t* comp, uint32_t nsk, std::vector<uint32_t>& perm) {
+      std::fill(cnt.begin(), cnt.end(), 0u);
+      for (uint32_t i = 0; i < nsk; i++) cnt[(size_t)comp[i] + 1]++;
+      for (size_t k = 1; k <= M; k++) cnt[k] += cnt[k - 1];
+      for (uint32_t i = 0; i < nsk; i++) perm[cnt[comp[i]]++] = i;
+    };
+    order_by(comp_r, rows.n, rperm);
+    order_by(comp_c, cols.n, cperm);
+  }
   std::vector<uint32_t> tile_list;
   auto build_tiles = [&](uint32_t tr) {
     const uint32_t tiles_r = (rows.n + tr - 1) / tr, tiles_c = (cols.n + kTB - 1) / kTB;
