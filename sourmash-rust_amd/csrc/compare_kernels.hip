@@ -506,9 +506,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 }
 
 // ---- pre-pass kernels ---------------------------------------------------------------------
-__global__ void k_iota(uint64_t* p, uint64_t n) {
+__global__ void k_iota(uint32_t* p, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
+  if (i < n) p[i] = (uint32_t)i;
 }
 // bound[r] = rank of the pooled element at sorted position r*n/R (bound[0] = 0, bound[R] = nruns)
 __global__ void k_bounds(const uint32_t* __restrict__ starts, uint32_t nruns, uint32_t n, uint32_t R,
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
 // pairs already united, racy on purpose: a lost or stale entry only repeats a union) keeps those
 // repeats away from the few hot parent words.
 constexpr int kSeenBits = 20;
-__global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ origin,
+__global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
                                                  const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent,
                                                  unsigned long long* seen) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,18 +672,18 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   const uint64_t n = same ? nr_elems : (inside ? nc_elems : nr_elems + nc_elems);
   if (n >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
   // ---- dictionary-encode: sort (hash, origin), run ids -> rank[origin]
-  T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 8); T.org1.ensure(n * 8);
+  T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 4); T.org1.ensure(n * 4);   // origins: element indices < 2^31
   if (inside) {
     HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
   } else {
     HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, rows.hashes, nr_elems * 8, hipMemcpyDeviceToDevice, s));
     if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
   }
-  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint64_t>(), n);
-  int cur = radix_sort_u64(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint64_t>(), T.org1.as<uint64_t>(), n,
-                           dev.scratch, s);
+  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint32_t>(), n);
+  int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), n,
+                               dev.scratch, s);
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
-  uint64_t* so = cur ? T.org1.as<uint64_t>() : T.org0.as<uint64_t>();
+  uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
   T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
   const uint32_t nruns = run_length_encode_u64(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so,
                                                T.rank.as<uint32_t>());

@@ -140,10 +140,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_add(uint32_t* __restrict_
 // stable scatter of one digit.  Wave w of the workgroup owns the contiguous sub-tile
 // [w*1024, (w+1)*1024) of the tile and walks it 64 keys per round, so (wave, round, lane)
 // order is index order and equal digits keep their relative order.
-template <bool HasVals>
+// VB: payload bytes per key (0 = keys only, 4 = u32, 8 = u64)
+template <int VB>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
-    const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout, const uint64_t* __restrict__ vin,
-    uint64_t* __restrict__ vout, size_t n, int shift, const uint32_t* __restrict__ scanned,
+    const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout, const void* __restrict__ vin_,
+    void* __restrict__ vout_, size_t n, int shift, const uint32_t* __restrict__ scanned,
     uint32_t nblocks) {
   __shared__ uint32_t wcount[kWaves][256];
   __shared__ uint32_t woff[kWaves][256];
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
       uint32_t d = meta[i] >> 16, r = meta[i] & 0xFFFFu;
       size_t o = (size_t)woff[w][d] + r;
       kout[o] = key[i];
-      if (HasVals) vout[o] = vin[idx];
+      if (VB == 8) static_cast<uint64_t*>(vout_)[o] = static_cast<const uint64_t*>(vin_)[idx];
+      if (VB == 4) static_cast<uint32_t*>(vout_)[o] = static_cast<const uint32_t*>(vin_)[idx];
     }
   }
 }
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
                                                            const uint32_t* __restrict__ bscan,
                                                            uint64_t* __restrict__ uniq,
                                                            uint32_t* __restrict__ starts,
-                                                           const uint64_t* __restrict__ origin,
+                                                           const uint32_t* __restrict__ origin,
                                                            uint32_t* __restrict__ rank_out) {
   __shared__ uint32_t wsum[kRleThreads / 64];
   size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
@@ -308,8 +310,8 @@ static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, uint32_t*
 }
 static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanChunk + 1; }
 
-int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
+static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
+                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
   const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
@@ -332,7 +334,7 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
 
   int cur = 0;
   uint64_t* kk[2] = {k0, k1};
-  uint64_t* vv[2] = {v0, v1};
+  void* vv[2] = {v0, v1};
   for (int p = first_pass; p < last_pass; p++) {
     bool trivial = false;
     for (int d = 0; d < 256; d++)
@@ -341,11 +343,14 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
     hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
                        blockhist, nblocks);
     exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, scan_tmp, s);
-    if (v0)
-      hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
+    if (v0 && vbytes == 8)
+      hipLaunchKernelGGL(k_radix_scatter<8>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks);
+    else if (v0 && vbytes == 4)
+      hipLaunchKernelGGL(k_radix_scatter<4>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
                          kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks);
     else
-      hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
+      hipLaunchKernelGGL(k_radix_scatter<0>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
                          kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks);
     HIP_CHECK(hipGetLastError());
     cur ^= 1;
@@ -353,8 +358,17 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
   return cur;
 }
 
+int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
+  return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass);
+}
+int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
+                       hipStream_t s) {
+  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8);
+}
+
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
-                               DeviceBuffer& scratch, hipStream_t s, const uint64_t* origin, uint32_t* rank_out,
+                               DeviceBuffer& scratch, hipStream_t s, const uint32_t* origin, uint32_t* rank_out,
                                const uint64_t* key2, uint64_t* uniq2, int key2_shift) {
   if (n == 0) return 0;
   if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
