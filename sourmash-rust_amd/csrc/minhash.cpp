@@ -908,7 +908,8 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
       all_scaled &= mode == kScaled && m.max_hash == m0.max_hash;
       all_num &= mode == kNum;
     }
-    if (same && n_mh <= 65536) {
+    if (same) same = n_mh < (1u << 24);   // the group tag shares a word with the position (24 + 40 bits)
+    if (same) {
       // one sketch listed twice is served in order instead
       std::vector<const KmerMinHash*> sorted(mhs, mhs + n_mh);
       std::sort(sorted.begin(), sorted.end());
