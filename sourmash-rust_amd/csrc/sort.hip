@@ -20,12 +20,9 @@ namespace smh {
 
 namespace {
 
-#ifndef SMH_SORT_THREADS
-#define SMH_SORT_THREADS 256
-#endif
-constexpr int kSortThreads = SMH_SORT_THREADS;
-constexpr int kSortItems = 16;                       // keys per thread per tile
-constexpr int kSortTile = kSortThreads * kSortItems;  // 4096 keys per workgroup
+constexpr int kSortThreads = 256;   // one thread per digit value in the count / scatter kernels
+constexpr int kSortItems = 8;                        // keys per thread per tile (16 KB LDS stage: 6 workgroups per CU)
+constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 keys per workgroup
 constexpr int kWaves = kSortThreads / 64;
 
 __device__ __forceinline__ uint64_t lanemask_lt() {
@@ -138,8 +135,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_add(uint32_t* __restrict_
 }
 
 // stable scatter of one digit.  Wave w of the workgroup owns the contiguous sub-tile
-// [w*1024, (w+1)*1024) of the tile and walks it 64 keys per round, so (wave, round, lane)
+// [w*512, (w+1)*512) of the tile and walks it 64 keys per round, so (wave, round, lane)
 // order is index order and equal digits keep their relative order.
+// The tile is first put in digit order in LDS, then written out by consecutive lanes: a wave's
+// store covers a few contiguous digit runs instead of 64 scattered 8-byte pieces (the direct
+// scatter ran at 1.6 TB/s of combined traffic, bound by partial-line writes).
 // VB: payload bytes per key (0 = keys only, 4 = u32, 8 = u64)
 template <int VB>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
@@ -147,12 +147,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     void* __restrict__ vout_, size_t n, int shift, const uint32_t* __restrict__ scanned,
     uint32_t nblocks) {
   __shared__ uint32_t wcount[kWaves][256];
-  __shared__ uint32_t woff[kWaves][256];
+  __shared__ uint32_t lbase[kWaves][256];   // position in the digit-ordered tile of (wave, digit)'s first key
+  __shared__ uint32_t dexcl[256];           // first position of digit d in the digit-ordered tile
+  __shared__ uint32_t gbase[256];           // first global position of digit d for this workgroup
+  __shared__ uint32_t wtot[kWaves];
+  __shared__ __attribute__((aligned(16))) uint64_t stage[kSortTile];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   for (int i = t; i < kWaves * 256; i += kSortThreads) (&wcount[0][0])[i] = 0;
   __syncthreads();
 
-  const size_t wbase = (size_t)blockIdx.x * kSortTile + (size_t)w * (kSortItems * 64);
+  const size_t tbase = (size_t)blockIdx.x * kSortTile;
+  const size_t wbase = tbase + (size_t)w * (kSortItems * 64);
+  const uint32_t tile_n = (uint32_t)((n - tbase) < (size_t)kSortTile ? (n - tbase) : (size_t)kSortTile);
   uint64_t key[kSortItems];
   uint32_t meta[kSortItems];  // digit << 16 | rank within the wave's sub-tile
   const uint64_t lt = lanemask_lt();
@@ -176,25 +182,69 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     if (active && below == 0) wcount[w][d] = prior + (uint32_t)__popcll(m);
   }
   __syncthreads();
-  if (t < 256) {
-    // thread d resolves digit d: base of this workgroup + counts of earlier waves
-    uint32_t run = scanned[(size_t)t * nblocks + blockIdx.x];
+  {
+    // thread d resolves digit d (kSortThreads == 256): tile-wide exclusive scan over the digits
+    uint32_t tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < kWaves; ww++) tot += wcount[ww][t];
+    uint32_t incl = tot;
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int ww = 0; ww < w; ww++) before += wtot[ww];
+    const uint32_t ex = before + incl - tot;
+    dexcl[t] = ex;
+    gbase[t] = scanned[(size_t)t * nblocks + blockIdx.x];
+    uint32_t run = ex;
 #pragma unroll
     for (int ww = 0; ww < kWaves; ww++) {
-      woff[ww][t] = run;
+      lbase[ww][t] = run;
       run += wcount[ww][t];
     }
   }
   __syncthreads();
+  // keys into digit order
 #pragma unroll
   for (int i = 0; i < kSortItems; i++) {
     size_t idx = wbase + (size_t)i * 64 + lane;
-    if (idx < n) {
-      uint32_t d = meta[i] >> 16, r = meta[i] & 0xFFFFu;
-      size_t o = (size_t)woff[w][d] + r;
-      kout[o] = key[i];
-      if (VB == 8) static_cast<uint64_t*>(vout_)[o] = static_cast<const uint64_t*>(vin_)[idx];
-      if (VB == 4) static_cast<uint32_t*>(vout_)[o] = static_cast<const uint32_t*>(vin_)[idx];
+    if (idx < n) stage[lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu)] = key[i];
+  }
+  __syncthreads();
+  uint32_t gpos[kSortItems];
+#pragma unroll
+  for (int i = 0; i < kSortItems; i++) {
+    const uint32_t p = (uint32_t)i * kSortThreads + t;   // consecutive lanes, consecutive positions
+    gpos[i] = 0;
+    if (p < tile_n) {
+      const uint64_t k = stage[p];
+      const uint32_t d = (uint32_t)(k >> shift) & 255u;
+      gpos[i] = gbase[d] + (p - dexcl[d]);
+      kout[gpos[i]] = k;
+    }
+  }
+  if (VB != 0) {
+    __syncthreads();   // everyone has read the keys: the stage is reused for the payload
+#pragma unroll
+    for (int i = 0; i < kSortItems; i++) {
+      size_t idx = wbase + (size_t)i * 64 + lane;
+      if (idx < n) {
+        const uint32_t lp = lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu);
+        if (VB == 8) stage[lp] = static_cast<const uint64_t*>(vin_)[idx];
+        if (VB == 4) reinterpret_cast<uint32_t*>(stage)[lp] = static_cast<const uint32_t*>(vin_)[idx];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSortItems; i++) {
+      const uint32_t p = (uint32_t)i * kSortThreads + t;
+      if (p < tile_n) {
+        if (VB == 8) static_cast<uint64_t*>(vout_)[gpos[i]] = stage[p];
+        if (VB == 4) static_cast<uint32_t*>(vout_)[gpos[i]] = reinterpret_cast<uint32_t*>(stage)[p];
+      }
     }
   }
 }
