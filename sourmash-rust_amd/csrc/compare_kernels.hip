@@ -23,6 +23,7 @@
 
 #include "device.hpp"
 #include "kernels.hpp"
+#include "tile_plan.hpp"
 
 namespace smh {
 namespace {
@@ -765,64 +766,24 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   HIP_CHECK(hipStreamSynchronize(s));
   const uint32_t* comp_r = h_root.data();
   const uint32_t* comp_c = same ? h_root.data() : h_root.data() + rows.n;
-  // sketches of one component become adjacent (stable: original order inside a component)
-  std::vector<uint32_t> rperm(rows.n), cperm(cols.n);
-  {
-    // counting sort by root id (roots are node ids < M): O(N), stable
-    std::vector<uint32_t> cnt((size_t)M + 1);
-    auto order_by = [&](const uint32_t* comp, uint32_t nsk, std::vector<uint32_t>& perm) {
-      std::fill(cnt.begin(), cnt.end(), 0u);
-      for (uint32_t i = 0; i < nsk; i++) cnt[(size_t)comp[i] + 1]++;
-      for (size_t k = 1; k <= M; k++) cnt[k] += cnt[k - 1];
-      for (uint32_t i = 0; i < nsk; i++) perm[cnt[comp[i]]++] = i;
-    };
-    order_by(comp_r, rows.n, rperm);
-    order_by(comp_c, cols.n, cperm);
-  }
-  std::vector<uint32_t> tile_list;
-  auto build_tiles = [&](uint32_t tr) {
-    const uint32_t tiles_r = (rows.n + tr - 1) / tr, tiles_c = (cols.n + kTB - 1) / kTB;
-    tile_list.clear();
-    if ((uint64_t)tiles_r * tiles_c > (1ull << 28)) {   // too many to flag one by one: visit them all
-      for (uint32_t i = 0; i < tiles_r; i++)
-        for (uint32_t j = 0; j < tiles_c; j++) {
-          if (symmetric && (uint64_t)j * kTB + kTB - 1 < (uint64_t)i * tr) continue;
-          tile_list.push_back(i); tile_list.push_back(j);
-        }
-      return;
-    }
-    std::vector<uint8_t> flag((size_t)tiles_r * tiles_c, std::getenv("SOURMASH_AMD_CMP_ALL_TILES") ? 1 : 0);
-    // both slot sequences are sorted by component: walk them together
-    uint32_t i = 0, j = 0;
-    while (i < rows.n && j < cols.n) {
-      const uint32_t cr = comp_r[rperm[i]], cc = comp_c[cperm[j]];
-      if (cr < cc) { i++; continue; }
-      if (cc < cr) { j++; continue; }
-      uint32_t i1 = i, j1 = j;
-      while (i1 < rows.n && comp_r[rperm[i1]] == cr) i1++;
-      while (j1 < cols.n && comp_c[cperm[j1]] == cr) j1++;
-      for (uint32_t ti = i / tr; ti <= (i1 - 1) / tr; ti++)
-        for (uint32_t tj = j / kTB; tj <= (j1 - 1) / kTB; tj++) flag[(size_t)ti * tiles_c + tj] = 1;
-      i = i1; j = j1;
-    }
-    for (uint32_t ti = 0; ti < tiles_r; ti++)
-      for (uint32_t tj = 0; tj < tiles_c; tj++) {
-        // symmetric: a tile wholly below the diagonal (all its column slots < all its row slots) is
-        // produced by the mirrored writes of the tiles above it
-        if (symmetric && (uint64_t)tj * kTB + kTB - 1 < (uint64_t)ti * tr) continue;
-        if (flag[(size_t)ti * tiles_c + tj]) { tile_list.push_back(ti); tile_list.push_back(tj); }
-      }
-  };
+  // sketches of one component become adjacent (stable: original order inside a component); then
+  // the tiles that can hold a same-component pair (tile_plan.cpp, host only)
+  TilePlan plan;
+  plan_order(comp_r, rows.n, comp_c, cols.n, M, &plan);
+  const bool all_on = std::getenv("SOURMASH_AMD_CMP_ALL_TILES") != nullptr;
   uint32_t tr = (uint32_t)(rpw * wpb);
-  build_tiles(tr);
+  plan_tiles(comp_r, rows.n, comp_c, cols.n, tr, kTB, symmetric, all_on, &plan);
   if (std::getenv("SOURMASH_AMD_CMP_GEO") == nullptr && wpb == 4 && minw == 8) {
     // few tiles left: shorter ones fill the chip better (the kernel is latency bound, a
     // workgroup per CU leaves 7/8 of the wave slots empty)
-    while (rpw > 1 && tile_list.size() / 2 < (size_t)dev.cu_count() * 32) {
+    while (rpw > 1 && plan.tiles.size() / 2 < (size_t)dev.cu_count() * 32) {
       rpw >>= 1; tr = (uint32_t)(rpw * wpb);
-      build_tiles(tr);
+      plan_tiles(comp_r, rows.n, comp_c, cols.n, tr, kTB, symmetric, all_on, &plan);
     }
   }
+  const std::vector<uint32_t>& rperm = plan.rperm;
+  const std::vector<uint32_t>& cperm = plan.cperm;
+  const std::vector<uint32_t>& tile_list = plan.tiles;
   const uint32_t tiles = (uint32_t)(tile_list.size() / 2);
   const uint64_t all_tiles = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
   g_last_tiles_visited = tiles; g_last_tiles_total = all_tiles; g_last_pairs_per_tile = (uint64_t)tr * kTB;

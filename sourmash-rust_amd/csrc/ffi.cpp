@@ -1,6 +1,7 @@
 // ffi.cpp -- the C ABI: every symbol of include/sourmash.h (the reference's surface, restating
 // src/ffi.rs and src/utils.rs) and the additive MI355X entry points of include/sourmash_amd.h.
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -8,6 +9,7 @@
 
 #include "../../include/sourmash_amd.h"
 #include "minhash.hpp"
+#include "tile_plan.hpp"
 #include "signature.hpp"
 
 using smh::Error;
@@ -722,6 +724,22 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
 
 void smh_compare_last_stats(uint64_t* tiles_visited, uint64_t* tiles_total, uint64_t* pairs_per_tile) {
   smh::compare_last_stats(tiles_visited, tiles_total, pairs_per_tile);
+}
+
+// test hook (host only, no device): the compare block's tile planning
+int smh_test_plan_tiles(const uint32_t* comp_r, uint32_t nrows, const uint32_t* comp_c, uint32_t ncols, uint32_t max_comp,
+                        uint32_t tr, uint32_t tc, bool symmetric, uint32_t* rperm_out, uint32_t* cperm_out,
+                        uint32_t* tiles_out, uint32_t tiles_cap, uint32_t* n_tiles) {
+  return pad_code([&] {
+    require(n_tiles, "n_tiles");
+    smh::TilePlan plan;
+    smh::plan_order(comp_r, nrows, comp_c, ncols, max_comp, &plan);
+    smh::plan_tiles(comp_r, nrows, comp_c, ncols, tr, tc, symmetric, false, &plan);
+    *n_tiles = (uint32_t)(plan.tiles.size() / 2);
+    if (rperm_out) std::copy(plan.rperm.begin(), plan.rperm.end(), rperm_out);
+    if (cperm_out) std::copy(plan.cperm.begin(), plan.cperm.end(), cperm_out);
+    if (tiles_out && plan.tiles.size() <= (size_t)tiles_cap * 2) std::copy(plan.tiles.begin(), plan.tiles.end(), tiles_out);
+  });
 }
 
 int smh_release_workspace(void) {

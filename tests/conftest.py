@@ -78,3 +78,9 @@ def pkg():
     if not os.path.exists(os.path.join(ROOT, "sourmash-rust_amd", "lib", "libsourmash_amd.so")):
         ge.build()
     return ge.load_package()
+
+
+@pytest.fixture(scope="session")
+def pkg_lib(pkg):
+    """The loaded C-ABI library (ctypes); loading needs no GPU."""
+    return pkg.lib()
