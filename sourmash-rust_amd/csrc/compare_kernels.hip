@@ -205,6 +205,36 @@ __global__ __launch_bounds__(256) void k_pair_grid(const uint64_t* __restrict__ 
 // |A u Q| = |A| + |Q| - count_common.  The search window's lower end is carried from step to step
 // (elements ascend).  Unlike k_compare_wave the LDS footprint is one Q per workgroup, not A + B per
 // wave, so occupancy stays high.
+struct WavePair { uint32_t cm, cc; bool cut; };
+// one wave, one ordered pair (A streamed from memory, Q searched): see k_compare_few
+template <bool WantCC>
+__device__ __forceinline__ WavePair wave_pair(const uint64_t* __restrict__ A, uint32_t la, const uint64_t* Q, uint32_t lq,
+                                              uint32_t n, int lane) {
+  uint32_t base = 0, cc = 0, cm = 0;
+  bool cut = false;
+  for (uint32_t i0 = 0; i0 < la; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool ok = i < la;
+    const uint64_t a = ok ? A[i] : ~0ull;
+    uint32_t lo = base, len = lq - base;
+    while (len > 0) {
+      const uint32_t half = len >> 1, mid = lo + half;
+      const bool lt = Q[mid] < a;
+      lo = lt ? mid + 1 : lo;
+      len = lt ? len - half - 1 : half;
+    }
+    const bool match = ok && lo < lq && Q[lo] == a;
+    const uint64_t mm = __ballot(match);
+    const uint32_t u = i + lo - (cc + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
+    cm += (uint32_t)__popcll(__ballot(match && u < n));
+    cc += (uint32_t)__popcll(mm);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+    // union rank of the step's last element already past the cut: nothing later can count
+    if (!WantCC && (uint32_t)__builtin_amdgcn_readlane((int)u, 63) >= n && i0 + 64 <= la) { cut = true; break; }
+  }
+  return {cm, cc, cut};
+}
+
 template <bool QLds, bool WantCC>
 __global__ __launch_bounds__(256) void k_compare_few(SketchSet many, SketchSet few, uint32_t many_is_row, uint32_t num,
                                                      const uint32_t* __restrict__ row_nums, CompareOut out) {
@@ -222,41 +252,75 @@ __global__ __launch_bounds__(256) void k_compare_few(SketchSet many, SketchSet f
   for (uint32_t node = blockIdx.x * 4 + w; node < many.n; node += gridDim.x * 4) {
     const uint64_t ao = many.offsets[node];
     const uint32_t la = (uint32_t)(many.offsets[node + 1] - ao);
-    const uint64_t* A = many.hashes + ao;
     uint32_t n = row_nums ? row_nums[many_is_row ? node : y] : num;
     n = n ? n : 0xffffffffu;
-    uint32_t base = 0, cc = 0, cm = 0;
-    bool cut = false;
-    for (uint32_t i0 = 0; i0 < la; i0 += 64) {
-      const uint32_t i = i0 + lane;
-      const bool ok = i < la;
-      const uint64_t a = ok ? A[i] : ~0ull;
-      uint32_t lo = base, len = lq - base;
-      while (len > 0) {
-        const uint32_t half = len >> 1, mid = lo + half;
-        const bool lt = Q[mid] < a;
-        lo = lt ? mid + 1 : lo;
-        len = lt ? len - half - 1 : half;
-      }
-      const bool match = ok && lo < lq && Q[lo] == a;
-      const uint64_t mm = __ballot(match);
-      const uint32_t u = i + lo - (cc + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
-      cm += (uint32_t)__popcll(__ballot(match && u < n));
-      cc += (uint32_t)__popcll(mm);
-      base = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
-      // union rank of the step's last element already past the cut: nothing later can count
-      if (!WantCC && (uint32_t)__builtin_amdgcn_readlane((int)u, 63) >= n && i0 + 64 <= la) { cut = true; break; }
-    }
+    const WavePair r = wave_pair<WantCC>(many.hashes + ao, la, Q, lq, n, lane);
     if (lane == 0) {
-      const uint64_t tot_u = (uint64_t)la + lq - cc;
-      const uint64_t size = (cut || tot_u > n) ? n : tot_u;
+      const uint64_t tot_u = (uint64_t)la + lq - r.cc;
+      const uint64_t size = (r.cut || tot_u > n) ? n : tot_u;
       const size_t pid = many_is_row ? (size_t)node * few.n + y : (size_t)y * many.n + node;
-      if (out.common) out.common[pid] = cm;
+      if (out.common) out.common[pid] = r.cm;
       if (out.size) out.size[pid] = size;
-      if (out.jaccard) out.jaccard[pid] = (double)cm / (double)(size > 1 ? size : 1);
+      if (out.jaccard) out.jaccard[pid] = (double)r.cm / (double)(size > 1 ? size : 1);
       if (WantCC) {
-        if (out.count_common) out.count_common[pid] = cc;
-        if (out.containment) out.containment[pid] = (double)cc / (double)(many_is_row ? la : lq);
+        if (out.count_common) out.count_common[pid] = r.cc;
+        if (out.containment) out.containment[pid] = (double)r.cc / (double)(many_is_row ? la : lq);
+      }
+    }
+  }
+}
+
+// k_compare_comp: the N x M block when only a modest number of pairs can share a hash (small
+// components): one workgroup per (column, its component's rows).  The column sketch sits in LDS,
+// each wave takes rows of the same component -- slots [r0, r1) of the row order -- and computes
+// the pair exactly like k_compare_few.  No rank encoding is needed on this route, and a pair
+// keeps 64 lanes busy instead of one, which is what a launch of a few thousand pairs needs.
+struct CompWork { uint32_t col, r0, r1; };
+template <bool QLds, bool WantCC>
+__global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet cols, const CompWork* __restrict__ work,
+                                                      const uint32_t* __restrict__ rperm, uint32_t num,
+                                                      const uint32_t* __restrict__ row_nums, uint32_t symmetric,
+                                                      CompareOut out) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const CompWork wk = work[blockIdx.x];
+  const uint32_t col = wk.col;
+  const uint64_t qo = cols.offsets[col];
+  const uint32_t lq = (uint32_t)(cols.offsets[col + 1] - qo);
+  const uint64_t* Q = cols.hashes + qo;
+  if (QLds) {
+    for (uint32_t t = tid; t < lq; t += 256) lds64[t] = Q[t];
+    __syncthreads();
+    Q = lds64;
+  }
+  for (uint32_t slot = wk.r0 + w; slot < wk.r1; slot += 4) {
+    const uint32_t row = rperm[slot];
+    const uint64_t ao = rows.offsets[row];
+    const uint32_t la = (uint32_t)(rows.offsets[row + 1] - ao);
+    uint32_t n = row_nums ? row_nums[row] : num;
+    n = n ? n : 0xffffffffu;
+    const WavePair r = wave_pair<WantCC>(rows.hashes + ao, la, Q, lq, n, lane);
+    if (lane == 0) {
+      const uint64_t tot_u = (uint64_t)la + lq - r.cc;
+      const uint64_t size = (r.cut || tot_u > n) ? n : tot_u;
+      const double jac = (double)r.cm / (double)(size > 1 ? size : 1);
+      const size_t pid = (size_t)row * cols.n + col;
+      if (out.common) out.common[pid] = r.cm;
+      if (out.size) out.size[pid] = size;
+      if (out.jaccard) out.jaccard[pid] = jac;
+      if (WantCC) {
+        if (out.count_common) out.count_common[pid] = r.cc;
+        if (out.containment) out.containment[pid] = (double)r.cc / (double)la;
+      }
+      if (symmetric && row != col) {   // same list on both axes, one num: also pair (col, row)
+        const size_t pid2 = (size_t)col * cols.n + row;
+        if (out.common) out.common[pid2] = r.cm;
+        if (out.size) out.size[pid2] = size;
+        if (out.jaccard) out.jaccard[pid2] = jac;
+        if (WantCC) {
+          if (out.count_common) out.count_common[pid2] = r.cc;
+          if (out.containment) out.containment[pid2] = (double)r.cc / (double)lq;
+        }
       }
     }
   }
@@ -589,22 +653,25 @@ __global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
   if (i < m) parent[i] = i;
 }
 // sorted position i continues the run of i-1 (same hash): their sketches are connected
-// Related sketches meet as neighbours in thousands of runs; `seen` (a direct-mapped table of the
-// pairs already united, racy on purpose: a lost or stale entry only repeats a union) keeps those
-// repeats away from the few hot parent words.
-constexpr int kSeenBits = 20;
+// Related sketches meet as neighbours in thousands of runs, and every one of those unions ends at
+// the same few parent words.  Device-scope loads on this part are served past the per-XCD L2s, so
+// they are rationed: a first launch unites a small sample of the neighbour pairs, which already
+// connects nearly everything; the later launches (fresh caches) look at more pairs with ORDINARY
+// cached loads first -- a stale parent word still names an ancestor, so equal roots in a cached
+// view prove the two are connected -- and only the few that are not go to the atomic path.
+template <int Shift, bool Filter>
 __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
-                                                 const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent,
-                                                 unsigned long long* seen) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                 const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent) {
+  uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) << Shift;
   if (i == 0 || i >= n) return;
   if (keys[i] != keys[i - 1]) return;
-  const uint32_t a = node[origin[i]], b = node[origin[i - 1]];
+  uint32_t a = node[origin[i]], b = node[origin[i - 1]];
   if (a == b) return;
-  const unsigned long long pair = ((unsigned long long)a << 32) | b;
-  const uint32_t slot = ((a * 0x9E3779B1u) ^ (b * 0x85EBCA77u)) >> (32 - kSeenBits);
-  if (seen[slot] == pair) return;
-  seen[slot] = pair;
+  if (Filter) {
+    for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[a]; if (p == a) break; a = p; }
+    for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[b]; if (p == b) break; b = p; }
+    if (a == b) return;
+  }
   uf_union(parent, a, b);
 }
 // a row block that is a slice of the column set: row element t IS column element delta + t
@@ -637,7 +704,7 @@ __global__ __launch_bounds__(256) void k_fill_disjoint(const uint64_t* __restric
 }
 
 struct TiledScratch {
-  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, perm, seen;
+  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, perm;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -656,7 +723,7 @@ void compare_last_stats(uint64_t* visited, uint64_t* total, uint64_t* pairs_per_
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
-                          &T.node, &T.parent, &T.root, &T.tiles, &T.perm, &T.seen})
+                          &T.node, &T.parent, &T.root, &T.tiles, &T.perm})
     b->release();
 }
 
@@ -685,6 +752,97 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
                                dev.scratch, s);
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
+  // ---- components: which tiles can hold a pair that shares a hash
+  const uint32_t M = same ? cols.n : rows.n + cols.n;
+  T.node.ensure((size_t)(n + (inside ? nr_elems : 0)) * 4);
+  T.parent.ensure((size_t)M * 4); T.root.ensure((size_t)M * 4);
+  uint32_t* d_node = T.node.as<uint32_t>();
+  auto elem_nodes = [&](const SketchSet& set, uint64_t ne, uint32_t base, uint32_t* dst) {
+    if (ne) hipLaunchKernelGGL(k_elem_node, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, set.offsets, set.n, ne, base, dst);
+  };
+  if (same) elem_nodes(cols, nc_elems, 0, d_node);
+  else if (inside) { elem_nodes(cols, nc_elems, rows.n, d_node); elem_nodes(rows, nr_elems, 0, d_node + n); }
+  else { elem_nodes(rows, nr_elems, 0, d_node); elem_nodes(cols, nc_elems, rows.n, d_node + nr_elems); }
+  hipLaunchKernelGGL(k_uf_init, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M);
+  // 1/256 sample straight to the atomic path, then 1/16 and everything through the cached filter
+  hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((n / 256 + 256) / 256)), dim3(256), 0, s, sk, so, d_node, n,
+                     T.parent.as<uint32_t>());
+  hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, s, sk, so, d_node, n,
+                     T.parent.as<uint32_t>());
+  hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sk, so, d_node, n,
+                     T.parent.as<uint32_t>());
+  if (inside && nr_elems)
+    hipLaunchKernelGGL(k_uf_alias, dim3((unsigned)((nr_elems + 255) / 256)), dim3(256), 0, s, d_node + n, d_node, nr_elems,
+                       (uint64_t)(rows.hashes - cols.hashes), T.parent.as<uint32_t>());
+  hipLaunchKernelGGL(k_uf_roots, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M, T.root.as<uint32_t>());
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> h_root(M);
+  HIP_CHECK(hipMemcpyAsync(h_root.data(), T.root.ptr, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  const uint32_t* comp_r = h_root.data();
+  const uint32_t* comp_c = same ? h_root.data() : h_root.data() + rows.n;
+  TilePlan plan;
+  plan_order(comp_r, rows.n, comp_c, cols.n, M, &plan);
+  const bool want_cc = out.count_common || out.containment;
+
+  // ---- few sharing pairs: one workgroup per (column, its component's rows), no rank encoding
+  {
+    const std::vector<uint32_t>& rp = plan.rperm;
+    const std::vector<uint32_t>& cp = plan.cperm;
+    struct Box { uint32_t r0, r1, c0, c1; };
+    std::vector<Box> boxes;
+    uint64_t pairs = 0;
+    for (uint32_t i = 0, j = 0; i < rows.n && j < cols.n;) {
+      const uint32_t cr = comp_r[rp[i]], cc = comp_c[cp[j]];
+      if (cr < cc) { i++; continue; }
+      if (cc < cr) { j++; continue; }
+      uint32_t i1 = i, j1 = j;
+      while (i1 < rows.n && comp_r[rp[i1]] == cr) i1++;
+      while (j1 < cols.n && comp_c[cp[j1]] == cr) j1++;
+      boxes.push_back({i, i1, j, j1});
+      pairs += (uint64_t)(i1 - i) * (j1 - j);
+      i = i1; j = j1;
+    }
+    uint64_t limit = 1ull << 18;
+    if (const char* e = std::getenv("SOURMASH_AMD_CMP_COMP_PAIRS")) limit = std::strtoull(e, nullptr, 10);
+    if (pairs <= limit && std::getenv("SOURMASH_AMD_CMP_ALL_TILES") == nullptr) {
+      constexpr uint32_t kRowsPerItem = 32;
+      std::vector<CompWork> work;
+      for (const Box& b : boxes)
+        for (uint32_t c = b.c0; c < b.c1; c++) {
+          const uint32_t rs = symmetric ? std::max(b.r0, c) : b.r0;   // same order on both axes: upper triangle only
+          for (uint32_t r = rs; r < b.r1; r += kRowsPerItem) work.push_back({cp[c], r, std::min(b.r1, r + kRowsPerItem)});
+        }
+      g_last_tiles_visited = pairs; g_last_tiles_total = (uint64_t)rows.n * cols.n; g_last_pairs_per_tile = 1;
+      const uint64_t np = (uint64_t)rows.n * cols.n;
+      dev.prof_begin(s);
+      hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
+                         cols.n, num, row_nums, out);
+      HIP_CHECK(hipGetLastError());
+      dev.prof_end("compare_fill", s);
+      if (!work.empty()) {
+        T.perm.ensure((size_t)rows.n * 4 + 8);
+        T.tiles.ensure(work.size() * sizeof(CompWork));
+        HIP_CHECK(hipMemcpyAsync(T.perm.ptr, rp.data(), (size_t)rows.n * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(T.tiles.ptr, work.data(), work.size() * sizeof(CompWork), hipMemcpyHostToDevice, s));
+        const uint32_t col_max = max_len;   // bound on the longest column (max over both sides)
+        const bool q_lds = col_max <= 8192;
+        const size_t lds = q_lds ? (size_t)(col_max ? col_max : 1) * 8 : 16;
+        dev.prof_begin(s);
+#define SMH_CC(L_, C_) hipLaunchKernelGGL((k_compare_comp<L_, C_>), dim3((unsigned)work.size()), dim3(256), lds, s, rows, cols, \
+                                          reinterpret_cast<const CompWork*>(T.tiles.ptr), T.perm.as<uint32_t>(), num, row_nums, \
+                                          symmetric ? 1u : 0u, out)
+        if (q_lds) { if (want_cc) SMH_CC(true, true); else SMH_CC(true, false); }
+        else { if (want_cc) SMH_CC(false, true); else SMH_CC(false, false); }
+#undef SMH_CC
+        HIP_CHECK(hipGetLastError());
+        dev.prof_end("compare_comp", s);
+      }
+      HIP_CHECK(hipStreamSynchronize(s));   // work / perm staging vectors are stack-lifetime
+      return;
+    }
+  }
+
   T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
   const uint32_t nruns = run_length_encode_u64(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so,
                                                T.rank.as<uint32_t>());
@@ -731,7 +889,6 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   a.out = out;
   a.dbg = std::getenv("SOURMASH_AMD_CMP_DBG") ? (uint32_t)std::atoi(std::getenv("SOURMASH_AMD_CMP_DBG")) : 0;
   const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;
-  const bool want_cc = out.count_common || out.containment;
   // rows per wave: 16 (64-row tiles) amortises staging best; small problems use shorter tiles so
   // that the launch still covers the chip several times
   // geometry "rpw,wpb,minw" (experiments: SOURMASH_AMD_CMP_GEO)
@@ -740,36 +897,8 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // (1000 x 1000: 2.47 -> 2.20 ms, profiles/r01_compare_small_geometry.txt)
   if ((uint64_t)((rows.n + 15) / 16) * ((cols.n + kTB - 1) / kTB) < (uint64_t)dev.cu_count() * 32) rpw = 2;
   if (const char* e = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(e, "%d,%d,%d", &rpw, &wpb, &minw);
-  // ---- components: which tiles can hold a pair that shares a hash
-  const uint32_t M = same ? cols.n : rows.n + cols.n;
-  T.node.ensure((size_t)(n + (inside ? nr_elems : 0)) * 4);
-  T.parent.ensure((size_t)M * 4); T.root.ensure((size_t)M * 4);
-  uint32_t* d_node = T.node.as<uint32_t>();
-  auto elem_nodes = [&](const SketchSet& set, uint64_t ne, uint32_t base, uint32_t* dst) {
-    if (ne) hipLaunchKernelGGL(k_elem_node, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, set.offsets, set.n, ne, base, dst);
-  };
-  if (same) elem_nodes(cols, nc_elems, 0, d_node);
-  else if (inside) { elem_nodes(cols, nc_elems, rows.n, d_node); elem_nodes(rows, nr_elems, 0, d_node + n); }
-  else { elem_nodes(rows, nr_elems, 0, d_node); elem_nodes(cols, nc_elems, rows.n, d_node + nr_elems); }
-  hipLaunchKernelGGL(k_uf_init, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M);
-  T.seen.ensure((size_t)8 << kSeenBits);
-  HIP_CHECK(hipMemsetAsync(T.seen.ptr, 0, (size_t)8 << kSeenBits, s));   // (0, 0) is never a pair: a != b
-  hipLaunchKernelGGL(k_uf_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sk, so, d_node, n, T.parent.as<uint32_t>(),
-                     T.seen.as<unsigned long long>());
-  if (inside && nr_elems)
-    hipLaunchKernelGGL(k_uf_alias, dim3((unsigned)((nr_elems + 255) / 256)), dim3(256), 0, s, d_node + n, d_node, nr_elems,
-                       (uint64_t)(rows.hashes - cols.hashes), T.parent.as<uint32_t>());
-  hipLaunchKernelGGL(k_uf_roots, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M, T.root.as<uint32_t>());
-  HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> h_root(M);
-  HIP_CHECK(hipMemcpyAsync(h_root.data(), T.root.ptr, (size_t)M * 4, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
-  const uint32_t* comp_r = h_root.data();
-  const uint32_t* comp_c = same ? h_root.data() : h_root.data() + rows.n;
   // sketches of one component become adjacent (stable: original order inside a component); then
   // the tiles that can hold a same-component pair (tile_plan.cpp, host only)
-  TilePlan plan;
-  plan_order(comp_r, rows.n, comp_c, cols.n, M, &plan);
   const bool all_on = std::getenv("SOURMASH_AMD_CMP_ALL_TILES") != nullptr;
   uint32_t tr = (uint32_t)(rpw * wpb);
   plan_tiles(comp_r, rows.n, comp_c, cols.n, tr, kTB, symmetric, all_on, &plan);
