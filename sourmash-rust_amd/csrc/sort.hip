@@ -347,6 +347,33 @@ __global__ __launch_bounds__(256) void k_run_reduce(const uint32_t* __restrict__
 
 }  // namespace
 
+// scan_totals + scan_add in one launch (few chunks): every workgroup sums the totals of the chunks
+// before its own; the last one also reports the grand total
+__global__ __launch_bounds__(kScanThreads) void k_scan_add_fused(uint32_t* __restrict__ data, size_t m,
+                                                                 const uint32_t* __restrict__ chunk_tot, uint32_t nchunks,
+                                                                 uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t wsum[kScanThreads / 64];
+  __shared__ uint32_t off_s;
+  uint32_t part = 0;
+  for (uint32_t c = threadIdx.x; c < blockIdx.x; c += kScanThreads) part += chunk_tot[c];
+  for (int o = 32; o; o >>= 1) part += __shfl_xor(part, o);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int i = 0; i < kScanThreads / 64; i++) t += wsum[i];
+    off_s = t;
+    if (total_out && blockIdx.x == nchunks - 1) *total_out = t + chunk_tot[blockIdx.x];
+  }
+  __syncthreads();
+  const uint32_t add = off_s;
+  if (blockIdx.x == 0) return;   // nothing to add to the first chunk
+  const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanPer;
+#pragma unroll
+  for (int i = 0; i < kScanPer; i++)
+    if (base + i < m) data[base + i] += add;
+}
+
 // ---------------------------------------------------------------------------------
 // host drivers
 
@@ -354,8 +381,12 @@ __global__ __launch_bounds__(256) void k_run_reduce(const uint32_t* __restrict__
 static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, uint32_t* tmp, hipStream_t s) {
   const uint32_t nchunks = (uint32_t)((m + kScanChunk - 1) / kScanChunk);
   hipLaunchKernelGGL(k_scan_chunks, dim3(nchunks), dim3(kScanThreads), 0, s, d, m, tmp);
-  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanThreads), 0, s, tmp, nchunks, total);
-  if (nchunks > 1) hipLaunchKernelGGL(k_scan_add, dim3(nchunks), dim3(kScanThreads), 0, s, d, m, tmp);
+  if (nchunks <= 1024) {   // small scans are launch-bound: two launches instead of three
+    if (nchunks > 1 || total) hipLaunchKernelGGL(k_scan_add_fused, dim3(nchunks), dim3(kScanThreads), 0, s, d, m, tmp, nchunks, total);
+  } else {
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanThreads), 0, s, tmp, nchunks, total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nchunks), dim3(kScanThreads), 0, s, d, m, tmp);
+  }
   HIP_CHECK(hipGetLastError());
 }
 static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanChunk + 1; }
