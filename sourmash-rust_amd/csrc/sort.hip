@@ -250,6 +250,45 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
 }
 
 // ---------------------------------------------------------------------------------
+// Up to 4096 keys: one workgroup, bitonic network in LDS.  The eight-pass radix sort is ~40 tiny
+// launches, which is most of the latency of a small sketch (1 MB of DNA leaves ~1000 candidates).
+// Sorting (key, original index) pairs makes it stable, like the LSD sort it stands in for.
+constexpr int kSmallSortMax = 4096;
+template <int VB>
+__global__ __launch_bounds__(1024) void k_small_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
+                                                     const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
+  __shared__ uint64_t sk[kSmallSortMax];
+  __shared__ uint32_t si[kSmallSortMax];
+  uint32_t m = 1;
+  while (m < n) m <<= 1;   // padded size
+  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+    sk[i] = i < n ? kin[i] : ~0ull;
+    si[i] = i < n ? i : 0xffffffffu;   // pads sort after a real ~0 key
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= m; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < m; t += 1024) {
+        const uint32_t p = t ^ j;
+        if (p > t) {
+          const uint64_t a = sk[t], b = sk[p];
+          const uint32_t ia = si[t], ib = si[p];
+          const bool gt = a > b || (a == b && ia > ib);
+          const bool up = (t & k) == 0;
+          if (gt == up) { sk[t] = b; sk[p] = a; si[t] = ib; si[p] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    kout[i] = sk[i];
+    if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[si[i]];
+    if (VB == 4) static_cast<uint32_t*>(vout_)[i] = static_cast<const uint32_t*>(vin_)[si[i]];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // run-length encoding of sorted keys
 constexpr int kRleThreads = 256;
 constexpr int kRleItems = 8;
@@ -395,6 +434,13 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
                            DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
+  if (n <= (size_t)kSmallSortMax && first_pass == 0 && last_pass == 8) {
+    if (v0 && vbytes == 8) hipLaunchKernelGGL(k_small_sort<8>, dim3(1), dim3(1024), 0, s, k0, k1, v0, v1, (uint32_t)n);
+    else if (v0 && vbytes == 4) hipLaunchKernelGGL(k_small_sort<4>, dim3(1), dim3(1024), 0, s, k0, k1, v0, v1, (uint32_t)n);
+    else hipLaunchKernelGGL(k_small_sort<0>, dim3(1), dim3(1024), 0, s, k0, k1, nullptr, nullptr, (uint32_t)n);
+    HIP_CHECK(hipGetLastError());
+    return 1;
+  }
   const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
   const size_t hist_bytes = 8 * 256 * sizeof(unsigned long long);
   const size_t bh_bytes = (size_t)256 * nblocks * sizeof(uint32_t);
