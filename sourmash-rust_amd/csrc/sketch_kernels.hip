@@ -610,7 +610,7 @@ template <int W>
 __device__ __forceinline__ void hash_run(const uint8_t* __restrict__ res, const uint64_t* __restrict__ seg_off,
                                          uint32_t nseg, uint32_t win_rt, const HashParams& hp, uint64_t thr,
                                          const CandSink& sink, const Stage& stage, bool aligned, uint64_t g0,
-                                         uint64_t blk_seg_end) {
+                                         uint64_t blk_seg_end, const uint64_t* k2lut) {
   {
     const uint32_t win = W ? (uint32_t)W : win_rt;
     // the workgroup's first segment was looked up once with uniform (scalar) loads; only lanes
@@ -664,7 +664,10 @@ __device__ __forceinline__ void hash_run(const uint8_t* __restrict__ res, const 
         const uint64_t k2 = Wd[4 * blk + 2] | ((uint64_t)Wd[4 * blk + 3] << 32);
         if (blk < nblocks) mm3_block(h1, h2, k1, k2);
         else if (blk == nblocks) {
-          if (tail > 8) h2 ^= mix_k2(k2);
+          // nine residues: k2 is a single byte, its mix comes from a 256-entry table (2 of the 8
+          // 64-bit multiplies of the hash)
+          if (W == 9) h2 ^= k2lut[k2 & 0xffu];
+          else if (tail > 8) h2 ^= mix_k2(k2);
           if (tail > 0) h1 ^= mix_k1(k1);
         }
       }
@@ -684,8 +687,10 @@ __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict_
                                                       uint32_t nseg, uint32_t win, HashParams hp,
                                                       CandSink sink, uint32_t stage_cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
+  __shared__ uint64_t k2lut[W == 9 ? 256 : 1];
   const Stage stage{wsm, reinterpret_cast<uint64_t*>(wsm + 4), reinterpret_cast<uint64_t*>(wsm + 4) + stage_cap, stage_cap};
   if (threadIdx.x == 0) wsm[0] = 0;
+  if (W == 9) k2lut[threadIdx.x] = mix_k2((uint64_t)threadIdx.x);   // 256 threads, 256 byte values
   __syncthreads();
   const uint64_t thr = hp.thr;
   const bool aligned = ((hp.range_lo | (uintptr_t)res) & 7) == 0 && win <= 32 && win >= 1;
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(256) void k_hash_windows(const uint8_t* __restrict_
     const uint64_t g0 = b0 + (uint64_t)threadIdx.x * kWinRun;
     while (seg + 1 < nseg && b0 >= seg_off[seg + 1]) seg++;   // b0 is uniform
     const uint64_t blk_seg_end = seg_off[seg + 1];
-    if (g0 < hp.range_hi) hash_run<W>(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0, blk_seg_end);
+    if (g0 < hp.range_hi) hash_run<W>(res, seg_off, nseg, win, hp, thr, sink, stage, aligned, g0, blk_seg_end, k2lut);
     // a pass covers only 2048 windows: flushing (a returning global atomic) every pass would cost
     // more than the hashing; wait until the stage is half full
     stage_flush(stage, sink, threadIdx.x, blockDim.x, stage_cap / 2);
