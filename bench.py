@@ -223,7 +223,8 @@ def main():
                          "valu_bound": {"kernel_kmers_per_s": kmers_per_step / max(1.0, launches_per_step) / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
                                         "bare_murmur64_ceiling_per_s": MURMUR_CEILING,
                                         "frac": (kmers_per_step / max(1.0, launches_per_step) / (kern_ms * 1e-3) / MURMUR_CEILING) if kern_ms > 0 else 0.0},
-                         "note": "1 B/k-mer: the path is integer-VALU bound (46 multiply-class + ~110 other VALU ops per k-mer), "
+                         "note": "1 B/k-mer: the path is integer-VALU bound (34 multiply-class + ~105 other VALU ops per k-mer; a third of murmur's "
+                                 "multiplies come from LDS product tables, which is why the kernel can approach the straightforward bare-murmur rate), "
                                  "not HBM bound; see DESIGN.md 'Roofline'"},
             "cpu_baseline": cpu,
             "compare": compare,

@@ -140,22 +140,34 @@ __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <=
 
 // ---------------------------------------------------------------------------------
 // DNA arm, rolling 2-bit windows, ksize <= 64
-constexpr int kLutReplicas = 16;                 // lane l uses replica l & 15: at most 2-way conflicts
-constexpr int kLutDwords = 256 * kLutReplicas;   // 16 KiB
+// Product tables.  A k-mer reaches murmur as 8-byte words of ASCII letters, and the first thing
+// murmur does with a word is multiply it by c1 (k1 words) or c2 (k2 words).  Multiplication
+// distributes over the word's two 4-letter halves,  w*c = lo*c + ((hi*c) << 32)  (mod 2^64), and a
+// half is one of 256 strings, so the products come from tables indexed by the 2-bit digits the
+// kernel already holds: P1[i] = ascii4(i)*c1, P2[i] = ascii4(i)*c2 as u64 (the high half of a word
+// needs only the low dword of the entry), plus one small table for the k-mer's last, partial group
+// of letters.  This replaces the digit -> ASCII table AND a third of the 64-bit multiplies.
+constexpr int kLutReplicas = 2;                              // lane l uses replica l & 1 (1, 2: 37.8 ms; 4, 8: 39.7; 16: 50.5 -- LDS size, not bank conflicts, is what matters)
+constexpr int kLutEntries = 256 + 256 + 64;                  // P1, P2, partial group
+constexpr int kLutDwords = kLutEntries * kLutReplicas * 2;   // u64 entries: 9 KiB
 
-// murmur64 of a k-mer given as little-endian dwords D[0 .. 4*L) (bytes beyond K are zero)
+// murmur64 from premultiplied words: M[w] = word_w * (w even ? c1 : c2)
 template <int L>
-__device__ __forceinline__ uint64_t murmur_kmer(const uint32_t (&D)[4 * L], int K, uint64_t seed) {
+__device__ __forceinline__ uint64_t murmur_kmer_pre(const uint64_t (&M)[2 * L], int K, uint64_t seed) {
   uint64_t h1 = seed, h2 = seed;
   const int nblocks = K >> 4, tail = K & 15;
 #pragma unroll
   for (int blk = 0; blk < L; blk++) {
-    const uint64_t k1 = D[4 * blk] | ((uint64_t)D[4 * blk + 1] << 32);
-    const uint64_t k2 = D[4 * blk + 2] | ((uint64_t)D[4 * blk + 3] << 32);
-    if (blk < nblocks) mm3_block(h1, h2, k1, k2);
-    else if (blk == nblocks) {
-      if (tail > 8) h2 ^= mix_k2(k2);
-      if (tail > 0) h1 ^= mix_k1(k1);
+    const uint64_t k1 = rotl64(M[2 * blk], 31) * kC2;       // rest of mix_k1
+    const uint64_t k2 = rotl64(M[2 * blk + 1], 33) * kC1;   // rest of mix_k2
+    if (blk < nblocks) {
+      h1 ^= k1;
+      h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+      h2 ^= k2;
+      h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    } else if (blk == nblocks) {
+      if (tail > 8) h2 ^= k2;
+      if (tail > 0) h1 ^= k1;
     }
   }
   return mm3_finish(h1, h2, (uint64_t)K);
@@ -193,14 +205,21 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
   const int top_limb = (2 * K - 2) >> 5, top_sh = (2 * K - 2) & 31;
   const bool multi = b.starts != nullptr;
 
-  // 4 two-bit digits -> 4 ASCII bytes, digit d -> "ACGT"[d], first digit in the low byte
-  for (int e = tid; e < kLutDwords; e += THREADS) {
-    uint32_t idx = (uint32_t)e >> 4, v = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
-    lut[e] = v;
+  // product tables (see kLutEntries): entry e of replica r at u64 index e * kLutReplicas + r.
+  // digit d -> "ACGT"[d], first digit in the low byte; the partial group holds the k-mer's last
+  // K mod 4 letters (its multiplier follows the parity of the word it belongs to)
+  const int g_last = (K - 1) >> 2, nb_last = K - 4 * g_last;      // nb_last == 4: no partial group
+  const uint64_t c_last = ((g_last >> 1) & 1) ? kC2 : kC1;
+  uint64_t* ptab = reinterpret_cast<uint64_t*>(lut);
+  for (int e = tid; e < kLutEntries * kLutReplicas; e += THREADS) {
+    const uint32_t ent = (uint32_t)e / kLutReplicas;
+    const uint32_t idx = ent & 255u;
+    const int nb = ent < 512 ? 4 : nb_last;
+    uint32_t v = 0;
+    for (int j = 0; j < nb; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
+    ptab[e] = (uint64_t)v * (ent < 256 ? kC1 : (ent < 512 ? kC2 : c_last));
   }
-  const uint32_t lut_lane = (uint32_t)(tid & (kLutReplicas - 1)) << 2;  // byte offset of my replica
+  const uint32_t lut_lane = (uint32_t)(tid & (kLutReplicas - 1)) << 3;  // byte offset of my replica
   if (tid == 0) st_ctl[0] = 0;
 
   const uint64_t span = hp.range_hi - hp.range_lo;
@@ -321,21 +340,23 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
           uint64_t h[HB];
 #pragma unroll
           for (int q = 0; q < HB; q++) {
-            uint32_t D[4 * L];
+            uint64_t M[2 * L];
+#pragma unroll
+            for (int wi = 0; wi < 2 * L; wi++) M[wi] = 0;
 #pragma unroll
             for (int g = 0; g < 4 * L; g++) {
               if (4 * g < K) {
-                const uint32_t idx = (X[q][g >> 2] >> (8 * (g & 3))) & 0xffu;
-                uint32_t w = *reinterpret_cast<const uint32_t*>(
-                    reinterpret_cast<const char*>(lut) + ((idx << 6) | lut_lane));
-                const int nb = K - 4 * g;  // bytes of this dword that belong to the k-mer
-                if (nb < 4) w &= (1u << (8 * nb)) - 1u;
-                D[g] = w;
-              } else {
-                D[g] = 0;
+                uint32_t idx = (X[q][g >> 2] >> (8 * (g & 3))) & 0xffu;
+                const int nb = K - 4 * g;                       // letters of this group that belong to the k-mer
+                uint32_t ent;                                    // table entry: P1 / P2 by word parity, or the partial table
+                if (nb >= 4) ent = (((g >> 1) & 1) ? 256u : 0u) + idx;
+                else ent = 512u + (idx & ((1u << (2 * nb)) - 1u));
+                const char* at = reinterpret_cast<const char*>(lut) + ((ent * (kLutReplicas * 8)) | lut_lane);
+                if ((g & 1) == 0) M[g >> 1] = *reinterpret_cast<const uint64_t*>(at);                       // low half: full product
+                else M[g >> 1] += (uint64_t)(*reinterpret_cast<const uint32_t*>(at)) << 32;                // high half: low dword only
               }
             }
-            h[q] = murmur_kmer<L>(D, K, hp.seed);
+            h[q] = murmur_kmer_pre<L>(M, K, hp.seed);
           }
 #pragma unroll
           for (int q = 0; q < HB; q++)
