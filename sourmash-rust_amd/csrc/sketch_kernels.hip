@@ -805,7 +805,7 @@ inline int grid_for(uint64_t items, int per_block, int cap) {
 struct DnaCfg { int threads, logR, hb; };
 static DnaCfg dna_cfg() {
   static DnaCfg cfg = [] {
-    DnaCfg c{512, 6, 2};
+    DnaCfg c{512, 7, 2};
     if (const char* e = std::getenv("SOURMASH_AMD_DNA_CFG")) {
       int t = 0, r = 0, h = 0;
       if (sscanf(e, "%d,%d,%d", &t, &r, &h) == 3 && (t == 256 || t == 512) && r >= 5 && r <= 7 &&
@@ -837,7 +837,7 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
   if (p.ksize >= 1 && p.ksize <= 128 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
-    const DnaCfg c = p.thr_rec ? DnaCfg{512, 6, 2} : dna_cfg();   // the per-record variant exists in one geometry
+    const DnaCfg c = p.thr_rec ? DnaCfg{512, 7, 2} : dna_cfg();   // the per-record variant exists in one geometry
     int logR = c.logR;
     while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * c.threads * 2) logR--;
     const uint64_t tile = (uint64_t)c.threads << logR;
