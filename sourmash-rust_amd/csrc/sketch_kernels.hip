@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <=
 // needs only the low dword of the entry), plus one small table for the k-mer's last, partial group
 // of letters.  This replaces the digit -> ASCII table AND a third of the 64-bit multiplies.
 constexpr int kLutReplicas = 2;                              // lane l uses replica l & 1 (1, 2: 37.8 ms; 4, 8: 39.7; 16: 50.5 -- LDS size, not bank conflicts, is what matters)
-constexpr int kLutEntries = 256 + 256 + 64;                  // P1, P2, partial group
+constexpr int kLutEntries = 256 + 256 + 64 + 1;              // P1, P2, partial group, one zero entry (groups past the k-mer)
 constexpr int kLutDwords = kLutEntries * kLutReplicas * 2;   // u64 entries: 9 KiB
 
 // murmur64 from premultiplied words: M[w] = word_w * (w even ? c1 : c2)
@@ -214,10 +214,22 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
   for (int e = tid; e < kLutEntries * kLutReplicas; e += THREADS) {
     const uint32_t ent = (uint32_t)e / kLutReplicas;
     const uint32_t idx = ent & 255u;
-    const int nb = ent < 512 ? 4 : nb_last;
+    const int nb = ent < 512 ? 4 : (ent < 576 ? nb_last : 0);
     uint32_t v = 0;
     for (int j = 0; j < nb; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
     ptab[e] = (uint64_t)v * (ent < 256 ? kC1 : (ent < 512 ? kC2 : c_last));
+  }
+  // run-time k: table base and digit mask of every 4-letter group, fixed for the launch, so that
+  // the per-k-mer code below is the same straight line as for a compile-time k
+  uint32_t gbase[4 * L], gmask[4 * L];
+#pragma unroll
+  for (int g = 0; g < 4 * L; g++) {
+    const int nb = K - 4 * g;
+    uint32_t ent0 = 576u, mask = 0u;                                   // past the k-mer: the zero entry
+    if (nb >= 4) { ent0 = ((g >> 1) & 1) ? 256u : 0u; mask = 0xffu; }
+    else if (nb > 0) { ent0 = 512u; mask = (1u << (2 * nb)) - 1u; }
+    gbase[g] = ent0 * (kLutReplicas * 8);
+    gmask[g] = mask;
   }
   const uint32_t lut_lane = (uint32_t)(tid & (kLutReplicas - 1)) << 3;  // byte offset of my replica
   if (tid == 0) st_ctl[0] = 0;
@@ -345,13 +357,10 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
             for (int wi = 0; wi < 2 * L; wi++) M[wi] = 0;
 #pragma unroll
             for (int g = 0; g < 4 * L; g++) {
-              if (4 * g < K) {
-                uint32_t idx = (X[q][g >> 2] >> (8 * (g & 3))) & 0xffu;
-                const int nb = K - 4 * g;                       // letters of this group that belong to the k-mer
-                uint32_t ent;                                    // table entry: P1 / P2 by word parity, or the partial table
-                if (nb >= 4) ent = (((g >> 1) & 1) ? 256u : 0u) + idx;
-                else ent = 512u + (idx & ((1u << (2 * nb)) - 1u));
-                const char* at = reinterpret_cast<const char*>(lut) + ((ent * (kLutReplicas * 8)) | lut_lane);
+              if (KT == 0 || 4 * g < K) {
+                const uint32_t idx = (X[q][g >> 2] >> (8 * (g & 3))) & gmask[g];   // digits of this group that belong to the k-mer
+                // table entry: P1 / P2 by word parity, the partial table, or (run-time k only) the zero entry
+                const char* at = reinterpret_cast<const char*>(lut) + ((gbase[g] + idx * (kLutReplicas * 8)) | lut_lane);
                 if ((g & 1) == 0) M[g >> 1] = *reinterpret_cast<const uint64_t*>(at);                       // low half: full product
                 else M[g >> 1] += (uint64_t)(*reinterpret_cast<const uint32_t*>(at)) << 32;                // high half: low dword only
               }
