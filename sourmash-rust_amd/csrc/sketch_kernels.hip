@@ -6,8 +6,9 @@
 //                      and staged in LDS; each lane rolls two 2-bit packed windows (forward in
 //                      big- and little-endian digit order; the reverse complement is their
 //                      bitwise complement), picks the canonical strand with one 64-bit compare,
-//                      expands it to the ASCII bytes murmur needs through a bank-replicated LDS
-//                      table and runs MurmurHash3 x64_128 (first word) in registers.
+//                      takes the first multiply of every murmur word from LDS product tables
+//                      indexed by the 2-bit digits (the ASCII bytes are never formed) and runs the
+//                      rest of MurmurHash3 x64_128 (first word) in registers.
 //                      replaces: src/lib.rs:260-267 (+ revcomp 677-689, _checkdna 795-804,
 //                      _hash_murmur 33-35) and the `hash <= max_hash` filter of add_hash 198.
 //   k_dna_generic      same contract for any ksize, one lane per k-mer, byte-wise.
@@ -175,14 +176,14 @@ __device__ __forceinline__ uint64_t murmur_kmer_pre(const uint64_t (&M)[2 * L], 
 
 // KT > 0: ksize fixed at compile time; KT == 0: any ksize the limb count allows, at run time.
 // L = 32-bit limbs of a packed window: 2 for ksize <= 32, 4 for ksize <= 64, 8 for ksize <= 128.
-// THREADS lanes per workgroup share one LUT; HB = hashes computed together in one straight-line
+// THREADS lanes per workgroup share the product tables; HB = hashes computed together in one straight-line
 // block (independent murmur chains the scheduler can interleave).
 // PR: thresholds are looked up per record (hp.thr_rec; grouped bottom-num batches) instead of the
 // launch-uniform hp.thr
 template <int KT, int THREADS, int HB, int L, bool PR = false>
 __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
                                                          int logR, uint32_t stage_cap) {
-  // LDS: [LUT 16 KiB][staged candidates: count, hashes, positions][sequence tile]
+  // LDS: [product tables 9 KiB][staged candidates: count, hashes, positions][sequence tile]
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* lut = smem;
   uint32_t* st_ctl = smem + kLutDwords;                       // [0] = count, [2..3] = flush base
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     const uintptr_t ga = g0 & ~(uintptr_t)15;
     const uint32_t m = (uint32_t)(g0 - ga);
     const uint32_t nchunks = (m + (uint32_t)TILE + 16 * L + 8 + 15) >> 4;  // last lane reads < m+TILE+K+7
-    __syncthreads();  // LUT ready / previous tile fully consumed
+    __syncthreads();  // tables ready / previous tile fully consumed
     for (uint32_t c = tid; c < nchunks; c += THREADS) {
       uintptr_t addr = ga + ((uintptr_t)c << 4);
       uint4 v = make_uint4(0, 0, 0, 0);
