@@ -57,6 +57,21 @@ def test_compute_fails_loudly_without_gpu(pkg):
         pkg.hash_murmur(b"ACG")
     with pytest.raises(pkg.SourmashError):
         mh.compare(pkg.KmerMinHash(20, 10))
+    # the additive entry points too: batch, grouped, block compare, resident index -- error code 2, no crash,
+    # and nothing applied to the sketches
+    a, b = pkg.KmerMinHash(0, 21, False, 42, 1 << 60), pkg.KmerMinHash(0, 21, False, 42, 1 << 60)
+    for h in (7, 11, 13):
+        a.add_hash(h); b.add_hash(h + 1)
+    for call in (lambda: a.add_sequences([b"ACGT" * 20, b"TTGCA" * 10], True),
+                 lambda: pkg.KmerMinHash.add_sequences_grouped([a, b], [b"ACGT" * 20, b"TTGCA" * 10], [0, 1], True),
+                 lambda: pkg.matrix.compare_block([a, b], [a, b]),
+                 lambda: pkg.index.ResidentIndex([a, b]),
+                 lambda: pkg.index.search_minhashes([a, b], a, 0.1),
+                 lambda: a.count_common(b)):
+        with pytest.raises(pkg.SourmashError) as ei:
+            call()
+        assert ei.value.code == 2
+    assert a.mins == [7, 11, 13] and b.mins == [8, 12, 14]
 
 
 def test_product_does_not_reference_the_oracle():
