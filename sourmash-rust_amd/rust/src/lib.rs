@@ -46,6 +46,22 @@ extern "C" {
         rows: *const *mut RawKmerMinHash, n_rows: u32, cols: *const *mut RawKmerMinHash, n_cols: u32,
         jaccard: *mut f64, common: *mut u64, size: *mut u64, count_common: *mut u64, containment: *mut f64,
     ) -> i32;
+    pub fn smh_add_sequences_grouped(
+        sketches: *const *mut RawKmerMinHash, n_sketches: u32, seq: *const c_char, offsets: *const u64,
+        groups: *const u32, n_records: u32, force: bool,
+    ) -> i32;
+    pub fn smh_index_new(nodes: *const *mut RawKmerMinHash, n_nodes: u32) -> *mut RawIndex;
+    pub fn smh_index_free(index: *mut RawIndex);
+    pub fn smh_index_len(index: *const RawIndex) -> u32;
+    pub fn smh_index_find(
+        index: *mut RawIndex, query: *const RawKmerMinHash, threshold: f64, containment: bool,
+        out_indices: *mut u32, out_count: *mut u32,
+    ) -> i32;
+}
+
+#[repr(C)]
+pub struct RawIndex {
+    _private: [u8; 0],
 }
 
 extern "C" {
@@ -205,4 +221,72 @@ pub fn compare_matrix(rows: &[KmerMinHash], cols: &[KmerMinHash]) -> Result<Vec<
         return Err(take_error());
     }
     Ok(out)
+}
+
+/// One signature per group of records (one genome = its contigs) in ONE device pass: the loop
+/// `for file in files { let mut mh = template.clone(); for rec in file { mh.add_sequence(rec) } }`
+/// of the reference's callers.  `groups[r]` is the sketch that record `r` feeds.
+pub fn sketch_groups(sketches: &mut [KmerMinHash], records: &[&[u8]], groups: &[u32], force: bool) -> Result<(), SourmashError> {
+    assert_eq!(records.len(), groups.len());
+    let mut flat = Vec::new();
+    let mut off = vec![0u64];
+    for r in records {
+        flat.extend_from_slice(r);
+        off.push(flat.len() as u64);
+    }
+    let hs: Vec<Handle> = sketches.iter().map(|m| m.to_handle()).collect();
+    let hp: Vec<*mut RawKmerMinHash> = hs.iter().map(|h| h.0).collect();
+    let rc = unsafe {
+        smh_add_sequences_grouped(hp.as_ptr(), hp.len() as u32, flat.as_ptr() as *const c_char, off.as_ptr(),
+                                  groups.as_ptr(), records.len() as u32, force)
+    };
+    for (m, h) in sketches.iter_mut().zip(hs.iter()) {
+        m.read_back(h);
+    }
+    if rc != 0 {
+        return Err(take_error());
+    }
+    Ok(())
+}
+
+/// `LinearIndex` (reference `src/index/linear.rs`) whose leaves live in HBM: `find` uploads only
+/// the query.  Built once from the leaves' sketches; `search_fn` of the reference becomes the
+/// `containment` flag (similarity vs containment, `src/index/search.rs`).
+pub struct ResidentIndex {
+    raw: *mut RawIndex,
+    _leaves: Vec<Handle>,
+}
+
+impl ResidentIndex {
+    pub fn new(leaves: &[KmerMinHash]) -> Result<ResidentIndex, SourmashError> {
+        let hs: Vec<Handle> = leaves.iter().map(|m| m.to_handle()).collect();
+        let hp: Vec<*mut RawKmerMinHash> = hs.iter().map(|h| h.0).collect();
+        let raw = unsafe { smh_index_new(hp.as_ptr(), hp.len() as u32) };
+        if raw.is_null() {
+            return Err(take_error());
+        }
+        Ok(ResidentIndex { raw, _leaves: hs })
+    }
+
+    pub fn len(&self) -> usize {
+        unsafe { smh_index_len(self.raw) as usize }
+    }
+
+    /// Positions of the leaves with similarity (or containment) above `threshold`, ascending.
+    pub fn find(&self, query: &KmerMinHash, threshold: f64, containment: bool) -> Result<Vec<usize>, SourmashError> {
+        let q = query.to_handle();
+        let mut out = vec![0u32; self.len().max(1)];
+        let mut n = 0u32;
+        let rc = unsafe { smh_index_find(self.raw, q.0, threshold, containment, out.as_mut_ptr(), &mut n) };
+        if rc != 0 {
+            return Err(take_error());
+        }
+        Ok(out[..n as usize].iter().map(|&i| i as usize).collect())
+    }
+}
+
+impl Drop for ResidentIndex {
+    fn drop(&mut self) {
+        unsafe { smh_index_free(self.raw) }
+    }
 }
