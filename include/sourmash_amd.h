@@ -54,6 +54,10 @@ int smh_add_sequences_grouped_dev(KmerMinHash *const *sketches, uint32_t n_sketc
 /* add_hash over an array (reference src/lib.rs:412-417 add_many) */
 int smh_add_many(KmerMinHash *ptr, const uint64_t *hashes, uint64_t n);
 
+/* KmerMinHash::add_many_with_abund (reference src/lib.rs:419-426; Rust API only, the reference header
+ * has no symbol for it): item i is the pair (hashes[i], abunds[i]) and is added abunds[i] times. */
+int smh_add_many_with_abund(KmerMinHash *ptr, const uint64_t *hashes, const uint64_t *abunds, uint64_t n);
+
 /* murmur64 of n byte strings (offsets: n+1 host entries) on the device
  * (reference src/lib.rs:33-35 _hash_murmur) */
 int smh_hash_words(const char *bytes, const uint64_t *offsets, uint32_t n, uint64_t seed,

@@ -41,6 +41,7 @@ def lib():
     L.omh_add_word.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.omh_add_sequence.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
     L.omh_add_many.argtypes = [C.c_void_p, u64p, C.c_size_t]
+    L.omh_add_many_with_abund.argtypes = [C.c_void_p, u64p, u64p, C.c_size_t]
     L.omh_add_from.argtypes = [C.c_void_p, C.c_void_p]
     L.omh_merge.argtypes = [C.c_void_p, C.c_void_p]
     L.omh_count_common.argtypes = [C.c_void_p, C.c_void_p, u64p]
@@ -118,6 +119,13 @@ class MinHash:
         import numpy as np
         a = np.ascontiguousarray(hashes, dtype=np.uint64)
         self._chk(self._L.omh_add_many(self._p, a.ctypes.data_as(u64p), a.size))
+
+    def add_many_with_abund(self, items):
+        import numpy as np
+        items = list(items)
+        h = np.ascontiguousarray([i[0] for i in items], dtype=np.uint64)
+        a = np.ascontiguousarray([i[1] for i in items], dtype=np.uint64)
+        self._chk(self._L.omh_add_many_with_abund(self._p, h.ctypes.data_as(u64p), a.ctypes.data_as(u64p), h.size))
 
     def add_sequence(self, seq, force=False):
         seq = bytes(seq)

@@ -190,6 +190,12 @@ class MinHash:
         for h in hashes:
             self.add_hash(h)
 
+    def add_many_with_abund(self, items):
+        # src/lib.rs:419-426
+        for h, n in items:
+            for _ in range(n):
+                self.add_hash(h)
+
     def add_sequence(self, seq, force=False):
         s = bytes(seq).translate(_UPPER)
         k = self.ksize

@@ -352,6 +352,15 @@ int omh_add_many(omh_t *mh, const uint64_t *hashes, size_t n) {
   }
   return OMH_OK;
 }
+/* src/lib.rs:419-426 add_many_with_abund: item.0 added item.1 times, literally */
+int omh_add_many_with_abund(omh_t *mh, const uint64_t *hashes, const uint64_t *abunds, size_t n) {
+  for (size_t i = 0; i < n; i++)
+    for (uint64_t r = 0; r < abunds[i]; r++) {
+      int st = omh_add_hash(mh, hashes[i]);
+      if (st != OMH_OK) return st;
+    }
+  return OMH_OK;
+}
 int omh_add_from(omh_t *mh, const omh_t *other) {
   return omh_add_many(mh, other->mins, other->n);
 }

@@ -58,6 +58,7 @@ int omh_add_word(omh_t *mh, const uint8_t *word, size_t len);
 int omh_add_sequence(omh_t *mh, const uint8_t *seq, size_t len, int force,
                      char *errbuf, size_t errcap);
 int omh_add_many(omh_t *mh, const uint64_t *hashes, size_t n);
+int omh_add_many_with_abund(omh_t *mh, const uint64_t *hashes, const uint64_t *abunds, size_t n);
 int omh_add_from(omh_t *mh, const omh_t *other);
 int omh_merge(omh_t *mh, const omh_t *other);
 int omh_count_common(const omh_t *a, const omh_t *b, uint64_t *out);

@@ -466,6 +466,14 @@ int smh_add_many(KmerMinHash* ptr, const uint64_t* hashes, uint64_t n) {
   return pad_code([&] { require(ptr, "ptr"); if (n) require(hashes, "hashes"); ptr->materialize(); ptr->add_many(hashes, n); });
 }
 
+int smh_add_many_with_abund(KmerMinHash* ptr, const uint64_t* hashes, const uint64_t* abunds, uint64_t n) {
+  return pad_code([&] {
+    require(ptr, "ptr");
+    if (n) { require(hashes, "hashes"); require(abunds, "abunds"); }
+    ptr->add_many_with_abund(hashes, abunds, n);
+  });
+}
+
 int smh_hash_words(const char* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out) {
   return pad_code([&] {
     require(offsets, "offsets"); require(out, "out");

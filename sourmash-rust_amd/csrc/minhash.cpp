@@ -167,6 +167,31 @@ void KmerMinHash::add_from(const KmerMinHash& other) {
   other.materialize();
   for (uint64_t h : other.mins) add_hash(h);
 }
+// reference src/lib.rs:419-426: `for item in hashes { for _ in 0..item.1 { self.add_hash(item.0) } }`.
+// After the first add_hash of an item the sketch either holds the hash or is unchanged, and every
+// further add_hash of the same value meets the same state (only one abundance moves), so the inner
+// loop's repeats 2..count collapse into one more add_hash plus an O(1) bump of the slot it hit --
+// same result, panics included, without looping over an abundance of millions.
+void KmerMinHash::add_many_with_abund(const uint64_t* hashes, const uint64_t* counts, size_t n) {
+  materialize();
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t h = hashes[i], c = counts[i];
+    if (c == 0) continue;
+    add_hash(h);
+    if (c == 1) continue;
+    if (!has_abunds) {
+      // untracked: a repeat can still change nothing but is evaluated once for its panics
+      add_hash(h);
+      continue;
+    }
+    const size_t pos = std::lower_bound(mins.begin(), mins.end(), h) - mins.begin();
+    const uint64_t before = (pos < mins.size() && mins[pos] == h && pos < abunds.size()) ? abunds[pos] : 0;
+    add_hash(h);                                  // repeat no. 2 (may panic exactly like the reference)
+    const bool bumped = pos < mins.size() && mins[pos] == h && pos < abunds.size() && abunds[pos] == before + 1;
+    if (bumped) abunds[pos] += c - 2;             // repeats 3..c hit the same slot
+  }
+}
+
 void KmerMinHash::add_many(const uint64_t* hashes, size_t n) {
   // a handful of hashes: the reference's loop.  A bulk array: same result through the device fold
   // (filter + sort + distinct + count), which does not degrade quadratically like Vec::insert.

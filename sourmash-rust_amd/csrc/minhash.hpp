@@ -85,6 +85,7 @@ struct KmerMinHash {
   void add_from(const KmerMinHash& other);                               // 405-410
   void add_many(const uint64_t* hashes, size_t n);                       // 412-417
   void add_many_bulk(const uint64_t* hashes, size_t n);                  // same, through the device fold
+  void add_many_with_abund(const uint64_t* hashes, const uint64_t* counts, size_t n);  // 419-426 ((hash, count) pairs)
   bool merge_on_device(const KmerMinHash& other);                        // large well-formed merges
   uint64_t count_common(const KmerMinHash& other) const;                 // 428-436 (device)
   void intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const;  // 470-499

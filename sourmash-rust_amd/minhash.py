@@ -89,6 +89,13 @@ class KmerMinHash:
         a = np.ascontiguousarray(hashes, dtype=np.uint64)
         call(self._L.smh_add_many, self._p, a.ctypes.data_as(u64p), a.size)
 
+    def add_many_with_abund(self, items):
+        """reference src/lib.rs:419-426: items = [(hash, abundance), ...]; each hash is added abundance times."""
+        items = list(items)
+        h = np.ascontiguousarray([i[0] for i in items], dtype=np.uint64)
+        a = np.ascontiguousarray([i[1] for i in items], dtype=np.uint64)
+        call(self._L.smh_add_many_with_abund, self._p, h.ctypes.data_as(u64p), a.ctypes.data_as(u64p), h.size)
+
     def add_sequence(self, seq, force=False):
         seq = bytes(seq)
         if b"\0" in seq:

@@ -212,6 +212,40 @@ def test_protein_dropped_codons(pkg, coracle):
             same_state(g, o)
 
 
+def test_protein_arm_pinned_to_reference_codontable(pkg, coracle):
+    """The device's translation against DATA of the reference: tests/golden/codontable.json holds the
+    64 pairs of the CODONTABLE literal (reference src/lib.rs:691-777) and the six-frame order of
+    src/lib.rs:280-300 (tests/golden/make_codontable.py).  Expected sketches are built here from that
+    table alone; only the hash of a residue window and add_hash come from the oracle, and both of
+    those are pinned by reference KATs (tests/test_oracle_kat.py)."""
+    from test_codontable import revcomp, table_windows
+    with open(os.path.join(GOLDEN, "codontable.json")) as fh:
+        doc = json.load(fh)
+    # (1) every codon on its own: "XYZ" -> forward frame 0 gives table[XYZ], reverse frame 0 gives
+    # table[revcomp(XYZ)], frames 1 and 2 are incomplete.  ksize 3 = windows of one residue.
+    for codon, aa in sorted(doc["table"].items()):
+        g = pkg.KmerMinHash(0, 3, True, 42, (1 << 64) - 1, True)
+        g.add_sequence(codon.encode(), True)
+        exp = {}
+        for r in (aa, doc["table"][revcomp(codon.encode()).decode()]):
+            h = coracle.hash_murmur(r.encode(), 42)
+            exp[h] = exp.get(h, 0) + 1
+        assert dict(zip(g.mins, g.abunds)) == exp, codon
+    # (2) all 64 codons in one record, all six frames, every ksize/3 in 1..4, lower case included
+    allc = "".join(sorted(doc["table"])).encode()
+    rng = random.Random(77)
+    for seq in (allc, allc.lower(), bytes(rng.choice(b"ACGT") for _ in range(5000)),
+                bytes(rng.choice(b"ACGTN") for _ in range(3001))):
+        for ksize in (3, 6, 9, 12, 27):
+            for num, mx in ((0, (1 << 64) - 1), (25, 0)):      # scaled: total counts; num + abundance: order matters (Q3)
+                g = pkg.KmerMinHash(num, ksize, True, 42, mx, True)
+                o = coracle.MinHash(num, ksize, True, 42, mx, True)
+                g.add_sequence(seq, True)
+                for w in table_windows(doc, seq, ksize):
+                    o.add_word(w)
+                same_state(g, o)
+
+
 def test_many_records_per_launch(pkg, coracle):
     rng = random.Random(13)
     recs = [rand_seq(rng, rng.choice([0, 5, 30, 31, 32, 100, 151, 151, 151, 2000]), bad=rng.choice([0, 0, 0.01]))

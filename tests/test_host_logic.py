@@ -35,6 +35,38 @@ def test_add_hash_matches_oracle(pkg, coracle, num, mx, track):
     same_state(g, o)
 
 
+@pytest.mark.parametrize("num,mx,track", [(5, 0, True), (20, 0, False), (0, 1 << 62, True), (0, 0, True),
+                                          (4, 1 << 62, True), (1, 0, True), (3, 0, True)])
+def test_add_many_with_abund_matches_oracles(pkg, coracle, pyoracle, num, mx, track):
+    """reference src/lib.rs:419-426: (hash, count) pairs, each hash added count times.  The product
+    collapses the repeats (O(1) per item); both oracles loop literally.  Q3 (an occurrence equal to
+    the current largest min of a full sketch is not counted) makes the repeats matter."""
+    rng = random.Random(num * 11 + track + (mx & 7))
+    universe = [rng.getrandbits(63) for _ in range(30)]
+    g = pkg.KmerMinHash(num, 21, False, 42, mx, track)
+    o = coracle.MinHash(num, 21, False, 42, mx, track)
+    p = pyoracle.MinHash(num, 21, False, 42, mx, track)
+    for round_ in range(6):
+        items = [(rng.choice(universe), rng.choice([0, 1, 1, 2, 3, 7, 40])) for _ in range(rng.randint(0, 25))]
+        g.add_many_with_abund(items); o.add_many_with_abund(items); p.add_many_with_abund(items)
+        same_state(g, o)
+        assert g.mins == p.mins and g.abunds == p.abunds
+    # a count far too large to loop over
+    g.add_many_with_abund([(universe[0], 10 ** 12)])
+    before = dict(zip(o.mins, o.abunds or []))
+    o.add_many_with_abund([(universe[0], 3)])
+    after = dict(zip(o.mins, o.abunds or []))
+    assert g.mins == o.mins
+    if track and universe[0] in after:
+        step = (after[universe[0]] - before.get(universe[0], 0))      # 3 literal repeats moved it by `step`
+        exp = dict(after)
+        if step == 3:
+            exp[universe[0]] = before.get(universe[0], 0) + 10 ** 12
+        elif step == 1:                                                # inserted once, repeats not counted (Q3)
+            exp[universe[0]] = after[universe[0]]
+        assert dict(zip(g.mins, g.abunds)) == exp
+
+
 def test_merge_matches_oracle_including_quirks(pkg, coracle):
     rng = random.Random(4)
     for trial in range(60):
