@@ -9,21 +9,28 @@ metric = k-mers hashed per second, whole job (all ranks).  Records are sharded a
 (weak scaling: 10 GB per GPU); there is no data-path collective in the sketch step.
 
 Secondary (configs[2]/[3], reported in the same JSON line under "compare"): all-vs-all Jaccard
-matrix of num=2000 signatures, rows sharded across ranks with one RCCL all-gather of the signatures.
+matrix of num=2000 signatures, rows sharded across ranks with one RCCL all-gather of the
+signatures -- on the family-structured collection of SURVEY.md 8d AND on the same collection with
+one hash shared by every signature (a contaminant k-mer: one connected component, every tile of
+the matrix has to be walked), each next to the C oracle on the host cores.
 
 Also on the line: "roofline" for the dominant kernel (k_dna_rolling) from HIP events recorded by the
 library on the stream it launches on, and "cpu_baseline": the C oracle (a port of the reference's
-algorithm; the reference is Rust and cannot be built here) timed on one host core over a bounded
-sample of the same workload.
+algorithm; the reference is Rust and cannot be built here) timed on ONE host core and on all of
+them (count printed) over bounded samples of the same workloads, results checked equal to the GPU's.
 
-Launch: python bench.py --gpus 1 --steps K --warmup W
+Launch: python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks)
    or:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,19 +41,130 @@ sys.path.insert(0, ROOT)
 K = 31
 MAX_HASH = 18446744073709552       # round((2^64-1)/1000): scaled=1000
 REC_LEN = 1_000_000
+NUM = 2000                         # signature size of the compare matrix (configs[2], [3])
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 256 * 4                    # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
+VALU_CYCLES = 2.0                  # ... a wave64 VALU instruction issues over 2 cycles
+MAX_CLOCK_HZ = 2.4e9               # ... max clock
+CONTAMINANT = 1                    # the hash every signature of the one-component collection shares
+
+
+def host_cores():
+    """Cores this process may use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+# --------------------------------------------------------------------------------------------
+# CPU-baseline workers: separate processes (started as children; they never touch the GPU) that
+# run the C oracle over their share of the sample and leave the result where the parent can check
+# it against the GPU's.  `python bench.py --cpu-worker <kind> ...`
+def cpu_worker(argv):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import coracle
+    kind, out_path = argv[0], argv[1]
+    if kind == "sketch":
+        first, last, budget = int(argv[2]), int(argv[3]), float(argv[4])
+        o = coracle.MinHash(0, K, False, 42, MAX_HASH, False)
+        done, spent = 0, 0.0
+        for r in range(first, last):
+            rec = bytes(coracle.synth_dna(r * REC_LEN, REC_LEN, 2, 0))      # input generation is NOT timed
+            t0 = time.perf_counter()
+            o.add_sequence(rec, True)
+            spent += time.perf_counter() - t0
+            done += 1
+            if spent >= budget:
+                break
+        np.save(out_path, o.mins_np())
+        print(json.dumps({"records": done, "seconds": spent}))
+    elif kind == "config0":
+        # BASELINE configs[0]: 1 MB, k=31, num=500, compare to itself (reference tests/minhash.rs path)
+        rec = bytes(coracle.synth_dna(0, REC_LEN, 1, 0))
+        o = coracle.MinHash(500, K, False, 42, 0, False)
+        t0 = time.perf_counter()
+        o.add_sequence(rec, False)
+        t1 = time.perf_counter()
+        reps = 200
+        for _ in range(reps):
+            j = o.compare(o)
+        t2 = time.perf_counter()
+        np.save(out_path, o.mins_np())
+        print(json.dumps({"sketch_seconds": t1 - t0, "kmers": REC_LEN - K + 1, "compare_seconds": (t2 - t1) / reps,
+                          "self_compare": j}))
+    elif kind == "compare":
+        n_sig, first, last, budget, contaminated = int(argv[2]), int(argv[3]), int(argv[4]), float(argv[5]), int(argv[6])
+        from __graft_entry__ import load_package
+        load_package()
+        from sourmash_rust_amd import synth
+        sigs = synth.family_signatures(0, n_sig, num=NUM, seed=3)
+        if contaminated:
+            sigs[:, 0] = CONTAMINANT
+        cols = [sigs[i] for i in range(n_sig)]
+        rows_done, spent, jac = 0, 0.0, []
+        for r in range(first, last):
+            t0 = time.perf_counter()
+            _, _, j = coracle.compare_matrix([sigs[r]], cols, NUM, K, 0)
+            spent += time.perf_counter() - t0
+            jac.append(j[0])
+            rows_done += 1
+            if spent >= budget:
+                break
+        np.save(out_path, np.stack(jac) if jac else np.zeros((0, n_sig)))
+        print(json.dumps({"rows": rows_done, "seconds": spent}))
+    else:
+        raise SystemExit("unknown worker kind " + kind)
+
+
+def run_workers(specs):
+    """specs: list of argv lists.  Starts them all at once, returns [(parsed json, output path)]."""
+    tmp = tempfile.mkdtemp(prefix="smh_cpu_")
+    procs = []
+    for i, spec in enumerate(specs):
+        out = os.path.join(tmp, "w%d.npy" % i)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", spec[0], out] + [str(x) for x in spec[1:]]
+        procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True), out))
+    res = []
+    for p, out in procs:
+        stdout, _ = p.communicate(timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError("cpu worker failed: " + stdout[-500:])
+        res.append((json.loads(stdout.strip().splitlines()[-1]), out))
+    return res
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks as fresh child
+    processes (this process has not touched the GPU), relay their output, exit with their code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + argv
+    return subprocess.call(cmd, cwd=ROOT)
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gb", type=float, default=10.0, help="GB of DNA per GPU (BASELINE config: 10)")
     ap.add_argument("--compare-n", type=int, default=0, help="signatures in the matrix (0 = by --gpus)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-core sketch sample (others scale with it)")
     ap.add_argument("--no-compare", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -60,6 +178,8 @@ def main():
     if os.environ.get("BENCH_SHARE_GPU") == "1":
         local = 0
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         if backend == "nccl":
@@ -77,6 +197,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # ---------------------------------------------------------------- input: resident in HBM
     n_rec = max(1, int(round(args.gb * 1e9 / REC_LEN)))
@@ -110,10 +236,7 @@ def main():
     to_host_ms = (time.perf_counter() - t1) * 1e3
     assert host_mins.size == retained and bool((host_mins[1:] > host_mins[:-1]).all())
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(dt)
     value = world * kmers_per_step * args.steps / dt
 
     ms, launches = C.c_double(), C.c_uint64()
@@ -123,89 +246,146 @@ def main():
     # algorithmic bytes per launch: 1 B read per k-mer position + 8 B per retained hash
     bytes_per_launch = (total + 8.0 * retained) / max(1.0, launches_per_step)
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, gfx950 x2
-    # correction on FETCH_SIZE): measured on exactly this workload, kept under profiles/
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dna_rolling.json")))
+    kmers_per_launch = kmers_per_step / max(1.0, launches_per_step)
+    # Counter-derived figures come from the committed rocprofv3 --pmc passes of exactly this workload
+    # (profiles/), NOT from this run: HBM bytes per launch (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and
+    # VALU wave-instructions per 64 k-mers (SQ_INSTS_VALU / wave steps).
+    traffic, traffic_src, valu = None, None, None
+    for name in ("r02_pmc_dna_rolling.json", "r01_pmc_dna_rolling.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
         if abs(total - 10e9) < 1 and launches_per_step == 1.0:
-            traffic = pmc["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    # ceiling of any k=31 hashing kernel on this chip: bare murmur64 with operands in registers
-    # (tools/microbench.hip, profiles/r01_microbench_int_ops.txt)
-    MURMUR_CEILING = 361.4e9
+            traffic = pmc.get("hbm_bytes_per_launch")
+            valu = pmc.get("valu_insts_per_64_kmers")
+            traffic_src = "profiles/%s: separate rocprofv3 --pmc passes of this command, committed; not measured in this run" % name
+        break
+    valu_bound = None
+    if valu and kern_ms > 0:
+        floor_ms = kmers_per_launch / 64.0 * valu * VALU_CYCLES / (SIMDS * MAX_CLOCK_HZ) * 1e3
+        valu_bound = {"valu_insts_per_64_kmers": valu, "cycles_per_wave_inst": VALU_CYCLES, "simds": SIMDS,
+                      "clock_hz": MAX_CLOCK_HZ, "floor_ms": floor_ms, "frac": floor_ms / kern_ms,
+                      "kernel_kmers_per_s": kmers_per_launch / (kern_ms * 1e-3),
+                      "label": "VALU issue floor from MI355X_MICROARCH.md (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz) "
+                               "for the kernel's measured instruction count; frac = floor / measured kernel time"}
 
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
+    sigs_host = None
     if not args.no_compare:
-        from sourmash_rust_amd import distributed as D, synth
+        from sourmash_rust_amd import distributed as D, matrix as MX, synth
         n_sig = args.compare_n or {1: 1000, 2: 2500, 4: 5000, 8: 10000}.get(world, 1000 * world)
         lo, hi, per = D.shard_range(n_sig, world, rank)
-        local_sigs = np.zeros((per, 2000), dtype=np.uint64)
-        local_sigs[: hi - lo] = synth.family_signatures(lo, hi, num=2000, seed=3)
-        mine = torch.from_numpy(local_sigs.view(np.int64)).cuda()
+        local_sigs = np.zeros((per, NUM), dtype=np.uint64)
+        local_sigs[: hi - lo] = synth.family_signatures(lo, hi, num=NUM, seed=3)
+        sigs_host = local_sigs
 
-        def compare_step():
-            # rows sharded by contiguous blocks; ONE all-gather (RCCL over xGMI) of the signatures
-            return D.compare_matrix_sharded(mine, n_sig, 2000, want=("jaccard",))
+        def time_collection(sig_block):
+            mine = torch.from_numpy(sig_block.view(np.int64)).cuda()
 
-        out = compare_step()
-        barrier()
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+            def compare_step():
+                # rows sharded by contiguous blocks; ONE all-gather (RCCL over xGMI) of the signatures
+                return D.compare_matrix_sharded(mine, n_sig, NUM, want=("jaccard",))
+
             out = compare_step()
-        barrier()
-        cdt = (time.perf_counter() - t0) / reps
-        ct = torch.tensor([cdt], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(ct, op=dist.ReduceOp.MAX)
-        cdt = float(ct.item())
-        diag_ok = True
-        if hi > lo:
-            j = out["jaccard"]
-            idx = torch.arange(hi - lo, device="cuda")
-            diag_ok = bool((j[idx, idx + lo] == 1.0).all().item())
-        # every rank checks its own row block; the line reports the conjunction
-        okt = torch.tensor([1 if diag_ok else 0], dtype=torch.int64, device="cuda")
-        if world > 1:
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        diag_ok = bool(okt.item())
-        tv, tt, ppt = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        L.smh_compare_last_stats(C.byref(tv), C.byref(tt), C.byref(ppt))
-        visited = min(tv.value * ppt.value, (hi - lo) * n_sig)          # pairs actually walked on this rank
-        eff = (visited * 32008 + ((hi - lo) * n_sig - visited) * 8) / cdt / 1e9
-        compare = {"metric": "signature pairs compared/sec (ordered pairs, num=2000)", "value": n_sig * n_sig / cdt,
-                   "unit": "pairs/s", "n_signatures": n_sig, "seconds": cdt, "self_jaccard_is_1": diag_ok,
-                   "tiles_visited": tv.value, "tiles_total": tt.value, "pairs_per_tile": ppt.value,
-                   "collection": "50 families of related signatures (SURVEY.md 8d); pairs across families share no hash "
-                                 "and are filled without being read (DESIGN.md 3.4)",
-                   "roofline": {"bound": "hbm", "achieved": eff, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": eff / HBM_PEAK_GBS,
-                                "label": "rank 0's EFFECTIVE bytes: 32 008 B per ordered pair walked (SURVEY.md 8d) + 8 B per pair "
-                                         "filled as disjoint; tiles are served from LDS/L2, compulsory HBM traffic is N*16 KB in + "
-                                         "N^2*8 B out; the kernel is bound by VALU issue and LDS latency (DESIGN.md 3.4)"}}
+            barrier()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                out = compare_step()
+            barrier()
+            cdt = max_over_ranks((time.perf_counter() - t0) / reps)
+            diag_ok = True
+            if hi > lo:
+                j = out["jaccard"]
+                idx = torch.arange(hi - lo, device="cuda")
+                diag_ok = bool((j[idx, idx + lo] == 1.0).all().item())
+            # every rank checks its own row block; the line reports the conjunction
+            okt = torch.tensor([1 if diag_ok else 0], dtype=torch.int64, device="cuda")
+            if world > 1:
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            st = MX.last_stats()
+            walked = min(st["tiles_visited"] * st["pairs_per_tile"], (hi - lo) * n_sig)   # pairs walked on this rank
+            return out, {"seconds": cdt, "pairs_per_s": n_sig * n_sig / cdt, "self_jaccard_is_1": bool(okt.item()),
+                         "route": st["route"], "tiles_visited": st["tiles_visited"], "tiles_total": st["tiles_total"],
+                         "pairs_per_tile": st["pairs_per_tile"], "rank0_pairs_walked": walked,
+                         "rank0_pairs_walked_per_s": walked / cdt,
+                         "rank0_union_elements_walked_per_s": walked * NUM / cdt}
+
+        out_fam, fam = time_collection(local_sigs)
+        one = local_sigs.copy()
+        one[:, 0] = CONTAMINANT        # (uniform 64-bit hashes: the smallest possible value keeps rows ascending)
+        out_one, onec = time_collection(one)
+        compare = {"metric": "signature pairs compared/sec (ordered pairs, num=%d)" % NUM, "value": fam["pairs_per_s"],
+                   "unit": "pairs/s", "n_signatures": n_sig, "seconds": fam["seconds"], "self_jaccard_is_1": fam["self_jaccard_is_1"],
+                   "collection": "50 families of related signatures (SURVEY.md 8d): pairs across families share no hash and are "
+                                 "filled without being walked (DESIGN.md 3.4) -- a property of the collection, not of the kernel",
+                   "families": fam,
+                   "one_component": dict(onec, collection="the same signatures with one hash (a contaminant k-mer) shared by all: "
+                                                          "one connected component, every pair has to be walked"),
+                   "note": "'union elements walked' = pairs walked x num: with two full num-sketches the truncated union walk ends "
+                           "after exactly num elements (reference src/lib.rs:470-499); per walked pair the effective traffic of "
+                           "SURVEY.md 8d is 32 008 B served from LDS/L2, compulsory HBM traffic is N*16 KB in + N^2*8 B out"}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import coracle
-        o = coracle.MinHash(0, K, False, 42, MAX_HASH, False)
-        done = 0
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < args.cpu_seconds and done < n_rec:
-            o.add_sequence(bytes(coracle.synth_dna(done * REC_LEN, REC_LEN, 2, 0)), True)
-            done += 1
-        cdt = time.perf_counter() - t0
-        # the same records through the GPU path must give the same sketch
-        g = pkg.KmerMinHash(0, K, False, 42, MAX_HASH, False)
-        g.add_sequences_dev(seq.data_ptr(), done * REC_LEN, offsets[: done + 1], True, stream)
-        assert g.mins == o.mins, "GPU sketch differs from the CPU oracle on the baseline sample"
-        cpu = {"value": done * (REC_LEN - K + 1) / cdt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-               "sample": "first %d of the %d records (1 MB each) of the same workload, C oracle incl. input generation; "
-                         "sketch checked equal to the GPU's" % (done, n_rec)}
+        cores = host_cores()
+        scale = args.cpu_seconds / 10.0
+
+        def gpu_sketch(first, count):
+            g = pkg.KmerMinHash(0, K, False, 42, MAX_HASH, False)
+            g.add_sequences_dev(seq.data_ptr() + first * REC_LEN, count * REC_LEN, offsets[: count + 1], True, stream)
+            return g.mins_np()
+
+        # sketch, one core
+        (r1, p1), = run_workers([["sketch", 0, n_rec, 10.0 * scale]])
+        assert (gpu_sketch(0, r1["records"]) == np.load(p1)).all(), "GPU sketch differs from the CPU oracle (1-core sample)"
+        one_core = r1["records"] * (REC_LEN - K + 1) / r1["seconds"]
+        # sketch, all cores: worker w takes its own stretch of records
+        per_w = max(1, min(n_rec // max(1, cores), 200))
+        ws = run_workers([["sketch", w * per_w, (w + 1) * per_w, 5.0 * scale] for w in range(cores) if (w + 1) * per_w <= n_rec])
+        for w, (r, p) in enumerate(ws):
+            assert (gpu_sketch(w * per_w, r["records"]) == np.load(p)).all(), "GPU sketch differs from the CPU oracle (worker %d)" % w
+        all_cores = sum(r["records"] for r, _ in ws) * (REC_LEN - K + 1) / max(r["seconds"] for r, _ in ws)
+        # BASELINE configs[0] on the CPU, and the same through the GPU path
+        (r0, p0), = run_workers([["config0"]])
+        g0 = pkg.KmerMinHash(500, K, False, 42, 0, False)
+        rec0 = torch.empty(REC_LEN, dtype=torch.uint8, device="cuda")
+        assert L.smh_synth_dna_dev(C.c_void_p(rec0.data_ptr()), 0, REC_LEN, 1, 0, C.c_void_p(stream)) == 0
+        g0.add_sequences_dev(rec0.data_ptr(), REC_LEN, np.array([0, REC_LEN], dtype=np.uint64), False, stream)
+        assert (g0.mins_np() == np.load(p0)).all() and g0.compare(g0) == 1.0 and r0["self_compare"] == 1.0
+        cpu = {"value": one_core, "unit": "k-mers/s", "cores": 1, "kind": "port",
+               "sample": "first %d of the %d records (1 MB each) of the same workload through the C oracle's add_sequence "
+                         "(input generation not timed); sketch checked equal to the GPU's" % (r1["records"], n_rec),
+               "all_cores": {"value": all_cores, "cores": len(ws), "host_cores": cores,
+                             "sample": "%d independent workers, one stretch of records each (%d records in all), "
+                                       "every sketch checked equal to the GPU's" % (len(ws), sum(r["records"] for r, _ in ws))},
+               "config0": {"workload": "BASELINE configs[0]: 1 MB synthetic DNA, k=31, num=500, compare to itself",
+                           "sketch_kmers_per_s": r0["kmers"] / r0["sketch_seconds"], "compare_pairs_per_s": 1.0 / r0["compare_seconds"],
+                           "self_compare": r0["self_compare"], "cores": 1, "gpu_sketch_equal": True}}
+        if compare is not None:
+            n_sig = compare["n_signatures"]
+            for key, contaminated, gpu_out in (("families", 0, out_fam), ("one_component", 1, out_one)):
+                gj = gpu_out["jaccard"].cpu().numpy()
+                (rc1, pc1), = run_workers([["compare", n_sig, 0, n_sig, 3.0 * scale, contaminated]])
+                j1 = np.load(pc1)
+                assert (gj[: j1.shape[0]] == j1).all(), "GPU matrix differs from the CPU oracle (%s, 1-core rows)" % key
+                per_w = max(1, n_sig // cores)
+                cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, 3.0 * scale, contaminated] for w in range(cores)
+                                  if (w + 1) * per_w <= n_sig])
+                for w, (r, p) in enumerate(cw):
+                    jw = np.load(p)
+                    assert (gj[w * per_w: w * per_w + jw.shape[0]] == jw).all(), "GPU matrix differs from the CPU oracle (%s, worker %d)" % (key, w)
+                compare[key]["cpu_baseline"] = {
+                    "value": rc1["rows"] * n_sig / rc1["seconds"], "unit": "pairs/s", "cores": 1, "kind": "port",
+                    "sample": "rows 0..%d x all %d columns through the C oracle's compare (two merges + two intersections per "
+                              "pair, reference src/lib.rs:470-508); equal to the GPU's rows" % (rc1["rows"] - 1, n_sig),
+                    "all_cores": {"value": sum(r["rows"] for r, _ in cw) * n_sig / max(r["seconds"] for r, _ in cw),
+                                  "cores": len(cw), "host_cores": cores,
+                                  "sample": "%d workers, one row block each (%d rows in all), equal to the GPU's rows"
+                                            % (len(cw), sum(r["rows"] for r, _ in cw))}}
 
     if rank == 0:
         line = {
@@ -217,19 +397,17 @@ def main():
                        "retained_hashes": retained, "records_sharded_across_ranks": True,
                        "result": "sorted distinct hashes left in HBM; copy to host (PCIe, not in value) took %.1f ms" % to_host_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_dna_rolling<31,512,2>",
-                         "kernel_ms_avg": kern_ms, "launches_per_step": launches_per_step,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_dna_rolling<31,...>", "kernel_ms_avg": kern_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "valu_bound": {"kernel_kmers_per_s": kmers_per_step / max(1.0, launches_per_step) / (kern_ms * 1e-3) if kern_ms > 0 else 0.0,
-                                        "bare_murmur64_ceiling_per_s": MURMUR_CEILING,
-                                        "frac": (kmers_per_step / max(1.0, launches_per_step) / (kern_ms * 1e-3) / MURMUR_CEILING) if kern_ms > 0 else 0.0},
-                         "note": "1 B/k-mer: the path is integer-VALU bound (34 multiply-class + ~105 other VALU ops per k-mer; a third of murmur's "
-                                 "multiplies come from LDS product tables, which is why the kernel can approach the straightforward bare-murmur rate), "
-                                 "not HBM bound; see DESIGN.md 'Roofline'"},
+                         "valu_bound": valu_bound,
+                         "note": "1 B per k-mer: the path is integer-VALU bound, not HBM bound (SURVEY.md 8d; DESIGN.md 'Roofline'); "
+                                 "valu_bound prices the kernel against the guide's VALU issue peak"},
             "cpu_baseline": cpu,
             "compare": compare,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -113,9 +113,33 @@ int smh_index_compare(SmhIndex *rows, SmhIndex *cols, double *jaccard, uint64_t 
 int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       void *stream);
 
-/* Of the last block compare that took the tiled path: tiles launched (those that can hold pairs
- * sharing a hash), tiles in the block, pairs per tile.  Measurement aid. */
-void smh_compare_last_stats(uint64_t *tiles_visited, uint64_t *tiles_total, uint64_t *pairs_per_tile);
+/* Which kernel serves an N x M compare block is chosen from the block's shape (a wavefront per
+ * pair, a few-against-many stream, a per-component pair kernel, the tiled matrix kernel).  The
+ * choice NEVER changes a result.  It can be pinned: the parity tests run every route over the same
+ * inputs, and a caller that knows its collection is one big component can skip the pair route. */
+enum SmhCompareRoute {
+  SMH_ROUTE_AUTO = 0, SMH_ROUTE_WAVE = 1, SMH_ROUTE_FEW = 2, SMH_ROUTE_COMPONENTS = 3, SMH_ROUTE_TILED = 4
+};
+typedef struct SmhCompareTuning {
+  uint32_t route;             /* SmhCompareRoute; default AUTO */
+  uint32_t visit_all_tiles;   /* tiled route: 1 = launch every tile, not only those that can hold pairs sharing a hash */
+  uint32_t use_symmetry;      /* default 1: all-vs-all with one num computes the upper triangle and mirrors it */
+  uint64_t comp_pairs_limit;  /* AUTO: at most this many sharing pairs -> per-component pair kernel (default 2^18) */
+} SmhCompareTuning;
+void smh_compare_get_tuning(SmhCompareTuning *out);
+int smh_compare_set_tuning(const SmhCompareTuning *tuning);   /* NULL restores the defaults; process-wide */
+
+/* What the last block compare did.  Measurement aid and test evidence (which route ran; whether the
+ * tiled kernel's global-memory merge branch was taken). */
+typedef struct SmhCompareStats {
+  uint32_t route;               /* SmhCompareRoute that ran */
+  uint32_t rows_per_tile;       /* tiled route */
+  uint64_t tiles_visited;       /* tiled: tiles launched; components: pairs walked */
+  uint64_t tiles_total;         /* tiled: tiles in the block; components: pairs in the block */
+  uint64_t pairs_per_tile;
+  uint64_t lds_overflow_steps;  /* tiled: (tile, range) steps merged from global memory instead of the LDS stage */
+} SmhCompareStats;
+void smh_compare_last_stats(SmhCompareStats *out);
 
 /* Test hook, host only (no device needed): the tile planning of the N x M compare block.  comp_*:
  * connected-component id of every row / column (ids < max_comp); outputs: the slot orders and the

@@ -17,6 +17,16 @@ class SourmashStr(C.Structure):
     _fields_ = [("data", C.c_void_p), ("len", C.c_size_t), ("owned", C.c_bool)]
 
 
+class SmhCompareTuning(C.Structure):
+    _fields_ = [("route", C.c_uint32), ("visit_all_tiles", C.c_uint32), ("use_symmetry", C.c_uint32),
+                ("comp_pairs_limit", C.c_uint64)]
+
+
+class SmhCompareStats(C.Structure):
+    _fields_ = [("route", C.c_uint32), ("rows_per_tile", C.c_uint32), ("tiles_visited", C.c_uint64),
+                ("tiles_total", C.c_uint64), ("pairs_per_tile", C.c_uint64), ("lds_overflow_steps", C.c_uint64)]
+
+
 def build(force=False):
     """Compile the HIP/C++ sources in-tree (hipcc --offload-arch=gfx950)."""
     src = os.path.join(HERE, "csrc")
@@ -102,7 +112,9 @@ _SIGS = {
     "smh_test_plan_tiles": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.c_bool, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.c_uint32, C.POINTER(C.c_uint32)]),
-    "smh_compare_last_stats": (None, [u64p, u64p, u64p]),
+    "smh_compare_last_stats": (None, [C.POINTER(SmhCompareStats)]),
+    "smh_compare_get_tuning": (None, [C.POINTER(SmhCompareTuning)]),
+    "smh_compare_set_tuning": (C.c_int, [C.POINTER(SmhCompareTuning)]),
     "smh_synth_dna_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "smh_profile_enable": (None, [C.c_int]),
     "smh_profile_reset": (None, []),

@@ -355,7 +355,7 @@ struct TiledArgs {
   uint32_t xcd_chunk;      // tiles per XCD stretch (0 = list order)
   uint32_t symmetric;      // rows and columns are the same sketches with one num: pair (i, j) also writes (j, i)
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
-  uint32_t dbg;          // timing experiments only: 1 = stage but do not merge
+  unsigned long long* ovf_steps;   // (tile, range) steps that did not fit the LDS stage and merged from global memory
   CompareOut out;
 };
 
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
         const int t = w * kRowsPerWave + q;
         const uint32_t la = lenA[t];
         const uint32_t n = nrowL[t];
-        if ((!WantCC && ucount[q] >= n) || a.dbg == 1) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
+        if (!WantCC && ucount[q] >= n) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
         const uint32_t* A = poolA + offA[t];
         uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
         uint32_t av = A[0], bv = Bt[lane];
@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       }
     } else {
       // ---- rare: this range does not fit LDS for this tile; merge from global memory
+      if (tid == 0) atomicAdd(a.ovf_steps, 1ull);
       const uint32_t lb = lenB[lane];
       const uint32_t* B = a.crank + gB[lane];
 #pragma unroll
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void k_fill_disjoint(const uint64_t* __restric
 }
 
 struct TiledScratch {
-  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, perm;
+  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, perm, ovf;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -713,17 +714,41 @@ TiledScratch& tiled_scratch() {
 
 }  // namespace
 
-static uint64_t g_last_tiles_visited = 0, g_last_tiles_total = 0, g_last_pairs_per_tile = 0;
-void compare_last_stats(uint64_t* visited, uint64_t* total, uint64_t* pairs_per_tile) {
-  if (visited) *visited = g_last_tiles_visited;
-  if (total) *total = g_last_tiles_total;
-  if (pairs_per_tile) *pairs_per_tile = g_last_pairs_per_tile;
+// tuning (which kernel serves a block; never a result) and the record of the last block
+static CompareTuning g_tuning;
+static CompareStats g_stats;
+void compare_set_tuning(const CompareTuning& t) { g_tuning = t; }
+CompareTuning compare_get_tuning() { return g_tuning; }
+CompareStats compare_last_stats() { return g_stats; }
+
+// Geometry experiments (tools/): compiled in only with -DSMH_EXPERIMENTS, read once.
+struct TiledExperiments {
+  uint32_t per_range = 24;            // pooled elements per sketch per range
+  uint32_t capA = 1024, capB = 48;    // LDS dwords of the row pool; column elements per range
+  int rpw = 0, wpb = 4, minw = 8;     // rpw 0 = chosen from the block's shape
+  bool xcd = true;
+};
+static const TiledExperiments& tiled_experiments() {
+  static const TiledExperiments ex = [] {
+    TiledExperiments e;
+#ifdef SMH_EXPERIMENTS
+    if (const char* v = std::getenv("SOURMASH_AMD_CMP_PER_RANGE")) e.per_range = (uint32_t)std::max(4, std::atoi(v));
+    if (const char* v = std::getenv("SOURMASH_AMD_CMP_LDS")) {
+      int ca = 0, cb = 0;
+      if (sscanf(v, "%d,%d", &ca, &cb) == 2 && ca >= 256 && cb >= 8) { e.capA = (uint32_t)ca; e.capB = (uint32_t)cb; }
+    }
+    if (const char* v = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(v, "%d,%d,%d", &e.rpw, &e.wpb, &e.minw);
+    if (std::getenv("SOURMASH_AMD_CMP_NO_XCD")) e.xcd = false;
+#endif
+    return e;
+  }();
+  return ex;
 }
 
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
-                          &T.node, &T.parent, &T.root, &T.tiles, &T.perm})
+                          &T.node, &T.parent, &T.root, &T.tiles, &T.perm, &T.ovf})
     b->release();
 }
 
@@ -733,7 +758,9 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   TiledScratch& T = tiled_scratch();
   // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
   const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
-  const bool symmetric = same && row_nums == nullptr && std::getenv("SOURMASH_AMD_CMP_NO_SYM") == nullptr;
+  const CompareTuning tune = g_tuning;
+  const TiledExperiments& ex = tiled_experiments();
+  const bool symmetric = same && row_nums == nullptr && tune.use_symmetry != 0;
   // a row block that is a slice of the column set (one rank's rows of the gathered signatures):
   // its ranks are a slice of the columns' ranks, nothing extra to sort
   const bool inside = !same && rows.hashes >= cols.hashes && rows.hashes + nr_elems <= cols.hashes + nc_elems;
@@ -803,9 +830,10 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
       pairs += (uint64_t)(i1 - i) * (j1 - j);
       i = i1; j = j1;
     }
-    uint64_t limit = 1ull << 18;
-    if (const char* e = std::getenv("SOURMASH_AMD_CMP_COMP_PAIRS")) limit = std::strtoull(e, nullptr, 10);
-    if (pairs <= limit && std::getenv("SOURMASH_AMD_CMP_ALL_TILES") == nullptr) {
+    const bool take_comp = tune.route == kRouteComponents ? true
+                           : tune.route == kRouteTiled   ? false
+                                                         : (pairs <= tune.comp_pairs_limit && !tune.visit_all_tiles);
+    if (take_comp) {
       constexpr uint32_t kRowsPerItem = 32;
       std::vector<CompWork> work;
       for (const Box& b : boxes)
@@ -813,7 +841,9 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
           const uint32_t rs = symmetric ? std::max(b.r0, c) : b.r0;   // same order on both axes: upper triangle only
           for (uint32_t r = rs; r < b.r1; r += kRowsPerItem) work.push_back({cp[c], r, std::min(b.r1, r + kRowsPerItem)});
         }
-      g_last_tiles_visited = pairs; g_last_tiles_total = (uint64_t)rows.n * cols.n; g_last_pairs_per_tile = 1;
+      g_stats = CompareStats{};
+      g_stats.route = kRouteComponents;
+      g_stats.tiles_visited = pairs; g_stats.tiles_total = (uint64_t)rows.n * cols.n; g_stats.pairs_per_tile = 1;
       const uint64_t np = (uint64_t)rows.n * cols.n;
       dev.prof_begin(s);
       hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
@@ -850,9 +880,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
   // sketches walk several ranges per step
   uint64_t avg = max_len;
-  uint32_t per_range = 24;
-  if (const char* e = std::getenv("SOURMASH_AMD_CMP_PER_RANGE")) per_range = (uint32_t)std::atoi(e);
-  if (per_range < 4) per_range = 4;
+  const uint32_t per_range = ex.per_range;
   uint32_t R = (uint32_t)((avg + per_range - 1) / per_range);
   if (R < 1) R = 1;
   if (R > 8192) R = 8192;
@@ -880,29 +908,26 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // LDS budget per workgroup ~18 KB so that 8 workgroups of 4 waves fit a CU: the merge loop is a
   // dependent LDS-read -> compare -> advance chain, and occupancy is what hides its latency
   // (profiles/r01_compare_geometry.txt: 575 -> 1000 M pairs/s from 3 to 8 waves per SIMD)
-  a.capA = 1024;           // 16 rows x (~24 elements + sentinel) with 2.5x head-room
-  a.capBt = 48 * kTB;      // columns up to 47 elements in one range
-  if (const char* e = std::getenv("SOURMASH_AMD_CMP_LDS")) {
-    int ca = 0, cb = 0;
-    if (sscanf(e, "%d,%d", &ca, &cb) == 2 && ca >= 256 && cb >= 8) { a.capA = ca; a.capBt = cb * kTB; }
-  }
+  a.capA = ex.capA;         // 16 rows x (~24 elements + sentinel) with 2.5x head-room
+  a.capBt = ex.capB * kTB;  // columns up to 47 elements in one range
   a.out = out;
-  a.dbg = std::getenv("SOURMASH_AMD_CMP_DBG") ? (uint32_t)std::atoi(std::getenv("SOURMASH_AMD_CMP_DBG")) : 0;
+  T.ovf.ensure(8);
+  HIP_CHECK(hipMemsetAsync(T.ovf.ptr, 0, 8, s));
+  a.ovf_steps = T.ovf.as<unsigned long long>();
   const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;
   // rows per wave: 16 (64-row tiles) amortises staging best; small problems use shorter tiles so
   // that the launch still covers the chip several times
-  // geometry "rpw,wpb,minw" (experiments: SOURMASH_AMD_CMP_GEO)
-  int rpw = 4, wpb = 4, minw = 8;
+  int rpw = 4, wpb = ex.wpb, minw = ex.minw;
   // fewer than ~4 rounds of 16-row tiles over the chip: 8-row tiles keep all wave slots busy
   // (1000 x 1000: 2.47 -> 2.20 ms, profiles/r01_compare_small_geometry.txt)
   if ((uint64_t)((rows.n + 15) / 16) * ((cols.n + kTB - 1) / kTB) < (uint64_t)dev.cu_count() * 32) rpw = 2;
-  if (const char* e = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(e, "%d,%d,%d", &rpw, &wpb, &minw);
+  if (ex.rpw) rpw = ex.rpw;
   // sketches of one component become adjacent (stable: original order inside a component); then
   // the tiles that can hold a same-component pair (tile_plan.cpp, host only)
-  const bool all_on = std::getenv("SOURMASH_AMD_CMP_ALL_TILES") != nullptr;
+  const bool all_on = tune.visit_all_tiles != 0;
   uint32_t tr = (uint32_t)(rpw * wpb);
   plan_tiles(comp_r, rows.n, comp_c, cols.n, tr, kTB, symmetric, all_on, &plan);
-  if (std::getenv("SOURMASH_AMD_CMP_GEO") == nullptr && wpb == 4 && minw == 8) {
+  if (ex.rpw == 0 && wpb == 4 && minw == 8) {
     // few tiles left: shorter ones fill the chip better (the kernel is latency bound, a
     // workgroup per CU leaves 7/8 of the wave slots empty)
     while (rpw > 1 && plan.tiles.size() / 2 < (size_t)dev.cu_count() * 32) {
@@ -915,7 +940,9 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   const std::vector<uint32_t>& tile_list = plan.tiles;
   const uint32_t tiles = (uint32_t)(tile_list.size() / 2);
   const uint64_t all_tiles = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
-  g_last_tiles_visited = tiles; g_last_tiles_total = all_tiles; g_last_pairs_per_tile = (uint64_t)tr * kTB;
+  g_stats = CompareStats{};
+  g_stats.route = kRouteTiled; g_stats.rows_per_tile = tr;
+  g_stats.tiles_visited = tiles; g_stats.tiles_total = all_tiles; g_stats.pairs_per_tile = (uint64_t)tr * kTB;
   T.perm.ensure(((size_t)rows.n + cols.n) * 4 + 8);
   T.tiles.ensure(tile_list.size() * 4 + 8);
   HIP_CHECK(hipMemcpyAsync(T.perm.ptr, rperm.data(), (size_t)rows.n * 4, hipMemcpyHostToDevice, s));
@@ -932,7 +959,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     dev.prof_end("compare_fill", s);
   }
   if (tiles == 0) { HIP_CHECK(hipStreamSynchronize(s)); return; }
-  a.xcd_chunk = (tiles >= 64 && std::getenv("SOURMASH_AMD_CMP_NO_XCD") == nullptr) ? tiles / 8 : 0;
+  a.xcd_chunk = (tiles >= 64 && ex.xcd) ? tiles / 8 : 0;
   dev.prof_begin(s);
   bool launched = false;
 #define SMH_CT(R_, W_, M_)                                                                              \
@@ -947,7 +974,10 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   if (!launched) throw_internal("compare geometry not instantiated");
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_tiled", s);
+  unsigned long long ovf = 0;
+  HIP_CHECK(hipMemcpyAsync(&ovf, T.ovf.ptr, 8, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));   // tile_list / rperm / cperm are stack-lifetime staging vectors
+  g_stats.lds_overflow_steps = ovf;
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
@@ -976,9 +1006,11 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
                           uint64_t nc_elems, bool same_sets) {
   const uint64_t npairs = (uint64_t)rows.n * cols.n;
   if (npairs == 0) return;
+  const uint32_t route = g_tuning.route;
   // big blocks: dictionary-encode once, then the tiled kernel; small ones: one wavefront per pair
-  if (npairs >= 4096 && rows.n >= 8 && cols.n >= 16 && nr_elems + nc_elems > 0 &&
-      std::getenv("SOURMASH_AMD_NO_TILED") == nullptr) {
+  const bool block_ok = nr_elems + nc_elems > 0;
+  if (block_ok && (route == kRouteAuto ? (npairs >= 4096 && rows.n >= 8 && cols.n >= 16)
+                                       : (route == kRouteComponents || route == kRouteTiled))) {
     launch_tiled(rows, cols, nr_elems, nc_elems, max_row_len > max_col_len ? max_row_len : max_col_len, num, row_nums, out,
                  dev, s, same_sets);
     return;
@@ -989,7 +1021,7 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
     const SketchSet& many = rows_many ? rows : cols;
     const SketchSet& few = rows_many ? cols : rows;
     const uint32_t few_max = rows_many ? max_col_len : max_row_len;
-    if (many.n >= 64 && std::getenv("SOURMASH_AMD_NO_FEW") == nullptr) {
+    if (route == kRouteAuto ? many.n >= 64 : route == kRouteFew) {
       const bool q_lds = few_max <= 8192;
       const size_t lds = q_lds ? (size_t)(few_max ? few_max : 1) * 8 : 16;
       const bool want_cc = out.count_common || out.containment;
@@ -1004,6 +1036,8 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
 #undef SMH_CF
       HIP_CHECK(hipGetLastError());
       dev.prof_end("compare_few", s);
+      g_stats = CompareStats{};
+      g_stats.route = kRouteFew;
       return;
     }
   }
@@ -1019,6 +1053,8 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
   }
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_wave", s);
+  g_stats = CompareStats{};
+  g_stats.route = kRouteWave;
 }
 
 }  // namespace smh

@@ -730,8 +730,29 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
   });
 }
 
-void smh_compare_last_stats(uint64_t* tiles_visited, uint64_t* tiles_total, uint64_t* pairs_per_tile) {
-  smh::compare_last_stats(tiles_visited, tiles_total, pairs_per_tile);
+void smh_compare_last_stats(SmhCompareStats* out) {
+  if (!out) return;
+  const smh::CompareStats st = smh::compare_last_stats();
+  out->route = st.route; out->rows_per_tile = st.rows_per_tile;
+  out->tiles_visited = st.tiles_visited; out->tiles_total = st.tiles_total; out->pairs_per_tile = st.pairs_per_tile;
+  out->lds_overflow_steps = st.lds_overflow_steps;
+}
+void smh_compare_get_tuning(SmhCompareTuning* out) {
+  if (!out) return;
+  const smh::CompareTuning t = smh::compare_get_tuning();
+  out->route = t.route; out->visit_all_tiles = t.visit_all_tiles; out->use_symmetry = t.use_symmetry;
+  out->comp_pairs_limit = t.comp_pairs_limit;
+}
+int smh_compare_set_tuning(const SmhCompareTuning* in) {
+  return pad_code([&] {
+    smh::CompareTuning t;   // NULL = defaults
+    if (in) {
+      if (in->route > smh::kRouteTiled) smh::throw_internal("smh_compare_set_tuning: unknown route");
+      t.route = in->route; t.visit_all_tiles = in->visit_all_tiles; t.use_symmetry = in->use_symmetry;
+      t.comp_pairs_limit = in->comp_pairs_limit;
+    }
+    smh::compare_set_tuning(t);
+  });
 }
 
 // test hook (host only, no device): the compare block's tile planning

@@ -122,7 +122,25 @@ struct PairOut { unsigned long long tot_u, tot_c, common; };
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
                          Device& dev, hipStream_t s);
 
-void compare_last_stats(uint64_t* visited, uint64_t* total, uint64_t* pairs_per_tile);   // of the last tiled launch
+// Which kernel serves an N x M block is chosen from its shape.  The choice never changes a result;
+// it can be pinned (parity tests force every route over the same inputs, callers may know better).
+enum CompareRoute : uint32_t { kRouteAuto = 0, kRouteWave = 1, kRouteFew = 2, kRouteComponents = 3, kRouteTiled = 4 };
+struct CompareTuning {
+  uint32_t route = kRouteAuto;             // kRouteComponents / kRouteTiled both mean "the block path"; the two
+                                           // are told apart by comp_pairs_limit
+  uint32_t visit_all_tiles = 0;            // 1: launch every tile, not only those that can hold sharing pairs
+  uint32_t use_symmetry = 1;               // all-vs-all with one num: compute the upper triangle, mirror the rest
+  uint64_t comp_pairs_limit = 1ull << 18;  // at most this many sharing pairs: per-component pair kernel, else tiled
+};
+struct CompareStats {                      // of the last block compare
+  uint32_t route = 0;                      // CompareRoute that ran
+  uint32_t rows_per_tile = 0;
+  uint64_t tiles_visited = 0, tiles_total = 0, pairs_per_tile = 0;   // components route: pairs walked / pairs / 1
+  uint64_t lds_overflow_steps = 0;         // tiled: (tile, range) steps merged from global memory instead of LDS
+};
+void compare_set_tuning(const CompareTuning& t);
+CompareTuning compare_get_tuning();
+CompareStats compare_last_stats();
 void release_compare_scratch();   // frees the tiled kernel's pre-pass buffers
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,

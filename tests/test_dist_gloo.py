@@ -96,3 +96,42 @@ def test_row_sharded_matrix_and_sketch_union_gloo(n_total, coracle):
                 part.mins_push(int(h)); part.abunds_push(int(c))
             merged.merge(part)
         assert merged.mins == whole.mins and merged.abunds == whole.abunds
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` (the shape of the driver's command, no torchrun around it) must
+    start two ranks by itself.  There is no GPU here, so each rank stops at its first line of GPU
+    set-up -- which proves the launch went through: both ranks ran, with RANK/WORLD_SIZE set."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU machine: the real run is the driver's")
+    assert r.returncode != 0
+    text = r.stdout + r.stderr
+    assert "rank 0 needs cuda:0" in text and "rank 1 needs cuda:1" in text
+
+
+def test_bench_cpu_workers(tmp_path, coracle):
+    """The CPU-baseline workers of bench.py (`--cpu-worker`): bounded samples through the C oracle."""
+    import json
+    import subprocess
+
+    def run(*argv):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker"] + [str(a) for a in argv],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    d = run("config0", tmp_path / "c0.npy")
+    assert d["self_compare"] == 1.0 and d["kmers"] == 999970 and len(np.load(tmp_path / "c0.npy")) == 500
+    d = run("sketch", tmp_path / "s.npy", 3, 5, 0.01)
+    assert d["records"] == 1
+    o = coracle.MinHash(0, 31, False, 42, 18446744073709552, False)
+    o.add_sequence(bytes(coracle.synth_dna(3 * 1000000, 1000000, 2, 0)), True)
+    assert (np.load(tmp_path / "s.npy") == o.mins_np()).all()
+    d = run("compare", tmp_path / "c.npy", 60, 2, 60, 0.05, 1)
+    j = np.load(tmp_path / "c.npy")
+    assert j.shape == (d["rows"], 60) and j[0, 2] == 1.0 and (j > 0).all()      # contaminant: every pair shares a hash

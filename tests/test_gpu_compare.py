@@ -11,6 +11,29 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
+# Every oracle-compared matrix test runs over each way a block can be served (additive ABI
+# smh_compare_set_tuning; the choice must never change a result): the shape-based default, the
+# per-component pair kernel, the tiled matrix kernel over the tiles that can hold sharing pairs, and
+# the tiled kernel over EVERY tile.  `expect` = the route smh_compare_last_stats must report.
+ROUTES = [
+    pytest.param(dict(), None, id="auto"),
+    pytest.param(dict(route="components"), "components", id="components"),
+    pytest.param(dict(route="tiled"), "tiled", id="tiled"),
+    pytest.param(dict(route="tiled", visit_all_tiles=True), "tiled", id="tiled-all-tiles"),
+    pytest.param(dict(route="tiled", visit_all_tiles=True, use_symmetry=False), "tiled", id="tiled-all-tiles-nosym"),
+]
+
+
+def routed(pkg, tune, expect, fn):
+    with pkg.matrix.tuning(**tune):
+        out = fn()
+        st = pkg.matrix.last_stats()
+    if expect is not None:
+        assert st["route"] == expect, st
+        if tune.get("visit_all_tiles") and not tune.get("use_symmetry", True):
+            assert st["tiles_visited"] == st["tiles_total"], st
+    return out
+
 
 def mh_from_sketch(M, sk):
     mh = M(0 if sk["max_hash"] else sk["num"], sk["ksize"], sk["molecule"] == "protein", sk["seed"],
@@ -32,12 +55,14 @@ def test_sbt_v5_hit_counts(pkg, sbt_v5_leaves):
     assert sum(v > 0.5 for v in cont) == 2 and sum(v > 0.1 for v in cont) == 4
 
 
+@pytest.mark.parametrize("tune,expect", ROUTES)
 @pytest.mark.parametrize("tag", ["v5", "subset"])
-def test_golden_matrices(tag, pkg, sbt_v5_leaves, sbt_subset_sketches):
+def test_golden_matrices(tag, tune, expect, pkg, sbt_v5_leaves, sbt_subset_sketches):
     mats = np.load(os.path.join(GOLDEN, "golden_matrices.npz"))
     sks = [sbt_v5_leaves[k] for k in sorted(sbt_v5_leaves)] if tag == "v5" else sbt_subset_sketches
     mhs = [mh_from_sketch(pkg.KmerMinHash, s) for s in sks]
-    out = pkg.matrix.compare_block(mhs, mhs, want=("jaccard", "common", "size", "count_common", "containment"))
+    out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(
+        mhs, mhs, want=("jaccard", "common", "size", "count_common", "containment")))
     assert (out["common"] == mats[tag + "_common"]).all()
     assert (out["size"] == mats[tag + "_size"]).all()
     assert (out["jaccard"] == mats[tag + "_jaccard"]).all()
@@ -83,7 +108,8 @@ def test_large_sketches_not_in_lds(pkg, coracle):
     assert ga.intersection_size(gb) == (exp, len(a) + len(b) - exp)
 
 
-def test_device_csr_block(pkg, coracle):
+@pytest.mark.parametrize("tune,expect", ROUTES)
+def test_device_csr_block(tune, expect, pkg, coracle):
     import torch
     rng = np.random.RandomState(5)
     pool = np.unique(rng.randint(0, 1 << 62, size=3000, dtype=np.int64).astype(np.uint64))
@@ -95,7 +121,8 @@ def test_device_csr_block(pkg, coracle):
         cf, co = pkg.matrix.csr_from_sketches(cols)
         rt = torch.from_numpy(rf.view(np.int64)).cuda()
         ct = torch.from_numpy(cf.view(np.int64)).cuda()
-        out = pkg.matrix.compare_block_dev(rt, ro, ct, co, num, want=("jaccard", "common", "size", "count_common"))
+        out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block_dev(
+            rt, ro, ct, co, num, want=("jaccard", "common", "size", "count_common")))
         torch.cuda.synchronize()
         assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
         assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
@@ -129,10 +156,11 @@ def test_linear_index_find_and_scaffold(pkg, coracle, sbt_v5_leaves):
     assert cm == max(ocs) and pos == ocs.index(max(ocs))
 
 
-def test_tiled_block_edge_cases(pkg, coracle):
-    """The tiled matrix kernel on shapes that are not multiples of its 16 x 64 tiles, with empty and
-    ragged sketches, per-row nums that differ (H6: row i's num truncates pair (i, j)), a range that
-    overflows the LDS stage (falls back to the global-memory merge) and duplicate-heavy families."""
+@pytest.mark.parametrize("tune,expect", ROUTES)
+def test_tiled_block_edge_cases(tune, expect, pkg, coracle):
+    """The block kernels on shapes that are not multiples of the 16 x 64 tiles, with empty and
+    ragged sketches, per-row nums that differ (H6: row i's num truncates pair (i, j)), sketches
+    that hold a dense stretch of rank space and duplicate-heavy families."""
     rng = np.random.RandomState(11)
     pool = np.unique(rng.randint(0, 1 << 62, size=20000, dtype=np.int64).astype(np.uint64))
     dense = pool[:3000]                                  # one sketch holding a dense prefix of rank space
@@ -158,7 +186,8 @@ def test_tiled_block_edge_cases(pkg, coracle):
         for h in c:
             g.mins_push(int(h)); o.mins_push(int(h))
         col_mh.append(g); ocol.append(o)
-    out = pkg.matrix.compare_block(row_mh, col_mh, want=("jaccard", "common", "size", "count_common", "containment"))
+    out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(
+        row_mh, col_mh, want=("jaccard", "common", "size", "count_common", "containment")))
     for i in range(len(rows)):
         for j in range(0, len(cols), 7):
             c, s_ = orow[i].intersection_size(ocol[j])
@@ -170,63 +199,103 @@ def test_tiled_block_edge_cases(pkg, coracle):
             else:
                 assert np.isnan(out["containment"][i, j])
     # jaccard-only request takes the early-exit instantiation: same numbers
-    out2 = pkg.matrix.compare_block(row_mh, col_mh, want=("jaccard", "common", "size"))
+    out2 = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(row_mh, col_mh, want=("jaccard", "common", "size")))
     assert (out2["jaccard"] == out["jaccard"]).all() and (out2["common"] == out["common"]).all()
     assert (out2["size"] == out["size"]).all()
 
 
-def test_matrix_at_benchmark_size_properties(pkg):
-    """C3 at full size (1000 x 1000, num=2000): symmetry (all nums equal), unit diagonal, and a
-    checksum against the wavefront-per-pair kernel on a sample of rows."""
-    import os
-    import torch
-    from sourmash_rust_amd import synth
-    n = 1000
-    sigs = synth.family_signatures(0, n, num=2000, seed=3)
-    t = torch.from_numpy(sigs.view(np.int64)).cuda()
-    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
-    out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard", "common", "size"))
-    j = out["jaccard"].cpu().numpy()
-    assert (j == j.T).all() and (np.diag(j) == 1.0).all()
-    assert (out["size"].cpu().numpy() == 2000).all()
-    os.environ["SOURMASH_AMD_NO_TILED"] = "1"
-    try:
-        sub = pkg.matrix.compare_block_dev(t[:37].contiguous(), off[:38], t, off, 2000, want=("jaccard", "common"))
-    finally:
-        del os.environ["SOURMASH_AMD_NO_TILED"]
-    assert (sub["jaccard"].cpu().numpy() == j[:37]).all()
-    assert (sub["common"].cpu().numpy() == out["common"].cpu().numpy()[:37]).all()
-    # same-family pairs share hashes, different families do not
-    assert j[0, 50] > 0.2 and j[0, 1] == 0.0
+def _oracle_rows(coracle, sigs, rows, num):
+    """coracle.compare_matrix of the sampled rows against ALL columns (two merges + two intersections
+    per pair, reference src/lib.rs:470-508), spread over the host cores by row."""
+    from concurrent.futures import ThreadPoolExecutor      # ctypes releases the GIL inside the C call
+    cols = [sigs[i] for i in range(sigs.shape[0])]
+    with ThreadPoolExecutor(max_workers=min(16, len(rows))) as ex:
+        res = list(ex.map(lambda r: coracle.compare_matrix([sigs[r]], cols, num, 31, 0), rows))
+    return (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]), np.concatenate([r[2] for r in res]))
 
 
-def test_matrix_at_c4_size_properties(pkg):
-    """C4 at full size on one GPU (10 000 x 10 000, num=2000): symmetry, unit diagonal, constant
-    size, family structure, and agreement of a row sample with the wavefront-per-pair kernel."""
-    import os
+def _full_size_matrix_check(pkg, coracle, n, seed, sample_rows, tunes):
+    """All-vs-all at a BASELINE size: symmetry (all nums equal), unit diagonal, size == num, and the
+    sampled rows x ALL columns against the C oracle, for the family collection of SURVEY.md 8d and
+    for the same collection with one hash shared by every signature (one connected component: the
+    tiled kernel has to walk every tile)."""
     import torch
     from sourmash_rust_amd import synth
-    n = 10000
-    sigs = synth.family_signatures(0, n, num=2000, seed=4)
-    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    base = synth.family_signatures(0, n, num=2000, seed=seed)
     off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
-    out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard", "common"))
-    j = out["jaccard"]
-    assert bool((j == j.T).all()) and bool((j.diagonal() == 1.0).all())
-    # size == num everywhere: jaccard is exactly common / 2000 (IEEE division; checked with numpy on
-    # the host -- torch's GPU division by a scalar multiplies by the reciprocal)
-    assert (out["common"][:600].cpu().numpy().astype(np.float64) / 2000.0 == j[:600].cpu().numpy()).all()
-    fam = torch.arange(n, device="cuda") % 50
-    same = fam[:, None] == fam[None, :]
-    assert float(j[same].min()) > 0.2 and float(j[~same].max()) < 0.01
-    rows = torch.tensor([0, 1, 4999, 9999], device="cuda")
-    sub_t = t[rows].contiguous()
-    os.environ["SOURMASH_AMD_NO_TILED"] = "1"
-    try:
-        sub = pkg.matrix.compare_block_dev(sub_t, off[:5], t, off, 2000, want=("jaccard",))
-    finally:
-        del os.environ["SOURMASH_AMD_NO_TILED"]
-    assert bool((sub["jaccard"] == j[rows]).all())
+    for contaminated in (False, True):
+        sigs = base.copy()
+        if contaminated:
+            sigs[:, 0] = 1
+        t = torch.from_numpy(sigs.view(np.int64)).cuda()
+        ocommon, osize, ojac = _oracle_rows(coracle, sigs, sample_rows, 2000)
+        for tune, expect in tunes:
+            out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard", "common", "size")))
+            st = pkg.matrix.last_stats()
+            if contaminated and st["route"] == "tiled":
+                assert st["tiles_visited"] * 2 >= st["tiles_total"], st        # one component: (the upper half of) every tile
+            j = out["jaccard"]
+            assert bool((j == j.T).all()) and bool((j.diagonal() == 1.0).all())
+            assert bool((out["size"] == 2000).all())
+            idx = torch.tensor(sample_rows, device="cuda")
+            assert (j[idx].cpu().numpy() == ojac).all(), (contaminated, tune)
+            assert (out["common"][idx].cpu().numpy().view(np.uint64) == ocommon).all(), (contaminated, tune)
+            assert (osize == 2000).all()
+            fam = torch.arange(n, device="cuda") % 50
+            same = fam[:, None] == fam[None, :]
+            assert float(j[same].min()) > 0.2 and float(j[~same].max()) < 0.01
+            del out, j, same
+
+
+def test_matrix_at_benchmark_size_vs_oracle(pkg, coracle):
+    """C3 at full size (1000 x 1000, num=2000) through every block route; 40 sampled rows x all
+    columns against the C oracle."""
+    rows = sorted(set([0, 1, 49, 50, 51, 999] + list(range(7, 1000, 29))))
+    tunes = [(dict(), None), (dict(route="components"), "components"), (dict(route="tiled"), "tiled"),
+             (dict(route="tiled", visit_all_tiles=True), "tiled"), (dict(route="tiled", use_symmetry=False), "tiled")]
+    _full_size_matrix_check(pkg, coracle, 1000, 3, rows, tunes)
+
+
+def test_matrix_at_c4_size_vs_oracle(pkg, coracle):
+    """C4 at full size on one GPU (10 000 x 10 000, num=2000): the shape-based default route (the
+    tiled kernel: > 2^18 sharing pairs) on the family collection and on the one-component
+    collection, 32 sampled rows x all 10 000 columns against the C oracle."""
+    rows = sorted(set([0, 1, 49, 50, 4999, 5000, 9999] + list(range(13, 10000, 400))))
+    _full_size_matrix_check(pkg, coracle, 10000, 4, rows, [(dict(), "tiled")])
+
+
+def test_tiled_global_merge_branch(pkg, coracle):
+    """A range whose segments do not fit the tiled kernel's LDS stage is merged straight from global
+    memory.  Sketches that pack 2 000 hashes into a sliver of hash space (where everything else is
+    sparse) produce such ranges; smh_compare_last_stats must report that the branch ran, and every
+    pair must still match the oracle."""
+    rng = np.random.RandomState(41)
+    spread = lambda k: np.unique(rng.randint(0, 1 << 62, size=k, dtype=np.int64).astype(np.uint64))
+    lo = np.uint64(1) << np.uint64(61)
+    clustered = lambda k: np.unique(lo + rng.randint(0, 1 << 20, size=k, dtype=np.int64).astype(np.uint64))
+    pool = clustered(2600)
+    rows, cols = [], []
+    for i in range(70):
+        rows.append(np.sort(rng.choice(pool, 2000, replace=False)) if i % 5 == 0 else spread(rng.choice([300, 2000])))
+    for j in range(150):
+        cols.append(np.sort(rng.choice(pool, 1800, replace=False)) if j % 4 == 1 else spread(rng.choice([100, 2000])))
+    for num in (2000, 0, 150):
+        common, size, jac = coracle.compare_matrix(rows, cols, num, 31, 0 if num else 1 << 62)
+        import torch
+        rf, ro = pkg.matrix.csr_from_sketches(rows)
+        cf, co = pkg.matrix.csr_from_sketches(cols)
+        rt = torch.from_numpy(rf.view(np.int64)).cuda()
+        ct = torch.from_numpy(cf.view(np.int64)).cuda()
+        for tune in (dict(route="tiled"), dict(route="tiled", visit_all_tiles=True)):
+            with pkg.matrix.tuning(**tune):
+                out = pkg.matrix.compare_block_dev(rt, ro, ct, co, num, want=("jaccard", "common", "size", "count_common"))
+                st = pkg.matrix.last_stats()
+            assert st["route"] == "tiled" and st["lds_overflow_steps"] > 0, st
+            assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
+            assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
+            assert (out["jaccard"].cpu().numpy() == jac).all()
+            cc = np.array([[len(np.intersect1d(r, c)) for c in cols] for r in rows], dtype=np.uint64)
+            assert (out["count_common"].cpu().numpy().view(np.uint64) == cc).all()
 
 
 def test_end_to_end_genomes_to_matrix(pkg, coracle):
@@ -398,7 +467,8 @@ def test_pairwise_calls_see_every_mutation(pkg, coracle):
         assert gc.compare(ga) == oc.compare(oa)
 
 
-def test_row_block_that_is_a_slice_of_the_columns(pkg, coracle):
+@pytest.mark.parametrize("tune,expect", ROUTES)
+def test_row_block_that_is_a_slice_of_the_columns(tune, expect, pkg, coracle):
     """One rank's row block passed as a VIEW of the gathered signature set: the tiled pre-pass encodes
     the columns only and takes the rows' ranks from the same array."""
     import torch
@@ -411,7 +481,8 @@ def test_row_block_that_is_a_slice_of_the_columns(pkg, coracle):
         rows = allt[lo:hi]
         ro = np.arange(hi - lo + 1, dtype=np.uint64) * np.uint64(width)
         co = np.arange(n + 1, dtype=np.uint64) * np.uint64(width)
-        out = pkg.matrix.compare_block_dev(rows, ro, allt, co, width, want=("jaccard", "common", "size", "count_common"))
+        out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block_dev(
+            rows, ro, allt, co, width, want=("jaccard", "common", "size", "count_common")))
         torch.cuda.synchronize()
         common, size, jac = coracle.compare_matrix(list(sigs[lo:hi]), list(sigs), width, 31, 0)
         assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
@@ -420,8 +491,9 @@ def test_row_block_that_is_a_slice_of_the_columns(pkg, coracle):
         assert (out["jaccard"].cpu().numpy()[np.arange(hi - lo), np.arange(lo, hi)] == 1.0).all()
 
 
+@pytest.mark.parametrize("tune,expect", ROUTES)
 @pytest.mark.parametrize("same_set,uniform_num", [(True, False), (False, False), (True, True)])
-def test_components_and_disjoint_pairs(same_set, uniform_num, pkg, coracle):
+def test_components_and_disjoint_pairs(same_set, uniform_num, tune, expect, pkg, coracle):
     """The tiled path visits only tiles that can hold sharing pairs (connected components of the
     'shares a hash' graph) and fills the rest as disjoint.  Interleaved families, singletons, empty
     sketches, per-row nums, rows != columns, every output, against the oracle pair by pair."""
@@ -452,7 +524,7 @@ def test_components_and_disjoint_pairs(same_set, uniform_num, pkg, coracle):
     else:
         gc, oc = zip(*[_pair(pkg, coracle, 77, c) for c in cols])
     want = ("jaccard", "common", "size", "count_common", "containment")
-    out = pkg.matrix.compare_block(list(gr), list(gc), want=want)
+    out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(list(gr), list(gc), want=want))
     for i in range(len(rows)):
         for j in range(len(cols)):
             assert (int(out["common"][i, j]), int(out["size"][i, j])) == orr[i].intersection_size(oc[j]), (i, j)
@@ -462,5 +534,5 @@ def test_components_and_disjoint_pairs(same_set, uniform_num, pkg, coracle):
                 assert out["containment"][i, j] == orr[i].containment(oc[j])
             else:
                 assert np.isnan(out["containment"][i, j])
-    out2 = pkg.matrix.compare_block(list(gr), list(gc), want=("jaccard", "size"))
+    out2 = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(list(gr), list(gc), want=("jaccard", "size")))
     assert (out2["jaccard"] == out["jaccard"]).all() and (out2["size"] == out["size"]).all()

@@ -37,3 +37,19 @@ def test_bench_two_ranks_sharing_the_gpu(pkg):
     c = d["compare"]
     assert c["n_signatures"] == 601 and c["self_jaccard_is_1"] is True   # 601: the last row block is short
     assert d["cpu_baseline"] is None                                      # reported at N=1 only
+
+
+def test_bench_gpus_2_with_no_launcher_around_it(pkg):
+    """`python bench.py --gpus 2` exactly as typed (no torchrun wrapper): bench.py starts its own two
+    ranks as child processes before anything touches the GPU and relays rank 0's single JSON line."""
+    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--gb", "0.1", "--steps", "1", "--warmup", "0", "--compare-n", "300"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["compare"]["self_jaccard_is_1"] is True
+    assert d["compare"]["one_component"]["self_jaccard_is_1"] is True

@@ -179,6 +179,39 @@ while time.time() < t_end:
                 print("MERGE MISMATCH case", case, eg, eo)
                 sys.exit(1)
         n_sk += 1
+    elif rng.random() < 0.15:
+        # a block with more than 2^18 sharing pairs: the shape-based default takes the tiled kernel.
+        # Device CSR in, whole matrix against the C oracle's compare_matrix.
+        nrs = np.random.RandomState(rng.getrandbits(31))
+        nrow, ncol = rng.randint(520, 700), rng.randint(520, 900)
+        width = rng.choice([40, 200, 600])
+        pool = np.unique(nrs.randint(0, 1 << 62, size=width * rng.choice([2, 5, 20]), dtype=np.int64).astype(np.uint64))
+        ragged = rng.random() < 0.5
+        def mkb(cnt):
+            return [np.sort(nrs.choice(pool, min(len(pool), width if not ragged else nrs.choice([1, width // 3, width, 2 * width])),
+                                       replace=False)) for _ in range(cnt)]
+        rows = mkb(nrow)
+        same = rng.random() < 0.4
+        cols = rows if same else mkb(ncol)
+        num = rng.choice([0, width, width // 2, 7])
+        rf, ro = pkg.matrix.csr_from_sketches(rows)
+        rt = torch.from_numpy(rf.view(np.int64)).cuda()
+        if same:
+            ct, co = rt, ro
+        else:
+            cf, co = pkg.matrix.csr_from_sketches(cols)
+            ct = torch.from_numpy(cf.view(np.int64)).cuda()
+        tune = rng.choice([dict(), dict(), dict(route="tiled", visit_all_tiles=True), dict(route="tiled", use_symmetry=False)])
+        with pkg.matrix.tuning(**tune):
+            out = pkg.matrix.compare_block_dev(rt, ro, ct, co, num, want=("jaccard", "common", "size"))
+            st = pkg.matrix.last_stats()
+        common, size, jac = coracle.compare_matrix(rows, cols, num, 31, 0 if num else 1 << 62)
+        if st["route"] != "tiled" or not ((out["common"].cpu().numpy().view(np.uint64) == common).all()
+                                          and (out["size"].cpu().numpy().view(np.uint64) == size).all()
+                                          and (out["jaccard"].cpu().numpy() == jac).all()):
+            print("BIG COMPARE MISMATCH", nrow, ncol, width, num, same, ragged, tune, st)
+            sys.exit(1)
+        n_cmp += 1
     else:
         uni = np.unique(np.array([rng.getrandbits(63) for _ in range(rng.choice([50, 2000, 20000]))], dtype=np.uint64))
         nrow, ncol = rng.randint(1, 90), rng.randint(1, 140)
@@ -212,7 +245,11 @@ while time.time() < t_end:
         if rng.random() < 0.25:        # all-vs-all of one list (symmetric when the nums agree)
             gc, oc, cols, ncol = gm, om, rows, nrow
         want_cc = rng.random() < 0.6   # without count_common the kernels take their early-exit instantiation
-        out = pkg.matrix.compare_block(gm, gc, want=("jaccard", "common", "size") + (("count_common",) if want_cc else ()))
+        # any way the block can be served must give the same numbers (smh_compare_set_tuning)
+        tune = rng.choice([dict(), dict(), dict(route="components"), dict(route="tiled"), dict(route="tiled", visit_all_tiles=True),
+                           dict(route="tiled", visit_all_tiles=True, use_symmetry=False), dict(comp_pairs_limit=0)])
+        with pkg.matrix.tuning(**tune):
+            out = pkg.matrix.compare_block(gm, gc, want=("jaccard", "common", "size") + (("count_common",) if want_cc else ()))
         for i in range(nrow):
             for j in range(ncol):
                 c, s_ = om[i].intersection_size(oc[j])

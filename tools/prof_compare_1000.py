@@ -7,11 +7,16 @@ from __graft_entry__ import load_package
 pkg = load_package()
 from sourmash_rust_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+mode = sys.argv[2] if len(sys.argv) > 2 else "families"      # families | one_component | all_tiles | nosym
 sigs = synth.family_signatures(0, n, num=2000, seed=3)
+if mode == "one_component":
+    sigs[:, 0] = 1                                            # a contaminant hash shared by every signature
+tune = {"all_tiles": dict(route="tiled", visit_all_tiles=True), "nosym": dict(route="tiled", visit_all_tiles=True, use_symmetry=False)}.get(mode, {})
 t = torch.from_numpy(sigs.view(np.int64)).cuda()
 off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
-for it in range(12):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard",))
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("n=%d: %.3f ms per matrix (%.1f M pairs/s)" % (n, dt * 1e3, n * n / dt / 1e6))
+with pkg.matrix.tuning(**tune):
+    for it in range(12):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard",))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("n=%d %s: %.3f ms per matrix (%.1f M pairs/s) %s" % (n, mode, dt * 1e3, n * n / dt / 1e6, pkg.matrix.last_stats()))
