@@ -25,6 +25,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device.hpp"
 #include "kernels.hpp"
@@ -140,7 +141,7 @@ __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ sta
 __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 
 // ---------------------------------------------------------------------------------
-// DNA arm, rolling 2-bit windows, ksize <= 64
+// DNA arm, rolling 2-bit windows, ksize <= 128
 // Product tables.  A k-mer reaches murmur as 8-byte words of ASCII letters, and the first thing
 // murmur does with a word is multiply it by c1 (k1 words) or c2 (k2 words).  Multiplication
 // distributes over the word's two 4-letter halves,  w*c = lo*c + ((hi*c) << 32)  (mod 2^64), and a
@@ -148,30 +149,83 @@ __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <=
 // kernel already holds: P1[i] = ascii4(i)*c1, P2[i] = ascii4(i)*c2 as u64 (the high half of a word
 // needs only the low dword of the entry), plus one small table for the k-mer's last, partial group
 // of letters.  This replaces the digit -> ASCII table AND a third of the 64-bit multiplies.
-constexpr int kLutReplicas = 2;                              // lane l uses replica l & 1 (1, 2: 37.8 ms; 4, 8: 39.7; 16: 50.5 -- LDS size, not bank conflicts, is what matters)
+// One copy of the tables per workgroup: replicas (per lane parity ... per 16 lanes) were measured
+// and never paid (1, 2: 37.8 ms; 4, 8: 39.7; 16: 50.5 per 10 GB) -- with one copy the entry address
+// is (digits << 3) plus an immediate, two full-rate instructions per group.
 constexpr int kLutEntries = 256 + 256 + 64 + 1;              // P1, P2, partial group, one zero entry (groups past the k-mer)
-constexpr int kLutDwords = kLutEntries * kLutReplicas * 2;   // u64 entries: 9 KiB
+constexpr int kLutDwords = kLutEntries * 2;                  // u64 entries: 4.5 KiB
 
+// The hash runs on explicit 32-bit halves.  Issue rates on gfx950 (tools/instr_rate.hip,
+// profiles/r01_instr_rates.txt): two-operand VALU forms ~100 lanes/clk/CU, everything with three
+// operands (v_alignbit, v_add3, v_lshl_add, v_bfe, v_perm), every 32-bit multiply and v_mad_u64_u32
+// ~59 -- so the code below is written to need few of the latter: a 64 x 64 -> 64 multiply by a
+// constant is one v_mad_u64_u32 + two v_mul_lo_u32 + one v_add3, a 64-bit rotate two v_alignbit,
+// `k ^= k >> 33` two plain ops on the halves, and nothing is zero-extended into register pairs.
+struct W2 { uint32_t lo, hi; };
+__device__ __forceinline__ W2 w2_rotl(W2 x, int r) {   // 0 < r < 64, r != 32
+  if (r < 32) return {__builtin_amdgcn_alignbit(x.lo, x.hi, 32 - r), __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - r)};
+  return {__builtin_amdgcn_alignbit(x.hi, x.lo, 64 - r), __builtin_amdgcn_alignbit(x.lo, x.hi, 64 - r)};
+}
+__device__ __forceinline__ W2 w2_mul(W2 x, uint64_t c) {
+  const uint32_t cl = (uint32_t)c, ch = (uint32_t)(c >> 32);
+  // three v_mad_u64_u32 and one add: t = x.hi*cl; u = x.lo*ch + t (its low dword is the whole cross
+  // term); p = x.lo*cl; high dword = p.hi + u.lo.  (The compiler's own choice -- one v_mad_u64_u32,
+  // two v_mul_lo_u32 and a v_add3 -- is four half-rate instructions; measured 32.6 -> 32.0 ms per 10 GB.)
+  uint64_t t, u, p, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(t), "=s"(cy) : "v"(x.hi), "s"(cl));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(u), "=s"(cy) : "v"(x.lo), "s"(ch), "v"(t));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(cy) : "v"(x.lo), "s"(cl));
+  return {(uint32_t)p, (uint32_t)(p >> 32) + (uint32_t)u};
+}
+__device__ __forceinline__ W2 w2_xor(W2 a, W2 b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
+// 64-bit values the compiler must treat as whole register pairs (an empty asm hides how they were
+// put together): otherwise it splits a + b into zero-extended halves, moves and a v_add3
+__device__ __forceinline__ uint64_t w2_pair(W2 a) {
+  uint64_t v = ((uint64_t)a.hi << 32) | a.lo;
+  asm("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ W2 w2_split(uint64_t v) { return {(uint32_t)v, (uint32_t)(v >> 32)}; }
+__device__ __forceinline__ W2 w2_add(W2 a, W2 b) { return w2_split(w2_pair(a) + w2_pair(b)); }   // one v_lshl_add_u64
+// x * 5 + c as (x << 2) + x, then + c: two v_lshl_add_u64
+__device__ __forceinline__ W2 w2_mul5_add(W2 x, uint64_t c) {
+  const uint64_t v = w2_pair(x);
+  uint64_t t;
+  asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(t) : "v"(v));   // (left to itself the compiler multiplies by 5: two v_mad_u64_u32 and two moves)
+  return w2_split(t + c);
+}
+__device__ __forceinline__ W2 w2_fmix(W2 k) {
+  k.lo ^= k.hi >> 1;                                   // k ^= k >> 33
+  k = w2_mul(k, 0xff51afd7ed558ccdULL);
+  k.lo ^= k.hi >> 1;
+  k = w2_mul(k, 0xc4ceb9fe1a85ec53ULL);
+  k.lo ^= k.hi >> 1;
+  return k;
+}
 // murmur64 from premultiplied words: M[w] = word_w * (w even ? c1 : c2)
 template <int L>
-__device__ __forceinline__ uint64_t murmur_kmer_pre(const uint64_t (&M)[2 * L], int K, uint64_t seed) {
-  uint64_t h1 = seed, h2 = seed;
+__device__ __forceinline__ uint64_t murmur_kmer_pre(const W2 (&M)[2 * L], int K, uint64_t seed) {
+  W2 h1{(uint32_t)seed, (uint32_t)(seed >> 32)}, h2 = h1;
   const int nblocks = K >> 4, tail = K & 15;
 #pragma unroll
   for (int blk = 0; blk < L; blk++) {
-    const uint64_t k1 = rotl64(M[2 * blk], 31) * kC2;       // rest of mix_k1
-    const uint64_t k2 = rotl64(M[2 * blk + 1], 33) * kC1;   // rest of mix_k2
     if (blk < nblocks) {
-      h1 ^= k1;
-      h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-      h2 ^= k2;
-      h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+      h1 = w2_xor(h1, w2_mul(w2_rotl(M[2 * blk], 31), kC2));        // rest of mix_k1
+      // (rotl(h1, 27) + h2) * 5 + c; in the first block h2 is still the seed: rotl * 5 + (seed * 5 + c)
+      if (blk == 0) h1 = w2_mul5_add(w2_rotl(h1, 27), seed * 5 + 0x52dce729u);
+      else h1 = w2_mul5_add(w2_add(w2_rotl(h1, 27), h2), 0x52dce729u);
+      h2 = w2_xor(h2, w2_mul(w2_rotl(M[2 * blk + 1], 33), kC1));    // rest of mix_k2
+      h2 = w2_mul5_add(w2_add(w2_rotl(h2, 31), h1), 0x38495ab5u);
     } else if (blk == nblocks) {
-      if (tail > 8) h2 ^= k2;
-      if (tail > 0) h1 ^= k1;
+      if (tail > 8) h2 = w2_xor(h2, w2_mul(w2_rotl(M[2 * blk + 1], 33), kC1));
+      if (tail > 0) h1 = w2_xor(h1, w2_mul(w2_rotl(M[2 * blk], 31), kC2));
     }
   }
-  return mm3_finish(h1, h2, (uint64_t)K);
+  h1.lo ^= (uint32_t)K; h2.lo ^= (uint32_t)K;          // ^= len (K <= 128)
+  h1 = w2_add(h1, h2); h2 = w2_add(h2, h1);
+  h1 = w2_fmix(h1); h2 = w2_fmix(h2);
+  const W2 r = w2_add(h1, h2);                         // first word of the digest
+  return ((uint64_t)r.hi << 32) | r.lo;
 }
 
 // KT > 0: ksize fixed at compile time; KT == 0: any ksize the limb count allows, at run time.
@@ -180,13 +234,22 @@ __device__ __forceinline__ uint64_t murmur_kmer_pre(const uint64_t (&M)[2 * L], 
 // block (independent murmur chains the scheduler can interleave).
 // PR: thresholds are looked up per record (hp.thr_rec; grouped bottom-num batches) instead of the
 // launch-uniform hp.thr
+//
+// Bookkeeping.  A lane walks its bases four at a time (one dword of the tile).  A group of four is
+// CLEAN when all four bases are ACGT, none lies outside the current record's valid part, and all four
+// windows that end in it are complete and belong to the lane's run: then there is nothing to decide
+// per base.  One unsigned compare tells (g_span), and only groups that are not clean -- the first
+// one of a run, the ones around a record boundary or a non-ACGT byte, the last one -- take the
+// per-base path below, which produces a 4-bit mask of the windows that may be emitted.
 template <int KT, int THREADS, int HB, int L, bool PR = false>
 __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
                                                          int logR, uint32_t stage_cap) {
-  // LDS: [product tables 9 KiB][staged candidates: count, hashes, positions][sequence tile]
+  // LDS: static: the product tables (4.5 KiB; a compile-time address, so a table read is one
+  // ds_read with the table's base as its immediate offset); dynamic: [staged candidates: count,
+  // hashes, positions][sequence tile]
+  __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* lut = smem;
-  uint32_t* st_ctl = smem + kLutDwords;                       // [0] = count, [2..3] = flush base
+  uint32_t* st_ctl = smem;                                    // [0] = count, [2..3] = flush base
   uint64_t* st_hash = reinterpret_cast<uint64_t*>(st_ctl + 4);
   uint64_t* st_pos = st_hash + stage_cap;
   uint32_t* tile = reinterpret_cast<uint32_t*>(st_pos + (sink.pos ? stage_cap : 0));
@@ -206,39 +269,40 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
   const int top_limb = (2 * K - 2) >> 5, top_sh = (2 * K - 2) & 31;
   const bool multi = b.starts != nullptr;
 
-  // product tables (see kLutEntries): entry e of replica r at u64 index e * kLutReplicas + r.
+  // product tables (see kLutEntries): entry e at u64 index e.
   // digit d -> "ACGT"[d], first digit in the low byte; the partial group holds the k-mer's last
   // K mod 4 letters (its multiplier follows the parity of the word it belongs to)
   const int g_last = (K - 1) >> 2, nb_last = K - 4 * g_last;      // nb_last == 4: no partial group
   const uint64_t c_last = ((g_last >> 1) & 1) ? kC2 : kC1;
   uint64_t* ptab = reinterpret_cast<uint64_t*>(lut);
-  for (int e = tid; e < kLutEntries * kLutReplicas; e += THREADS) {
-    const uint32_t ent = (uint32_t)e / kLutReplicas;
+  for (int e = tid; e < kLutEntries; e += THREADS) {
+    const uint32_t ent = (uint32_t)e;
     const uint32_t idx = ent & 255u;
     const int nb = ent < 512 ? 4 : (ent < 576 ? nb_last : 0);
     uint32_t v = 0;
     for (int j = 0; j < nb; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
     ptab[e] = (uint64_t)v * (ent < 256 ? kC1 : (ent < 512 ? kC2 : c_last));
   }
-  // run-time k: table base and digit mask of every 4-letter group, fixed for the launch, so that
-  // the per-k-mer code below is the same straight line as for a compile-time k
-  uint32_t gbase[4 * L], gmask[4 * L];
+  // table base (bytes) and digit mask (already scaled by the 8-byte entry size) of every 4-letter
+  // group: compile-time constants for a compile-time k, fixed for the launch otherwise, so that the
+  // per-k-mer code is the same straight line either way
+  uint32_t gbase[4 * L], gmask8[4 * L];
 #pragma unroll
   for (int g = 0; g < 4 * L; g++) {
     const int nb = K - 4 * g;
     uint32_t ent0 = 576u, mask = 0u;                                   // past the k-mer: the zero entry
     if (nb >= 4) { ent0 = ((g >> 1) & 1) ? 256u : 0u; mask = 0xffu; }
     else if (nb > 0) { ent0 = 512u; mask = (1u << (2 * nb)) - 1u; }
-    gbase[g] = ent0 * (kLutReplicas * 8);
-    gmask[g] = mask;
+    gbase[g] = ent0 * 8u;
+    gmask8[g] = mask << 3;
   }
-  const uint32_t lut_lane = (uint32_t)(tid & (kLutReplicas - 1)) << 3;  // byte offset of my replica
   if (tid == 0) st_ctl[0] = 0;
 
   const uint64_t span = hp.range_hi - hp.range_lo;
   const uint64_t ntiles = (span + TILE - 1) / TILE;
   const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
   const uint32_t nsteps = (R + (uint32_t)K - 1 + 3) & ~3u;  // bases walked per lane, multiple of 4
+  const uint32_t warm_end = K > 4 ? ((uint32_t)(K - 1) & ~3u) : 0u;   // groups [0, warm_end) end before any window is complete
 
   for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const uint64_t T0 = hp.range_lo + tix * TILE;
@@ -264,9 +328,10 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     const uint64_t p0 = T0 + ((uint64_t)tid << logR);  // my first k-mer start position
     if (p0 < hp.range_hi) {
     const uint32_t nk = (hp.range_hi - p0) < R ? (uint32_t)(hp.range_hi - p0) : R;
+    const uint32_t hi_ok = nk + (uint32_t)K - 1;        // base index i ends a window of my run iff K-1 <= i < hi_ok
 
     // record bookkeeping: `lim` = index of the first base of my run that is not inside the
-    // current record's valid part; the per-base test is one compare.
+    // current record's valid part
     uint32_t rec = 0;
     uint64_t cur_end = b.vend0;
     if (multi) {
@@ -276,19 +341,34 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     }
     uint32_t lim = 0;
     if (cur_end > p0) lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
+    uint32_t vstart = 0;      // first base of the run of valid bases that reaches the current base
+    // clean groups: g_lo <= i0 < g_lo + g_span  (see the kernel comment)
+    uint32_t g_lo = 0, g_span = 0;
+    auto set_clean_window = [&](bool warm) {
+      const uint32_t lim2 = warm ? lim : (lim < hi_ok ? lim : hi_ok);
+      g_lo = warm ? vstart : vstart + (uint32_t)K - 1;   // warm-up groups emit nothing: only validity matters
+      g_span = lim2 >= g_lo + 4 ? lim2 - 3 - g_lo : 0u;
+    };
 
-    uint32_t x = (m & ~3u) + ((uint32_t)tid << logR);
+    // tile address of the lane's current dword: one pad dword per R bytes; the running form adds 4
+    // per group, and 4 more when the group crosses a multiple of R -- which it does for every lane
+    // of the workgroup at once (lane runs start R apart), so the increment is a scalar
+    const uint32_t xu = m & ~3u;                                     // uniform part of the lane's byte index
+    uint32_t ta = xu + ((uint32_t)tid << logR);
+    ta = ta + ((ta >> logR) << 2);                                   // byte offset in the padded tile
     const uint32_t sh = m & 3u;
-    uint32_t cur = tile[(x >> 2) + (x >> logR)];
+    uint32_t cur = tile[ta >> 2];
     // forward k-mer as 2-bit digits in L limbs: fbe = first base most significant, fle = first base least
     uint32_t fbe[L], fle[L];
 #pragma unroll
     for (int i = 0; i < L; i++) { fbe[i] = 0; fle[i] = 0; }
-    uint32_t vrun = 0;  // consecutive valid bases ending here
 
-    for (uint32_t i0 = 0; i0 < nsteps; i0 += 4) {
-      x += 4;
-      const uint32_t nxt = tile[(x >> 2) + (x >> logR)];
+    // one group of four bases; hashing = false for the warm-up groups
+    auto group = [&](uint32_t i0, auto hashing) {
+      constexpr bool kHash = decltype(hashing)::value;
+      const uint32_t xn = xu + i0 + 4;                               // uniform: byte index of the next dword
+      ta += (xn & (R - 1)) == 0 ? 8u : 4u;
+      const uint32_t nxt = tile[ta >> 2];
       const uint32_t d = __builtin_amdgcn_alignbyte(nxt, cur, sh);
       cur = nxt;
       // four bases at once: upper-case, 2-bit code (A0 C1 G2 T3), validity by re-encoding
@@ -297,29 +377,43 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
       const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
       const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
       const uint32_t diff4 = u4 ^ exp4;
+      uint32_t okmask = 0xFu;                                        // windows ending at base q that may be emitted
+      uint64_t tq[4];                                                // PR only: the threshold in force at each base
+      if (PR) { tq[0] = lthr; tq[1] = lthr; tq[2] = lthr; tq[3] = lthr; }
+      if (!(diff4 == 0 && i0 - g_lo < g_span)) {
+        // ---- not clean (rare): base by base, exactly the reference's conditions
+        okmask = 0;
 #pragma unroll
-      for (int g0b = 0; g0b < 4; g0b += HB) {
-        uint32_t X[HB][L];
-        bool ok[HB];
-        uint64_t tq[PR ? HB : 1];   // PR: the threshold in force at each of the HB bases
-#pragma unroll
-        for (int q = 0; q < HB; q++) {
-          const int bb = g0b + q;
-          const uint32_t i = i0 + bb;
-          const uint32_t code = (code4 >> (8 * bb)) & 3u;
-          uint32_t bad = (diff4 >> (8 * bb)) & 0xffu;
+        for (int q = 0; q < 4; q++) {
+          const uint32_t i = i0 + q;
+          uint32_t bad = (diff4 >> (8 * q)) & 0xffu;
           if (i >= lim) {
             // at or past the end of the record's valid part: find where base p0+i belongs
             const uint64_t qpos = p0 + i;
             if (multi) {
-              while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vrun = 0; }
+              while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vstart = i; }
               cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
               if (PR) lthr = hp.thr_rec[rec];
             }
             if (qpos >= cur_end) { bad = 1; lim = i + 1; }
             else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
           }
-          vrun = bad ? 0u : vrun + 1u;
+          if (bad) vstart = i + 1;
+          if (kHash) {
+            const bool ok = (i + 1 >= vstart + (uint32_t)K) && (i < hi_ok);
+            okmask |= ok ? (1u << q) : 0u;
+            if (PR) tq[q] = lthr;
+          }
+        }
+        set_clean_window(!kHash);
+      }
+#pragma unroll
+      for (int g0b = 0; g0b < 4; g0b += HB) {
+        uint32_t X[HB][L];
+#pragma unroll
+        for (int q = 0; q < HB; q++) {
+          const int bb = g0b + q;
+          const uint32_t code = (code4 >> (8 * bb)) & 3u;
           // fbe = ((fbe << 2) | code) & MASK ; fle = (fle >> 2) | code << (2K-2)   (limb-wise)
 #pragma unroll
           for (int li = L - 1; li > 0; li--) fbe[li] = __builtin_amdgcn_alignbit(fbe[li], fbe[li - 1], 30) & MASK[li];
@@ -330,51 +424,81 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
 #pragma unroll
           for (int li = 0; li < L; li++)
             if (li == top_limb) fle[li] |= code << top_sh;
-          // canonical strand: the reverse complement with ITS first base most significant is ~fle;
-          // fwd < rc decided from the top limb down
-          bool fwd = false;
-          if (L == 2) {
-            fwd = (((uint64_t)fbe[1] << 32) | fbe[0]) <
-                  (((uint64_t)(~fle[1] & MASK[1]) << 32) | (~fle[0] & MASK[0]));
-          } else {
-            bool decided = false;
+          if (kHash) {
+            // canonical strand: the reverse complement with ITS first base most significant is ~fle;
+            // fwd < rc decided from the top limb down
+            bool fwd = false;
+            if (L == 2) {
+              fwd = (((uint64_t)fbe[1] << 32) | fbe[0]) <
+                    (((uint64_t)(~fle[1] & MASK[1]) << 32) | (~fle[0] & MASK[0]));
+            } else {
+              bool decided = false;
 #pragma unroll
-            for (int li = L - 1; li >= 0; li--) {
-              const uint32_t f = fbe[li], r = ~fle[li] & MASK[li];
-              if (!decided && f != r) { fwd = f < r; decided = true; }
+              for (int li = L - 1; li >= 0; li--) {
+                const uint32_t f = fbe[li], r = ~fle[li] & MASK[li];
+                if (!decided && f != r) { fwd = f < r; decided = true; }
+              }
             }
-          }
 #pragma unroll
-          for (int li = 0; li < L; li++) X[q][li] = fwd ? fle[li] : ~fbe[li];  // chosen strand, first base low
-          ok[q] = (vrun >= (uint32_t)K) && (i + 1 >= (uint32_t)K) && (i + 1 - (uint32_t)K < nk);
-          if (PR) tq[q] = lthr;
+            for (int li = 0; li < L; li++) X[q][li] = fwd ? fle[li] : ~fbe[li];  // chosen strand, first base low
+          }
         }
-        if (i0 + g0b + HB >= (uint32_t)K) {  // uniform: past the warm-up bases
+        if (kHash && i0 + g0b + HB >= (uint32_t)K) {  // uniform: some window of this block is complete
           uint64_t h[HB];
 #pragma unroll
           for (int q = 0; q < HB; q++) {
-            uint64_t M[2 * L];
+            W2 M[2 * L];
 #pragma unroll
-            for (int wi = 0; wi < 2 * L; wi++) M[wi] = 0;
+            for (int wi = 0; wi < 2 * L; wi++) M[wi] = W2{0u, 0u};
 #pragma unroll
             for (int g = 0; g < 4 * L; g++) {
               if (KT == 0 || 4 * g < K) {
-                const uint32_t idx = (X[q][g >> 2] >> (8 * (g & 3))) & gmask[g];   // digits of this group that belong to the k-mer
-                // table entry: P1 / P2 by word parity, the partial table, or (run-time k only) the zero entry
-                const char* at = reinterpret_cast<const char*>(lut) + ((gbase[g] + idx * (kLutReplicas * 8)) | lut_lane);
-                if ((g & 1) == 0) M[g >> 1] = *reinterpret_cast<const uint64_t*>(at);                       // low half: full product
-                else M[g >> 1] += (uint64_t)(*reinterpret_cast<const uint32_t*>(at)) << 32;                // high half: low dword only
+                // byte offset of the group's table entry: its digits << 3 (entries are u64), masked to
+                // the digits that belong to the k-mer; P1 / P2 by word parity, the partial table, or
+                // (run-time k only) the zero entry
+                const uint32_t xw = X[q][g >> 2];
+                const int sb = 8 * (g & 3) - 3;
+                uint32_t off;
+                if (KT != 0 && K - 4 * g >= 4) {
+                  // a whole group of four letters: byte (g & 3) of the limb, times 8, in ONE sub-dword-addressed
+                  // shift (SDWA issues at full rate on gfx950: 32.0 -> 30.8 ms per 10 GB)
+                  if ((g & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(xw));
+                  else if ((g & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(xw));
+                  else if ((g & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(xw));
+                  else asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(xw));
+                } else {
+                  off = sb < 0 ? xw << 3 : xw >> sb;
+                  asm("" : "+v"(off));                                 // shift, then mask: two full-rate ops (not v_bfe + v_lshl_add)
+                  off &= gmask8[g];
+                }
+                const char* at = reinterpret_cast<const char*>(lut) + gbase[g] + off;
+                if ((g & 1) == 0) {                                  // low half of the word: full product
+                  const uint2 e = *reinterpret_cast<const uint2*>(at);
+                  M[g >> 1] = W2{e.x, e.y};
+                } else {
+                  M[g >> 1].hi += *reinterpret_cast<const uint32_t*>(at);   // high half: (entry << 32), low dword only
+                }
               }
             }
             h[q] = murmur_kmer_pre<L>(M, K, hp.seed);
           }
 #pragma unroll
           for (int q = 0; q < HB; q++)
-            if (ok[q] && h[q] <= (PR ? tq[q] : thr))
-              stage_emit(stage, sink, h[q], hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K));
+            if (h[q] <= (PR ? tq[g0b + q] : thr)) {       // ~1 in `scaled` windows gets here
+              uint32_t om = okmask;
+              asm volatile("" : "+v"(om));                  // keeps the mask test inside this rare block
+              if ((om >> (g0b + q)) & 1u)
+                stage_emit(stage, sink, h[q], hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K));
+            }
         }
       }
-    }
+    };
+
+    set_clean_window(true);
+    uint32_t i0 = 0;
+    for (; i0 < warm_end; i0 += 4) group(i0, std::false_type{});
+    set_clean_window(false);
+    for (; i0 < nsteps; i0 += 4) group(i0, std::true_type{});
     }  // p0 < range_hi
 
     // ---- flush the staged candidates: ONE global atomic per tile, coalesced stores
@@ -811,16 +935,19 @@ inline int grid_for(uint64_t items, int per_block, int cap) {
 // ---------------------------------------------------------------------------------
 // launchers
 
-// launch geometry of the rolling kernel (override for experiments: SOURMASH_AMD_DNA_CFG="threads,logR,hb")
+// launch geometry of the rolling kernel: 512 lanes, runs of 128 positions, two hashes per block.
+// Other geometries exist only in experiment builds (-DSMH_EXPERIMENTS, SOURMASH_AMD_DNA_CFG="threads,logR,hb").
 struct DnaCfg { int threads, logR, hb; };
 static DnaCfg dna_cfg() {
   static DnaCfg cfg = [] {
     DnaCfg c{512, 7, 2};
+#ifdef SMH_EXPERIMENTS
     if (const char* e = std::getenv("SOURMASH_AMD_DNA_CFG")) {
       int t = 0, r = 0, h = 0;
       if (sscanf(e, "%d,%d,%d", &t, &r, &h) == 3 && (t == 256 || t == 512) && r >= 5 && r <= 7 &&
           (h == 1 || h == 2 || h == 4)) c = DnaCfg{t, r, h};
     }
+#endif
     return c;
   }();
   return cfg;
@@ -834,8 +961,13 @@ static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSin
     hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
     return;
   }
+#ifdef SMH_EXPERIMENTS
   if (c.threads == 512) { if (c.hb == 4) SMH_LAUNCH(512, 4); else if (c.hb == 2) SMH_LAUNCH(512, 2); else SMH_LAUNCH(512, 1); }
   else { if (c.hb == 4) SMH_LAUNCH(256, 4); else if (c.hb == 2) SMH_LAUNCH(256, 2); else SMH_LAUNCH(256, 1); }
+#else
+  (void)c;
+  SMH_LAUNCH(512, 2);
+#endif
 #undef SMH_LAUNCH
 }
 
@@ -861,7 +993,7 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     long double expect = (long double)tile * (((long double)thr + 1.0L) / 18446744073709551616.0L);
     uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
     if (stage_cap < 128) stage_cap = 128;
-    const size_t lds = (size_t)kLutDwords * 4 + 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes +
+    const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes +   // dynamic part; the tables are static LDS
                        4 * ((x_bytes >> logR) + 2);
     if (p.ksize == 31) launch_rolling<31, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     else if (p.ksize == 21) launch_rolling<21, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
