@@ -358,10 +358,16 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     ta = ta + ((ta >> logR) << 2);                                   // byte offset in the padded tile
     const uint32_t sh = m & 3u;
     uint32_t cur = tile[ta >> 2];
-    // forward k-mer as 2-bit digits in L limbs: fbe = first base most significant, fle = first base least
-    uint32_t fbe[L], fle[L];
+    // two rolled windows of 2-bit digits in L limbs.  fle: the forward k-mer, first base least
+    // significant.  cf: the COMPLEMENT of the forward k-mer, first base most significant -- which is
+    // the reverse complement with ITS first base least significant.  Both candidates for the hashed
+    // strand are therefore at hand as they are (first base low), and the reference's `kmer < rc`
+    // (src/lib.rs:263; ASCII order A<C<G<T equals digit order) needs no complementing either: with
+    // M = 4^k - 1, forward read first-base-most-significant is M - cf and the reverse complement read
+    // that way is M - fle, so  kmer < rc  <=>  M - cf < M - fle  <=>  fle < cf.
+    uint32_t cf[L], fle[L];
 #pragma unroll
-    for (int i = 0; i < L; i++) { fbe[i] = 0; fle[i] = 0; }
+    for (int i = 0; i < L; i++) { cf[i] = 0; fle[i] = 0; }
 
     // one group of four bases; hashing = false for the warm-up groups
     auto group = [&](uint32_t i0, auto hashing) {
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
       const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
       const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
       const uint32_t diff4 = u4 ^ exp4;
+      const uint32_t ccode4 = code4 ^ 0x03030303u;                   // complement digits
       uint32_t okmask = 0xFu;                                        // windows ending at base q that may be emitted
       uint64_t tq[4];                                                // PR only: the threshold in force at each base
       if (PR) { tq[0] = lthr; tq[1] = lthr; tq[2] = lthr; tq[3] = lthr; }
@@ -414,10 +421,11 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
         for (int q = 0; q < HB; q++) {
           const int bb = g0b + q;
           const uint32_t code = (code4 >> (8 * bb)) & 3u;
-          // fbe = ((fbe << 2) | code) & MASK ; fle = (fle >> 2) | code << (2K-2)   (limb-wise)
+          const uint32_t ccode = (ccode4 >> (8 * bb)) & 3u;
+          // cf = ((cf << 2) | (3 - code)) & MASK ; fle = (fle >> 2) | code << (2K-2)   (limb-wise)
 #pragma unroll
-          for (int li = L - 1; li > 0; li--) fbe[li] = __builtin_amdgcn_alignbit(fbe[li], fbe[li - 1], 30) & MASK[li];
-          fbe[0] = ((fbe[0] << 2) | code) & MASK[0];
+          for (int li = L - 1; li > 0; li--) cf[li] = __builtin_amdgcn_alignbit(cf[li], cf[li - 1], 30) & MASK[li];
+          cf[0] = ((cf[0] << 2) | ccode) & MASK[0];
 #pragma unroll
           for (int li = 0; li < L - 1; li++) fle[li] = __builtin_amdgcn_alignbit(fle[li + 1], fle[li], 2);
           fle[L - 1] >>= 2;
@@ -425,22 +433,20 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
           for (int li = 0; li < L; li++)
             if (li == top_limb) fle[li] |= code << top_sh;
           if (kHash) {
-            // canonical strand: the reverse complement with ITS first base most significant is ~fle;
-            // fwd < rc decided from the top limb down
+            // canonical strand: kmer < rc  <=>  fle < cf (see above), decided from the top limb down
             bool fwd = false;
             if (L == 2) {
-              fwd = (((uint64_t)fbe[1] << 32) | fbe[0]) <
-                    (((uint64_t)(~fle[1] & MASK[1]) << 32) | (~fle[0] & MASK[0]));
+              fwd = (((uint64_t)fle[1] << 32) | fle[0]) < (((uint64_t)cf[1] << 32) | cf[0]);
             } else {
               bool decided = false;
 #pragma unroll
               for (int li = L - 1; li >= 0; li--) {
-                const uint32_t f = fbe[li], r = ~fle[li] & MASK[li];
+                const uint32_t f = fle[li], r = cf[li];
                 if (!decided && f != r) { fwd = f < r; decided = true; }
               }
             }
 #pragma unroll
-            for (int li = 0; li < L; li++) X[q][li] = fwd ? fle[li] : ~fbe[li];  // chosen strand, first base low
+            for (int li = 0; li < L; li++) X[q][li] = fwd ? fle[li] : cf[li];  // chosen strand, first base low
           }
         }
         if (kHash && i0 + g0b + HB >= (uint32_t)K) {  // uniform: some window of this block is complete
@@ -459,9 +465,10 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
                 const uint32_t xw = X[q][g >> 2];
                 const int sb = 8 * (g & 3) - 3;
                 uint32_t off;
-                if (KT != 0 && K - 4 * g >= 4) {
-                  // a whole group of four letters: byte (g & 3) of the limb, times 8, in ONE sub-dword-addressed
-                  // shift (SDWA issues at full rate on gfx950: 32.0 -> 30.8 ms per 10 GB)
+                if (KT != 0) {
+                  // compile-time k: byte (g & 3) of the limb, times 8, in ONE sub-dword-addressed shift (SDWA
+                  // issues at full rate on gfx950: 32.0 -> 30.8 ms per 10 GB).  The last, partial group needs no
+                  // mask: both windows are zero above their 2k bits.
                   if ((g & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(xw));
                   else if ((g & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(xw));
                   else if ((g & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(xw));
