@@ -66,6 +66,15 @@ void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* s
 void launch_translate(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t nseg, uint64_t total, uint32_t ksize,
                       uint8_t* residues, uint32_t* bad_utf8, hipStream_t s);
 
+// Protein arm in ONE pass over the DNA (translation + hashing, no residue buffer): every window of
+// `win` residues of the six frames whose position in the six-frame layout (seg_offsets, as above)
+// lies in [p.range_lo, p.range_hi) -- range_hi == ~0 means "all".  b.vend0 (single record) must be 0
+// when the record is shorter than p.ksize.  *high_flag is OR-ed with 1 when the batch holds a byte
+// >= 0x80: the result must then be discarded and the two-pass path taken (UTF-8 panic semantics).
+// Returns false (nothing launched) for window lengths it has no instantiation for.
+bool launch_protein_fused(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t win, const HashParams& p,
+                          const CandSink& sink, uint32_t* high_flag, Device& dev, hipStream_t s);
+
 // hashes[lo..hi) that are <= thr go to the sink with their index as stream position
 // (bulk add_many, reference src/lib.rs:412-417)
 void launch_filter_hashes(const uint64_t* hashes, const HashParams& p, const CandSink& sink, hipStream_t s);

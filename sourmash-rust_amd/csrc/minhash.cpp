@@ -277,20 +277,52 @@ struct DnaSource : HashSource {
   }
 };
 
+// The protein arm.  A launch over the WHOLE position space takes the fused kernel (one pass over
+// the DNA, no residue buffer); if that kernel met a byte >= 0x80 (where the reference's
+// str::from_utf8 may panic) its output is discarded and the launch is repeated on the two-pass path
+// -- k_translate into E.resbuf (done once, on first need) + k_hash_windows -- which also serves
+// launches over a part of the position space and window lengths the fused kernel has no
+// instantiation for.
 struct ProteinSource : HashSource {
-  const uint8_t* res = nullptr;
-  const uint64_t* seg_off = nullptr;
+  SeqBatch b;
+  std::vector<uint64_t> seg;           // host copy of the segment table (6 frames per record)
+  const uint64_t* seg_off = nullptr;   // device copy
   uint32_t nseg = 0;
   uint64_t total = 0;
-  uint32_t win = 0;
+  uint32_t win = 0, ksize = 0;
   uint64_t seed = 0;
   Device* dev = nullptr;
+  Engine* eng = nullptr;
+  bool* have_error = nullptr;
+  Error* err = nullptr;
+  bool translated = false;
   uint64_t positions() const override { return total; }
+  void translate(hipStream_t s);
   void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
     HashParams p;
-    p.seed = seed; p.thr = thr; p.range_lo = lo; p.range_hi = hi;
+    p.seed = seed; p.thr = thr; p.ksize = ksize;
+    if (!translated && lo == 0 && hi == total) {
+      p.range_lo = 0; p.range_hi = ~0ull;
+      eng->badbuf.ensure(8);
+      uint32_t* flag = eng->badbuf.as<uint32_t>();
+      HIP_CHECK(hipMemsetAsync(flag, 0, 4, s));
+      dev->prof_begin(s);
+      const bool ran = launch_protein_fused(b, seg_off, win, p, sink, flag, *dev, s);
+      if (ran) {
+        dev->prof_end("protein_fused", s);
+        uint32_t high = 0;
+        HIP_CHECK(hipMemcpyAsync(&high, flag, 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (!high) return;
+        HIP_CHECK(hipMemsetAsync(sink.count, 0, 8, s));   // discard: the two-pass path decides what a non-ASCII byte does
+      } else {
+        dev->prof_end("protein_fused_unsupported", s);
+      }
+    }
+    if (!translated) translate(s);
+    p.range_lo = lo; p.range_hi = hi;
     dev->prof_begin(s);
-    launch_hash_windows(res, total, seg_off, nseg, win, p, sink, s);
+    launch_hash_windows(eng->resbuf.as<uint8_t>(), total, seg_off, nseg, win, p, sink, s);
     dev->prof_end("hash_windows", s);
   }
 };
@@ -704,15 +736,14 @@ void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, 
   if (nrec > 1) b.vends = E.vendbuf.as<uint64_t>();
   else b.vend0 = vends[0];
 }
-// Protein arm set-up (reference src/lib.rs:277-301): segment table (6 frames per record), six-frame
-// translation into E.resbuf, and the reference's UTF-8 panic: a codon chunk that is not UTF-8 makes
-// from_utf8().unwrap() panic in that frame -- frames before it were added, it and the rest of the
-// record were not.  Returns false when there is nothing to hash.
+// Protein arm set-up (reference src/lib.rs:277-301): the segment table (6 frames per record) of the
+// six-frame layout that defines the arm's position space.  Returns false when there is nothing to hash.
 bool prepare_protein(const SeqBatch& b, const uint64_t* h_offsets, uint32_t nrec, uint32_t ksize, uint64_t seed, Engine& E,
                      Device& dev, hipStream_t s, ProteinSource* src, bool* have_error, Error* err) {
   const uint32_t aa_k = ksize / 3;
   const uint32_t nseg = 6 * nrec;
-  std::vector<uint64_t> seg(nseg + 1, 0);
+  std::vector<uint64_t>& seg = src->seg;
+  seg.assign(nseg + 1, 0);
   for (uint32_t r = 0; r < nrec; r++) {
     const uint64_t len = h_offsets[r + 1] - h_offsets[r];
     for (uint32_t f = 0; f < 6; f++) {
@@ -725,16 +756,33 @@ bool prepare_protein(const SeqBatch& b, const uint64_t* h_offsets, uint32_t nrec
   if (aa_k == 0) throw_panic("window size must be non-zero");  // aa.windows(0), quirk Q8
   if (total == 0) return false;
   E.segbuf.ensure((size_t)(nseg + 1) * 8);
+  HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
+  src->b = b;
+  if (nrec == 1) src->b.vend0 = (h_offsets[1] - h_offsets[0]) >= ksize ? b.len : 0;
+  src->seg_off = E.segbuf.as<uint64_t>(); src->nseg = nseg;
+  src->total = total; src->win = aa_k; src->ksize = ksize; src->seed = seed; src->dev = &dev; src->eng = &E;
+  src->have_error = have_error; src->err = err; src->translated = false;
+  return true;
+}
+}  // namespace
+
+// Six-frame translation into E.resbuf, and the reference's UTF-8 panic: a codon chunk that is not
+// UTF-8 makes from_utf8().unwrap() panic in that frame -- frames before it were added, it and the
+// rest of the record were not.
+void ProteinSource::translate(hipStream_t s) {
+  Engine& E = *eng;
   E.badbuf.ensure((size_t)nseg * 4);
   E.resbuf.ensure(total + 64);  // k_hash_windows reads whole 8-byte words past the last start
-  HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_CHECK(hipMemsetAsync(E.badbuf.ptr, 0, (size_t)nseg * 4, s));
-  dev.prof_begin(s);
-  launch_translate(b, E.segbuf.as<uint64_t>(), nseg, total, ksize, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);
-  dev.prof_end("translate", s);
+  SeqBatch tb = b;
+  tb.vend0 = b.len;
+  dev->prof_begin(s);
+  launch_translate(tb, seg_off, nseg, total, ksize, E.resbuf.as<uint8_t>(), E.badbuf.as<uint32_t>(), s);
+  dev->prof_end("translate", s);
   std::vector<uint32_t> bad(nseg);
   HIP_CHECK(hipMemcpyAsync(bad.data(), E.badbuf.ptr, (size_t)nseg * 4, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  const uint32_t nrec = nseg / 6;
   for (uint32_t r = 0; r < nrec; r++) {
     for (uint32_t f = 0; f < 6; f++) {
       if (!bad[6 * r + f]) continue;
@@ -747,11 +795,8 @@ bool prepare_protein(const SeqBatch& b, const uint64_t* h_offsets, uint32_t nrec
       break;
     }
   }
-  src->res = E.resbuf.as<uint8_t>(); src->seg_off = E.segbuf.as<uint64_t>(); src->nseg = nseg;
-  src->total = total; src->win = aa_k; src->seed = seed; src->dev = &dev;
-  return true;
+  translated = true;
 }
-}  // namespace
 
 // ------------------------------------------------------------------------------------
 // add_sequence front ends

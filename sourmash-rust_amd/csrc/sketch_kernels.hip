@@ -748,6 +748,322 @@ __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint
   }
 }
 
+// ---------------------------------------------------------------------------------
+// protein arm, fused: translation and hashing in ONE pass over the DNA, no residue buffer.
+//
+// A window of `W` residues of any of the six frames is the translation of 3W consecutive bases --
+// read forward, or read backward and complemented.  Every start position `a` of a record with
+// a + 3W <= length carries exactly one forward window (frame a mod 3) and exactly one
+// reverse-complement window, so the arm is the DNA kernel's walk with k = 3W and TWO hashes per
+// position instead of a canonical choice.  A lane keeps, for each of the three reading frames that
+// pass through its run, the last W residues of the forward translation and of the reverse-complement
+// translation (byte strings in registers).  Each base completes one codon: its six digit bits index a
+// 64-entry LDS table that holds the codon's residue and the residue of its reverse complement; the
+// forward string of that frame shifts down a byte and takes the new residue on top, the
+// reverse-complement string shifts up and takes it at the bottom (reference src/lib.rs:280-300 reads
+// revcomp(sequence) forward, which is the record backward), and both strings are hashed
+// (MurmurHash3 x64_128 of W <= 16 bytes: no full block, k1 and k2 straight from the registers).
+//
+// That covers every window whose 3W bases are all ACGT inside one record.  Windows that SKIP dropped
+// codons (to_aa drops a codon holding anything else and splices its neighbours together, quirk Q8)
+// are rare: the lane notices that a span is not clean with the same group test as the DNA kernel
+// and hands its start position to hash_spliced_windows(), which walks the bytes in global memory
+// exactly like the reference.  A byte >= 0x80 anywhere in the batch (where str::from_utf8 could
+// panic, src/lib.rs:787) raises `high_flag`: the host then discards this launch and takes the
+// two-pass path (k_translate + k_hash_windows), which reproduces the panic semantics.
+//
+// Candidate positions are residue indices of the six-frame layout (segment 6r + 2*frame + strand),
+// the order the reference walks them; seg_off is that layout's segment table.
+
+// record-relative geometry of the two windows that cover bases [a, a + 3W) of record `rec`
+struct WinPos { uint64_t g_fwd, g_rc; };
+__device__ __forceinline__ WinPos window_positions(const uint64_t* __restrict__ seg_off, uint32_t rec, uint64_t a_rel,
+                                                   uint64_t len, uint32_t kb) {
+  const uint32_t f = (uint32_t)(a_rel % 3);
+  const uint64_t rcidx = len - a_rel - kb;                  // index, in revcomp(record), of the window's first base
+  const uint32_t fr = (uint32_t)(rcidx % 3);
+  return {seg_off[6 * (uint64_t)rec + 2 * f] + a_rel / 3, seg_off[6 * (uint64_t)rec + 2 * fr + 1] + rcidx / 3};
+}
+
+__device__ __forceinline__ int dna_digit(uint32_t c) {      // A0 C1 G2 T3 (either case), -1 otherwise
+  const uint32_t u = c & 0xDFu;
+  return u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : -1;
+}
+__device__ __forceinline__ uint32_t aa_of_digits(int d0, int d1, int d2) {
+  // kCodonAA is indexed in T C A G order
+  const int t[4] = {2, 1, 3, 0};
+  return (uint32_t)(uint8_t)kCodonAA[16 * t[d0] + 4 * t[d1] + t[d2]];
+}
+
+// The two windows that START (forward) / whose first residue lies (reverse complement) in the span
+// [a, a + 3W) when that span is not all-ACGT-in-one-record: walk codon by codon, dropping codons
+// that hold anything but ACGT, like to_aa + windows() of the reference (src/lib.rs:779-793, 289-300).
+__device__ __noinline__ void hash_spliced_windows(const SeqBatch& b, const HashParams& hp, const uint64_t* __restrict__ seg_off,
+                                                  uint32_t win, uint64_t a, const CandSink& sink, const Stage& stage) {
+  const uint32_t kb = 3 * win;
+  uint32_t rec = 0;
+  uint64_t rs = 0, re = b.len;
+  if (b.starts) { rec = find_record(b.starts, b.nrec, a); rs = b.starts[rec]; re = b.starts[rec + 1]; }
+  const uint64_t len = re - rs;
+  if (len < hp.ksize || a < rs || a >= re) return;          // reference src/lib.rs:257
+  const uint64_t a_rel = a - rs;
+  // forward: first residue = codon [a, a+3) of frame a_rel % 3, then the following codons of that frame
+  {
+    const uint32_t f = (uint32_t)(a_rel % 3);
+    const uint64_t fend = rs + f + 3 * ((len - f) / 3);     // end of the frame's translated extent
+    Mm3Stream st(hp.seed);
+    uint32_t got = 0;
+    for (uint64_t c = a; c + 3 <= fend && got < win; c += 3) {
+      const int d0 = dna_digit(b.seq[c]), d1 = dna_digit(b.seq[c + 1]), d2 = dna_digit(b.seq[c + 2]);
+      if (d0 < 0 || d1 < 0 || d2 < 0) { if (c == a) break; continue; }   // a window starts at a KEPT residue
+      st.push(aa_of_digits(d0, d1, d2));
+      got++;
+    }
+    if (got == win) {
+      const uint64_t h = st.finish();
+      const uint64_t g = seg_off[6 * (uint64_t)rec + 2 * f] + a_rel / 3;
+      if (h <= hp.thr && g >= hp.range_lo && g < hp.range_hi) stage_emit(stage, sink, h, hp.pos_base + g);
+    }
+  }
+  // reverse complement: first residue = the codon read backward from base a + 3W - 1
+  if (a + kb <= re) {
+    const uint64_t e = a + kb - 1;
+    const uint64_t rcidx = len - 1 - (e - rs);
+    const uint32_t fr = (uint32_t)(rcidx % 3);
+    Mm3Stream st(hp.seed);
+    uint32_t got = 0;
+    for (uint64_t c = e; c >= rs + 2 && got < win; c -= 3) {
+      const int d0 = dna_digit(b.seq[c]), d1 = dna_digit(b.seq[c - 1]), d2 = dna_digit(b.seq[c - 2]);
+      if (d0 < 0 || d1 < 0 || d2 < 0) { if (c == e) break; if (c < 3) break; continue; }
+      st.push(aa_of_digits(3 - d0, 3 - d1, 3 - d2));
+      got++;
+      if (c < 3) break;                                     // (c -= 3 must not wrap)
+    }
+    if (got == win) {
+      const uint64_t h = st.finish();
+      const uint64_t g = seg_off[6 * (uint64_t)rec + 2 * fr + 1] + rcidx / 3;
+      if (h <= hp.thr && g >= hp.range_lo && g < hp.range_hi) stage_emit(stage, sink, h, hp.pos_base + g);
+    }
+  }
+}
+
+// murmur64 of a W-byte string held in dwords D[0..3] (bytes past W are zero), 1 <= W <= 16: no
+// full block, k1 = bytes 0..7, k2 = bytes 8..W-1 (reference src/lib.rs:33-35 on aa.windows())
+template <int W>
+__device__ __forceinline__ uint64_t murmur_short(const uint32_t (&D)[4], uint64_t seed, const uint64_t* k2tab) {
+  W2 h1{(uint32_t)seed, (uint32_t)(seed >> 32)}, h2 = h1;
+  if (W == 9) {
+    // k2 is one byte: its whole mix comes from a 256-entry table (2 of the hash's 8 multiplies)
+    const uint64_t m = k2tab[D[2] & 0xffu];
+    h2 = w2_xor(h2, W2{(uint32_t)m, (uint32_t)(m >> 32)});
+  } else if (W > 8) {
+    h2 = w2_xor(h2, w2_mul(w2_rotl(w2_mul(W2{D[2], D[3]}, kC2), 33), kC1));
+  }
+  h1 = w2_xor(h1, w2_mul(w2_rotl(w2_mul(W2{D[0], D[1]}, kC1), 31), kC2));
+  h1.lo ^= (uint32_t)W; h2.lo ^= (uint32_t)W;
+  h1 = w2_add(h1, h2); h2 = w2_add(h2, h1);
+  h1 = w2_fmix(h1); h2 = w2_fmix(h2);
+  const W2 r = w2_add(h1, h2);
+  return ((uint64_t)r.hi << 32) | r.lo;
+}
+
+template <int W, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParams hp, const uint64_t* __restrict__ seg_off,
+                                                           CandSink sink, int logR, uint32_t stage_cap,
+                                                           uint32_t* __restrict__ high_flag) {
+  constexpr int KB = 3 * W;                          // bases per window
+  constexpr int ND = (W + 3) / 4;                    // dwords of a residue string
+  // static LDS: codon table (digits -> residue | residue of the reverse complement << 8), mix_k2 of a byte
+  __shared__ uint32_t ctab[64];
+  __shared__ uint64_t k2tab[W == 9 ? 256 : 1];
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* st_ctl = smem;
+  uint64_t* st_hash = reinterpret_cast<uint64_t*>(st_ctl + 4);
+  uint64_t* st_pos = st_hash + stage_cap;
+  uint32_t* tile = reinterpret_cast<uint32_t*>(st_pos + (sink.pos ? stage_cap : 0));
+  const Stage stage{st_ctl, st_hash, st_pos, stage_cap};
+
+  const int tid = threadIdx.x;
+  const uint32_t R = 1u << logR;
+  const uint64_t TILE = (uint64_t)THREADS << logR;
+  const bool multi = b.starts != nullptr;
+  if (tid < 64) {
+    const int d0 = (tid >> 4) & 3, d1 = (tid >> 2) & 3, d2 = tid & 3;
+    ctab[tid] = aa_of_digits(d0, d1, d2) | (aa_of_digits(3 - d2, 3 - d1, 3 - d0) << 8);
+  }
+  if (W == 9) for (int e = tid; e < 256; e += THREADS) k2tab[e] = mix_k2((uint64_t)e);
+  if (tid == 0) st_ctl[0] = 0;
+
+  const uint64_t ntiles = (b.len + TILE - 1) / TILE;
+  const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
+  const uint32_t nsteps = ((R + (uint32_t)KB - 1 + 11) / 12) * 12;   // bases walked per lane: whole triples of dwords
+  const uint32_t warm_end = ((uint32_t)(KB - 1) / 12) * 12;          // iterations [0, warm_end) end before any window is complete
+  const bool ranged = !(hp.range_lo == 0 && hp.range_hi == ~0ull);
+  // the end of the valid part of record r: a record shorter than ksize adds nothing (src/lib.rs:257)
+  auto valid_end = [&](uint32_t r) -> uint64_t {
+    const uint64_t s0 = b.starts[r], s1 = b.starts[r + 1];
+    return s1 - s0 >= hp.ksize ? s1 : s0;
+  };
+
+  for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const uint64_t T0 = tix * TILE;
+    const uintptr_t g0 = (uintptr_t)(b.seq + T0);
+    const uintptr_t ga = g0 & ~(uintptr_t)15;
+    const uint32_t m = (uint32_t)(g0 - ga);
+    const uint32_t nchunks = (m + (uint32_t)TILE + (uint32_t)KB + 12 + 8 + 15) >> 4;
+    __syncthreads();
+    uint32_t high = 0;
+    for (uint32_t c = tid; c < nchunks; c += THREADS) {
+      uintptr_t addr = ga + ((uintptr_t)c << 4);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (addr < gend) v = *reinterpret_cast<const uint4*>(addr);
+      high |= v.x | v.y | v.z | v.w;
+      uint32_t x = c << 4;
+      uint32_t o = (x >> 2) + (x >> logR);
+      tile[o] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+    }
+    if (high & 0x80808080u) atomicOr(high_flag, 1u);      // (bytes of the 16-byte granules around the batch may flag too: harmless)
+    __syncthreads();
+
+    const uint64_t p0 = T0 + ((uint64_t)tid << logR);     // my first window start position
+    if (p0 < b.len) {
+    const uint32_t nk = (b.len - p0) < R ? (uint32_t)(b.len - p0) : R;
+    const uint32_t hi_ok = nk + (uint32_t)KB - 1;
+
+    uint32_t rec = 0;
+    uint64_t cur_end = b.vend0;
+    if (multi) { rec = find_record(b.starts, b.nrec, p0); cur_end = valid_end(rec); }
+    uint32_t lim = 0;
+    if (cur_end > p0) lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
+    uint32_t vstart = 0;
+    uint32_t g_lo = 0, g_span = 0;
+    auto set_clean_window = [&](bool warm) {
+      const uint32_t lim2 = warm ? lim : (lim < hi_ok ? lim : hi_ok);
+      g_lo = warm ? vstart : vstart + (uint32_t)KB - 1;
+      g_span = lim2 >= g_lo + 4 ? lim2 - 3 - g_lo : 0u;
+    };
+
+    const uint32_t xu = m & ~3u;
+    uint32_t ta = xu + ((uint32_t)tid << logR);
+    ta = ta + ((ta >> logR) << 2);
+    const uint32_t sh = m & 3u;
+    uint32_t cur = tile[ta >> 2];
+    uint32_t w4 = 0;                                      // last bases as 2-bit digits, newest lowest, times 4 (a ctab byte offset)
+    uint32_t Sf[3][ND], Sr[3][ND];                        // per reading frame (base index mod 3): forward / reverse-complement residue strings
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+      for (int d = 0; d < ND; d++) { Sf[t][d] = 0; Sr[t][d] = 0; }
+
+    // four bases (one dword of the tile); PH = (base index / 4) mod 3 fixes which frame each base completes
+    auto group = [&](uint32_t i0, auto phase, auto hashing) {
+      constexpr int PH = decltype(phase)::value;
+      constexpr bool kHash = decltype(hashing)::value;
+      const uint32_t xn = xu + i0 + 4;
+      ta += (xn & (R - 1)) == 0 ? 8u : 4u;
+      const uint32_t nxt = tile[ta >> 2];
+      const uint32_t d = __builtin_amdgcn_alignbyte(nxt, cur, sh);
+      cur = nxt;
+      const uint32_t u4 = d & 0xDFDFDFDFu;
+      const uint32_t c2 = (u4 >> 1) & 0x03030303u;
+      const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
+      const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
+      const uint32_t diff4 = u4 ^ exp4;
+      uint32_t okmask = 0xFu, slowmask = 0;
+      // the record each base of the group lies in, as a byte offset from the record at group entry
+      // (255 = further away than that: looked up again).  Only the rare emit path reads it.
+      const uint32_t rec0 = rec;
+      uint32_t recd = 0;
+      if (!(diff4 == 0 && i0 - g_lo < g_span)) {
+        okmask = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t i = i0 + q;
+          uint32_t bad = (diff4 >> (8 * q)) & 0xffu;
+          if (i >= lim) {
+            const uint64_t qpos = p0 + i;
+            if (multi) {
+              while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vstart = i; }
+              cur_end = valid_end(rec);
+            }
+            if (qpos >= cur_end) { bad = 1; lim = i + 1; }
+            else lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
+          }
+          if (bad) vstart = i + 1;
+          if (kHash) {
+            const bool inrun = i + 1 >= (uint32_t)KB && i < hi_ok;
+            const bool simple = inrun && (i + 1 >= vstart + (uint32_t)KB);
+            okmask |= simple ? (1u << q) : 0u;
+            slowmask |= (inrun && !simple) ? (1u << q) : 0u;
+            recd |= (rec - rec0 < 255u ? rec - rec0 : 255u) << (8 * q);
+          }
+        }
+        set_clean_window(!kHash);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int t = (4 * PH + q) % 3;                    // reading frame completed by this base (lane-relative)
+        w4 = ((w4 << 2) | (((code4 >> (8 * q)) & 3u) << 2)) & 0xfcu;
+        const uint32_t e = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctab) + w4);
+        const uint32_t af = e & 0xffu, ar = (e >> 8) & 0xffu;
+        // forward string: drop the oldest residue (byte 0), the new one becomes byte W-1
+#pragma unroll
+        for (int dd = 0; dd < ND - 1; dd++) Sf[t][dd] = __builtin_amdgcn_alignbyte(Sf[t][dd + 1], Sf[t][dd], 1);
+        Sf[t][ND - 1] = (Sf[t][ND - 1] >> 8) | (af << (8 * ((W - 1) & 3)));
+        // reverse-complement string: the new residue is its FIRST (byte 0), the oldest (byte W-1) falls off
+#pragma unroll
+        for (int dd = ND - 1; dd > 0; dd--) Sr[t][dd] = __builtin_amdgcn_alignbyte(Sr[t][dd], Sr[t][dd - 1], 3);
+        Sr[t][0] = (Sr[t][0] << 8) | ar;
+        if ((W & 3) != 0) Sr[t][ND - 1] &= (1u << (8 * (W & 3))) - 1u;
+        if (kHash && i0 + q + 1 >= (uint32_t)KB) {          // uniform: a window can be complete here
+          uint32_t Df[4] = {0, 0, 0, 0}, Dr[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int dd = 0; dd < ND; dd++) { Df[dd] = Sf[t][dd]; Dr[dd] = Sr[t][dd]; }
+          const uint64_t hf = murmur_short<W>(Df, hp.seed, k2tab);
+          const uint64_t hr = murmur_short<W>(Dr, hp.seed, k2tab);
+          if (hf <= hp.thr || hr <= hp.thr) {                // ~2 in `scaled` positions get here
+            uint32_t om = okmask;
+            asm volatile("" : "+v"(om));
+            if ((om >> q) & 1u) {
+              const uint64_t a = p0 + i0 + q + 1 - KB;      // all 3W bases lie in the record of base i0 + q
+              uint32_t wr = rec0 + ((recd >> (8 * q)) & 0xffu);
+              if (((recd >> (8 * q)) & 0xffu) == 255u) wr = find_record(b.starts, b.nrec, a);
+              const uint64_t rs = multi ? b.starts[wr] : 0, re = multi ? b.starts[wr + 1] : b.len;
+              const WinPos wp = window_positions(seg_off, wr, a - rs, re - rs, KB);
+              if (hf <= hp.thr && !(ranged && (wp.g_fwd < hp.range_lo || wp.g_fwd >= hp.range_hi)))
+                stage_emit(stage, sink, hf, hp.pos_base + wp.g_fwd);
+              if (hr <= hp.thr && !(ranged && (wp.g_rc < hp.range_lo || wp.g_rc >= hp.range_hi)))
+                stage_emit(stage, sink, hr, hp.pos_base + wp.g_rc);
+            }
+          }
+        }
+      }
+      if (kHash && slowmask) {
+#pragma unroll 1
+        for (int q = 0; q < 4; q++)
+          if ((slowmask >> q) & 1u) hash_spliced_windows(b, hp, seg_off, (uint32_t)W, p0 + i0 + q + 1 - KB, sink, stage);
+      }
+    };
+
+    set_clean_window(true);
+    uint32_t i0 = 0;
+    for (; i0 < warm_end; i0 += 12) {
+      group(i0, std::integral_constant<int, 0>{}, std::false_type{});
+      group(i0 + 4, std::integral_constant<int, 1>{}, std::false_type{});
+      group(i0 + 8, std::integral_constant<int, 2>{}, std::false_type{});
+    }
+    set_clean_window(false);
+    for (; i0 < nsteps; i0 += 12) {
+      group(i0, std::integral_constant<int, 0>{}, std::true_type{});
+      group(i0 + 4, std::integral_constant<int, 1>{}, std::true_type{});
+      group(i0 + 8, std::integral_constant<int, 2>{}, std::true_type{});
+    }
+    }  // p0 < b.len
+
+    stage_flush(stage, sink, tid, THREADS);
+  }
+}
+
 // protein arm, phase 2: a window starts at every kept residue and takes the next `win` kept
 // residues of the same segment (dropped codons are spliced out, quirk Q8).
 __device__ __forceinline__ void hash_window_slow(const uint8_t* __restrict__ res, uint64_t g, uint64_t end, uint32_t win,
@@ -1031,6 +1347,28 @@ void launch_translate(const SeqBatch& b, const uint64_t* seg_off, uint32_t nseg,
   hipLaunchKernelGGL(k_translate, dim3(grid_for(b.len, kTrTile, 16384)), dim3(kTrThreads), 0, s, b, seg_off, nseg, ksize,
                      residues, bad_utf8);
   HIP_CHECK(hipGetLastError());
+}
+
+bool launch_protein_fused(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t win, const HashParams& p,
+                          const CandSink& sink, uint32_t* high_flag, Device& dev, hipStream_t s) {
+  if (b.len == 0) return true;
+  if (!(win == 7 || win == 9 || win == 10)) return false;     // the usual protein k-mer sizes (ksize 21 / 27 / 30)
+  int logR = 7;
+  while (logR > 5 && (b.len >> logR) < (uint64_t)dev.cu_count() * 512 * 2) logR--;
+  const uint64_t tile = 512ull << logR;
+  const uint64_t ntiles = (b.len + tile - 1) / tile;
+  const int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
+  const uint32_t x_bytes = (uint32_t)tile + 3 * win + 12 + 96;
+  // two windows per position pass with probability (thr + 1) / 2^64 each
+  long double expect = 2.0L * (long double)tile * (((long double)p.thr + 1.0L) / 18446744073709551616.0L);
+  uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
+  if (stage_cap < 128) stage_cap = 128;
+  const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes + 4 * ((x_bytes >> logR) + 2);
+#define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, seg_offsets, sink, logR, stage_cap, high_flag)
+  if (win == 7) SMH_PF(7); else if (win == 9) SMH_PF(9); else SMH_PF(10);
+#undef SMH_PF
+  HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 void launch_hash_windows(const uint8_t* bytes, uint64_t total, const uint64_t* seg_offsets,

@@ -246,6 +246,74 @@ def test_protein_arm_pinned_to_reference_codontable(pkg, coracle):
                 same_state(g, o)
 
 
+def _profile(pkg, name):
+    import ctypes as C
+    ms, n = C.c_double(), C.c_uint64()
+    pkg.lib().smh_profile_get(name.encode(), C.byref(ms), C.byref(n))
+    return n.value
+
+
+@pytest.mark.parametrize("ksize", [21, 27, 28, 29, 30, 32])
+def test_protein_fused_kernel(ksize, pkg, coracle):
+    """The one-pass protein kernel (translation + hashing, no residue buffer; window lengths 7, 9, 10)
+    against the oracle on what it has to get right by itself: many records per launch with lengths
+    around ksize and around the tile geometry, lower case, runs of N that splice residues together
+    (quirk Q8), N at record ends, every sketch mode with abundance (positions = the reference's frame
+    order, quirk Q3), and bytes >= 0x80, for which the launch is discarded and repeated on the
+    two-pass path."""
+    rng = random.Random(ksize)
+    L = pkg.lib()
+
+    def rec(n, n_frac=0.0, lower=0.0):
+        out = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for i in range(n):
+            if rng.random() < lower:
+                out[i] |= 0x20
+        k = int(n * n_frac)
+        for _ in range(k):
+            p = rng.randrange(max(1, n)); ln = rng.choice([1, 1, 2, 3, 7, 30])
+            out[p:p + ln] = b"N" * min(ln, n - p)
+        return bytes(out)
+
+    lens = [0, 1, 2, ksize - 1, ksize, ksize + 1, ksize + 2, 3 * (ksize // 3) + 3, 100, 127, 128, 129, 1000, 4093, 70000, 65536 + 13]
+    batches = [
+        [rec(n) for n in lens],
+        [rec(n, n_frac=0.01, lower=0.3) for n in lens + [30000]],
+        [b"N" * 5 + rec(300) + b"NN", rec(64) + b"N", b"N" + rec(64), rec(29) + b"N" + rec(29) + b"NNN" + rec(31)],
+        [rec(200000, n_frac=0.0005)],
+    ]
+    for case in [(0, ksize, True, 42, (1 << 64) // 50, True), (60, ksize, True, 42, 0, True), (0, ksize, True, 7, (1 << 64) - 1, False)]:
+        for recs in batches:
+            if case[4] == (1 << 64) - 1 and sum(map(len, recs)) > 40000:
+                continue
+            g, o = pkg.KmerMinHash(*case), coracle.MinHash(*case)
+            L.smh_profile_reset(); L.smh_profile_enable(1)
+            g.add_sequences(recs, True)
+            fused = _profile(pkg, "protein_fused")
+            L.smh_profile_enable(0)
+            for r in recs:
+                o.add_sequence(r, True)
+            same_state(g, o)
+            if ksize // 3 in (7, 9, 10) and any(len(r) >= ksize for r in recs):
+                assert fused >= 1, "the fused kernel did not run"
+    # a non-ASCII byte: valid UTF-8 that is no codon is dropped, invalid UTF-8 panics (code 1) with the
+    # frames before it kept -- the fused launch must notice and hand over
+    for tail in (b"\xc3\xa9", b"\xff"):
+        seq = rec(500) + tail + rec(500)
+        g, o = pkg.KmerMinHash(0, ksize, True, 42, (1 << 64) // 20, True), coracle.MinHash(0, ksize, True, 42, (1 << 64) // 20, True)
+        eg = eo = None
+        try:
+            g.add_sequence(seq, True)
+        except pkg.SourmashError as e:
+            eg = e.code
+        try:
+            o.add_sequence(seq, True)
+        except coracle.OracleError as e:
+            eo = e.code
+        assert eg == eo
+        same_state(g, o)
+
+
 def test_many_records_per_launch(pkg, coracle):
     rng = random.Random(13)
     recs = [rand_seq(rng, rng.choice([0, 5, 30, 31, 32, 100, 151, 151, 151, 2000]), bad=rng.choice([0, 0, 0.01]))
