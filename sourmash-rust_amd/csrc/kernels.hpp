@@ -67,8 +67,9 @@ void launch_translate(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t n
                       uint8_t* residues, uint32_t* bad_utf8, hipStream_t s);
 
 // Protein arm in ONE pass over the DNA (translation + hashing, no residue buffer): every window of
-// `win` residues of the six frames whose position in the six-frame layout (seg_offsets, as above)
-// lies in [p.range_lo, p.range_hi) -- range_hi == ~0 means "all".  b.vend0 (single record) must be 0
+// `win` residues of the six frames of the whole batch (p.range_* are not used); candidate positions,
+// when the sink wants them, are indices of the six-frame layout (seg_offsets, as above) + p.pos_base.
+// b.vend0 (single record) must be 0
 // when the record is shorter than p.ksize.  *high_flag is OR-ed with 1 when the batch holds a byte
 // >= 0x80: the result must then be discarded and the two-pass path taken (UTF-8 panic semantics).
 // Returns false (nothing launched) for window lengths it has no instantiation for.

@@ -171,6 +171,10 @@ __device__ __forceinline__ W2 w2_mul(W2 x, uint64_t c) {
   // three v_mad_u64_u32 and one add: t = x.hi*cl; u = x.lo*ch + t (its low dword is the whole cross
   // term); p = x.lo*cl; high dword = p.hi + u.lo.  (The compiler's own choice -- one v_mad_u64_u32,
   // two v_mul_lo_u32 and a v_add3 -- is four half-rate instructions; measured 32.6 -> 32.0 ms per 10 GB.)
+  // (Three separate asm statements on purpose.  The scheduler tends to put u right behind t, which
+  // costs a wait state (s_nop) per multiply; pinning the order t, p, u inside one statement removes
+  // those and is nevertheless 1-2 % slower -- the padding is hidden by the other waves, the lost
+  // scheduling freedom is not.  Measured on both kernels, profiles/r02_dna_kernel_steps.txt.)
   uint64_t t, u, p, cy;
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(t), "=s"(cy) : "v"(x.hi), "s"(cl));
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(u), "=s"(cy) : "v"(x.lo), "s"(ch), "v"(t));
@@ -775,14 +779,32 @@ __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint
 // Candidate positions are residue indices of the six-frame layout (segment 6r + 2*frame + strand),
 // the order the reference walks them; seg_off is that layout's segment table.
 
-// record-relative geometry of the two windows that cover bases [a, a + 3W) of record `rec`
-struct WinPos { uint64_t g_fwd, g_rc; };
-__device__ __forceinline__ WinPos window_positions(const uint64_t* __restrict__ seg_off, uint32_t rec, uint64_t a_rel,
-                                                   uint64_t len, uint32_t kb) {
-  const uint32_t f = (uint32_t)(a_rel % 3);
-  const uint64_t rcidx = len - a_rel - kb;                  // index, in revcomp(record), of the window's first base
-  const uint32_t fr = (uint32_t)(rcidx % 3);
-  return {seg_off[6 * (uint64_t)rec + 2 * f] + a_rel / 3, seg_off[6 * (uint64_t)rec + 2 * fr + 1] + rcidx / 3};
+// The hashing kernel reports a candidate's position as (a << 1 | strand): the first base of the
+// window's span in the batch, strand 1 = reverse complement -- no table look-up on its emit path (a
+// dependent global load there, taken by one lane in five hundred, stalls the whole wave).  When the
+// caller wants positions (order-dependent sketch modes, grouped batches) this kernel rewrites them
+// as residue indices of the six-frame layout, the order the reference walks the windows in.
+__global__ __launch_bounds__(256) void k_protein_positions(uint64_t* __restrict__ pos, const unsigned long long* __restrict__ count,
+                                                           uint64_t capacity, const uint64_t* __restrict__ starts, uint32_t nrec,
+                                                           uint64_t batch_len, const uint64_t* __restrict__ seg_off, uint32_t kb,
+                                                           uint64_t pos_base) {
+  const uint64_t n = *count < capacity ? *count : capacity;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t code = pos[i], a = code >> 1;
+    uint32_t rec = 0;
+    uint64_t rs = 0, re = batch_len;
+    if (starts) { rec = find_record(starts, nrec, a); rs = starts[rec]; re = starts[rec + 1]; }
+    const uint64_t a_rel = a - rs, len = re - rs;
+    uint64_t g;
+    if ((code & 1) == 0) {
+      g = seg_off[6 * (uint64_t)rec + 2 * (a_rel % 3)] + a_rel / 3;
+    } else {
+      const uint64_t rcidx = len - a_rel - kb;              // index, in revcomp(record), of the window's first base
+      g = seg_off[6 * (uint64_t)rec + 2 * (rcidx % 3) + 1] + rcidx / 3;
+    }
+    pos[i] = pos_base + g;
+  }
 }
 
 __device__ __forceinline__ int dna_digit(uint32_t c) {      // A0 C1 G2 T3 (either case), -1 otherwise
@@ -798,18 +820,28 @@ __device__ __forceinline__ uint32_t aa_of_digits(int d0, int d1, int d2) {
 // The two windows that START (forward) / whose first residue lies (reverse complement) in the span
 // [a, a + 3W) when that span is not all-ACGT-in-one-record: walk codon by codon, dropping codons
 // that hold anything but ACGT, like to_aa + windows() of the reference (src/lib.rs:779-793, 289-300).
-__device__ __noinline__ void hash_spliced_windows(const SeqBatch& b, const HashParams& hp, const uint64_t* __restrict__ seg_off,
-                                                  uint32_t win, uint64_t a, const CandSink& sink, const Stage& stage) {
+// (everything by value: a reference parameter of a non-inlined function would force the caller's
+// kernel arguments into scratch memory)
+struct SplicedArgs {
+  const uint8_t* seq; uint64_t len; const uint64_t* starts; uint32_t nrec;
+  uint32_t ksize; uint64_t seed, thr;
+  uint64_t* sink_hash; uint64_t* sink_pos; unsigned long long* sink_count; uint64_t sink_capacity;
+  uint32_t* st_ctl; uint64_t* st_hash; uint64_t* st_pos; uint32_t st_cap;
+};
+__device__ __noinline__ void hash_spliced_windows(SplicedArgs A, uint32_t win, uint64_t a) {
+  SeqBatch b; b.seq = A.seq; b.len = A.len; b.starts = A.starts; b.nrec = A.nrec;
+  HashParams hp; hp.ksize = A.ksize; hp.seed = A.seed; hp.thr = A.thr;
+  CandSink sink; sink.hash = A.sink_hash; sink.pos = A.sink_pos; sink.count = A.sink_count; sink.capacity = A.sink_capacity;
+  const Stage stage{A.st_ctl, A.st_hash, A.st_pos, A.st_cap};
   const uint32_t kb = 3 * win;
   uint32_t rec = 0;
   uint64_t rs = 0, re = b.len;
   if (b.starts) { rec = find_record(b.starts, b.nrec, a); rs = b.starts[rec]; re = b.starts[rec + 1]; }
   const uint64_t len = re - rs;
   if (len < hp.ksize || a < rs || a >= re) return;          // reference src/lib.rs:257
-  const uint64_t a_rel = a - rs;
   // forward: first residue = codon [a, a+3) of frame a_rel % 3, then the following codons of that frame
   {
-    const uint32_t f = (uint32_t)(a_rel % 3);
+    const uint32_t f = (uint32_t)((a - rs) % 3);
     const uint64_t fend = rs + f + 3 * ((len - f) / 3);     // end of the frame's translated extent
     Mm3Stream st(hp.seed);
     uint32_t got = 0;
@@ -821,15 +853,12 @@ __device__ __noinline__ void hash_spliced_windows(const SeqBatch& b, const HashP
     }
     if (got == win) {
       const uint64_t h = st.finish();
-      const uint64_t g = seg_off[6 * (uint64_t)rec + 2 * f] + a_rel / 3;
-      if (h <= hp.thr && g >= hp.range_lo && g < hp.range_hi) stage_emit(stage, sink, h, hp.pos_base + g);
+      if (h <= hp.thr) stage_emit(stage, sink, h, a << 1);
     }
   }
   // reverse complement: first residue = the codon read backward from base a + 3W - 1
   if (a + kb <= re) {
     const uint64_t e = a + kb - 1;
-    const uint64_t rcidx = len - 1 - (e - rs);
-    const uint32_t fr = (uint32_t)(rcidx % 3);
     Mm3Stream st(hp.seed);
     uint32_t got = 0;
     for (uint64_t c = e; c >= rs + 2 && got < win; c -= 3) {
@@ -841,8 +870,7 @@ __device__ __noinline__ void hash_spliced_windows(const SeqBatch& b, const HashP
     }
     if (got == win) {
       const uint64_t h = st.finish();
-      const uint64_t g = seg_off[6 * (uint64_t)rec + 2 * fr + 1] + rcidx / 3;
-      if (h <= hp.thr && g >= hp.range_lo && g < hp.range_hi) stage_emit(stage, sink, h, hp.pos_base + g);
+      if (h <= hp.thr) stage_emit(stage, sink, h, (a << 1) | 1u);
     }
   }
 }
@@ -868,9 +896,8 @@ __device__ __forceinline__ uint64_t murmur_short(const uint32_t (&D)[4], uint64_
 }
 
 template <int W, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParams hp, const uint64_t* __restrict__ seg_off,
-                                                           CandSink sink, int logR, uint32_t stage_cap,
-                                                           uint32_t* __restrict__ high_flag) {
+__global__ __launch_bounds__(THREADS, THREADS / 128) void k_protein_fused(SeqBatch b, HashParams hp, CandSink sink, int logR,
+                                                                          uint32_t stage_cap, uint32_t* __restrict__ high_flag) {
   constexpr int KB = 3 * W;                          // bases per window
   constexpr int ND = (W + 3) / 4;                    // dwords of a residue string
   // static LDS: codon table (digits -> residue | residue of the reverse complement << 8), mix_k2 of a byte
@@ -898,7 +925,6 @@ __global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParam
   const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
   const uint32_t nsteps = ((R + (uint32_t)KB - 1 + 11) / 12) * 12;   // bases walked per lane: whole triples of dwords
   const uint32_t warm_end = ((uint32_t)(KB - 1) / 12) * 12;          // iterations [0, warm_end) end before any window is complete
-  const bool ranged = !(hp.range_lo == 0 && hp.range_hi == ~0ull);
   // the end of the valid part of record r: a record shorter than ksize adds nothing (src/lib.rs:257)
   auto valid_end = [&](uint32_t r) -> uint64_t {
     const uint64_t s0 = b.starts[r], s1 = b.starts[r + 1];
@@ -970,10 +996,6 @@ __global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParam
       const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
       const uint32_t diff4 = u4 ^ exp4;
       uint32_t okmask = 0xFu, slowmask = 0;
-      // the record each base of the group lies in, as a byte offset from the record at group entry
-      // (255 = further away than that: looked up again).  Only the rare emit path reads it.
-      const uint32_t rec0 = rec;
-      uint32_t recd = 0;
       if (!(diff4 == 0 && i0 - g_lo < g_span)) {
         okmask = 0;
 #pragma unroll
@@ -995,7 +1017,6 @@ __global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParam
             const bool simple = inrun && (i + 1 >= vstart + (uint32_t)KB);
             okmask |= simple ? (1u << q) : 0u;
             slowmask |= (inrun && !simple) ? (1u << q) : 0u;
-            recd |= (rec - rec0 < 255u ? rec - rec0 : 255u) << (8 * q);
           }
         }
         set_clean_window(!kHash);
@@ -1025,15 +1046,9 @@ __global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParam
             uint32_t om = okmask;
             asm volatile("" : "+v"(om));
             if ((om >> q) & 1u) {
-              const uint64_t a = p0 + i0 + q + 1 - KB;      // all 3W bases lie in the record of base i0 + q
-              uint32_t wr = rec0 + ((recd >> (8 * q)) & 0xffu);
-              if (((recd >> (8 * q)) & 0xffu) == 255u) wr = find_record(b.starts, b.nrec, a);
-              const uint64_t rs = multi ? b.starts[wr] : 0, re = multi ? b.starts[wr + 1] : b.len;
-              const WinPos wp = window_positions(seg_off, wr, a - rs, re - rs, KB);
-              if (hf <= hp.thr && !(ranged && (wp.g_fwd < hp.range_lo || wp.g_fwd >= hp.range_hi)))
-                stage_emit(stage, sink, hf, hp.pos_base + wp.g_fwd);
-              if (hr <= hp.thr && !(ranged && (wp.g_rc < hp.range_lo || wp.g_rc >= hp.range_hi)))
-                stage_emit(stage, sink, hr, hp.pos_base + wp.g_rc);
+              const uint64_t a = p0 + i0 + q + 1 - KB;      // first base of the span; see k_protein_positions
+              if (hf <= hp.thr) stage_emit(stage, sink, hf, a << 1);
+              if (hr <= hp.thr) stage_emit(stage, sink, hr, (a << 1) | 1u);
             }
           }
         }
@@ -1041,7 +1056,11 @@ __global__ __launch_bounds__(THREADS) void k_protein_fused(SeqBatch b, HashParam
       if (kHash && slowmask) {
 #pragma unroll 1
         for (int q = 0; q < 4; q++)
-          if ((slowmask >> q) & 1u) hash_spliced_windows(b, hp, seg_off, (uint32_t)W, p0 + i0 + q + 1 - KB, sink, stage);
+          if ((slowmask >> q) & 1u) {
+            const SplicedArgs sa{b.seq, b.len, b.starts, b.nrec, hp.ksize, hp.seed, hp.thr,
+                                 sink.hash, sink.pos, sink.count, sink.capacity, st_ctl, st_hash, st_pos, stage_cap};
+            hash_spliced_windows(sa, (uint32_t)W, p0 + i0 + q + 1 - KB);
+          }
       }
     };
 
@@ -1364,9 +1383,12 @@ bool launch_protein_fused(const SeqBatch& b, const uint64_t* seg_offsets, uint32
   uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
   if (stage_cap < 128) stage_cap = 128;
   const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes + 4 * ((x_bytes >> logR) + 2);
-#define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, seg_offsets, sink, logR, stage_cap, high_flag)
+#define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap, high_flag)
   if (win == 7) SMH_PF(7); else if (win == 9) SMH_PF(9); else SMH_PF(10);
 #undef SMH_PF
+  if (sink.pos)   // (a << 1 | strand) -> residue index of the six-frame layout
+    hipLaunchKernelGGL(k_protein_positions, dim3(dev.cu_count() * 4), dim3(256), 0, s, sink.pos, sink.count, sink.capacity, b.starts,
+                       b.nrec, b.len, seg_offsets, 3 * win, p.pos_base);
   HIP_CHECK(hipGetLastError());
   return true;
 }

@@ -21,8 +21,10 @@ def main():
     i = labels[label] + 1
     cnt, ops = Counter(), Counter()
     steps = 0
-    while steps < 100000:
+    while steps < 100000 and i < len(lines):
         steps += 1
+        if lines[i].startswith(label + ":"):      # fell through into the header again: one iteration done
+            break
         l = lines[i].strip()
         i += 1
         if not l or l.startswith(";") or l.startswith("."):
