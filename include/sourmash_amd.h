@@ -58,6 +58,16 @@ int smh_add_many(KmerMinHash *ptr, const uint64_t *hashes, uint64_t n);
  * has no symbol for it): item i is the pair (hashes[i], abunds[i]) and is added abunds[i] times. */
 int smh_add_many_with_abund(KmerMinHash *ptr, const uint64_t *hashes, const uint64_t *abunds, uint64_t n);
 
+/* KmerMinHash::check_compatible (reference src/lib.rs:176-190; Rust API only): 0, or the mismatch code
+ * (101 ksize, 102 DNA/protein, 103 max_hash, 104 seed) with the error slot set. */
+int smh_check_compatible(const KmerMinHash *ptr, const KmerMinHash *other);
+
+/* KmerMinHash::intersection (reference src/lib.rs:438-468; the reference header only exports its size):
+ * *common_out receives a malloc'ed array (free() it) of the hashes in both sketches that lie inside the
+ * bottom-`num` of the union, *n_common their number, *union_size the size of the combined sketch. */
+int smh_intersection(const KmerMinHash *ptr, const KmerMinHash *other, uint64_t **common_out, uint64_t *n_common,
+                     uint64_t *union_size);
+
 /* murmur64 of n byte strings (offsets: n+1 host entries) on the device
  * (reference src/lib.rs:33-35 _hash_murmur) */
 int smh_hash_words(const char *bytes, const uint64_t *offsets, uint32_t n, uint64_t seed,

@@ -474,6 +474,25 @@ int smh_add_many_with_abund(KmerMinHash* ptr, const uint64_t* hashes, const uint
   });
 }
 
+int smh_check_compatible(const KmerMinHash* ptr, const KmerMinHash* other) {
+  return pad_code([&] { require(ptr, "ptr"); require(other, "other"); ptr->check_compatible(*other); });
+}
+
+int smh_intersection(const KmerMinHash* ptr, const KmerMinHash* other, uint64_t** common_out, uint64_t* n_common,
+                     uint64_t* union_size) {
+  return pad_code([&] {
+    require(ptr, "ptr"); require(other, "other"); require(common_out, "common_out"); require(n_common, "n_common");
+    std::vector<uint64_t> common;
+    uint64_t size = 0;
+    ptr->intersection(*other, &common, &size);
+    uint64_t* out = (uint64_t*)malloc((common.empty() ? 1 : common.size()) * sizeof(uint64_t));
+    if (!out) smh::throw_internal("out of memory");
+    if (!common.empty()) memcpy(out, common.data(), common.size() * sizeof(uint64_t));
+    *common_out = out; *n_common = common.size();
+    if (union_size) *union_size = size;
+  });
+}
+
 int smh_hash_words(const char* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out) {
   return pad_code([&] {
     require(offsets, "offsets"); require(out, "out");

@@ -1458,6 +1458,25 @@ void KmerMinHash::intersection_size(const KmerMinHash& other, uint64_t* common, 
   if (size) *size = r.size;
 }
 
+// reference src/lib.rs:438-468: the common hashes themselves -- (A ^ B) ^ bottom_n(A u B) -- and the
+// size of the combined sketch.  The counts come from the device walk; the bottom-n of the union is a
+// prefix of the sorted union, so the list is the first `common` elements of the sorted intersection.
+void KmerMinHash::intersection(const KmerMinHash& other, std::vector<uint64_t>* common, uint64_t* size) const {
+  uint64_t n_common = 0, sz = 0;
+  intersection_size(other, &n_common, &sz);
+  materialize();
+  other.materialize();
+  common->clear();
+  common->reserve(n_common);
+  size_t i = 0, j = 0;
+  while (common->size() < n_common && i < mins.size() && j < other.mins.size()) {
+    if (mins[i] < other.mins[j]) i++;
+    else if (other.mins[j] < mins[i]) j++;
+    else { common->push_back(mins[i]); i++; j++; }
+  }
+  if (size) *size = sz;
+}
+
 double KmerMinHash::compare(const KmerMinHash& other) const {
   check_compatible(other);
   Engine::PairResult r;

@@ -89,6 +89,7 @@ struct KmerMinHash {
   bool merge_on_device(const KmerMinHash& other);                        // large well-formed merges
   uint64_t count_common(const KmerMinHash& other) const;                 // 428-436 (device)
   void intersection_size(const KmerMinHash& other, uint64_t* common, uint64_t* size) const;  // 470-499
+  void intersection(const KmerMinHash& other, std::vector<uint64_t>* common, uint64_t* size) const;   // 438-468
   double compare(const KmerMinHash& other) const;                        // 501-508 (device)
   size_t size() const { flush_pending(); return dev ? (size_t)dev->n : mins.size(); }
 

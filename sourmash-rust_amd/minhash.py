@@ -149,6 +149,19 @@ class KmerMinHash:
     def intersection(self, other): return call(self._L.kmerminhash_intersection, self._p, other._p)
     similarity = compare
 
+    def check_compatible(self, other):
+        """reference src/lib.rs:176-190: True, or SourmashError(101..104)."""
+        call(self._L.smh_check_compatible, self._p, other._p)
+        return True
+
+    def intersection_hashes(self, other):
+        """reference src/lib.rs:438-468 (Rust API): (common hashes, size of the combined sketch)."""
+        p, n, sz = u64p(), C.c_uint64(), C.c_uint64()
+        call(self._L.smh_intersection, self._p, other._p, C.byref(p), C.byref(n), C.byref(sz))
+        out = [int(p[i]) for i in range(n.value)]
+        _free(C.cast(p, C.c_void_p))
+        return out, sz.value
+
     def intersection_size(self, other):
         c, s = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
         rows = (C.c_void_p * 1)(self._p)

@@ -1,14 +1,23 @@
 //! Rust face of `libsourmash_amd.so`: the `extern "C"` declarations of `include/sourmash.h` /
 //! `include/sourmash_amd.h` that the hot path needs, and a `KmerMinHash` with the reference's
-//! public fields and method names (reference `src/lib.rs:37-46, 141-513`) whose hot-path methods
-//! forward to the GPU library.  SOURCE ONLY — never compiled in the build image (no toolchain).
+//! public fields, method names and signatures (reference `src/lib.rs:37-46, 141-513`).  EVERY
+//! method forwards to a C symbol of the library -- the sketch state is handed over through the raw
+//! push symbols, the call is made, and the state is read back -- so the numbers are the GPU
+//! library's, never this crate's.  Each symbol bound here is also called from
+//! `tests/c_abi_client.c`, which is what link-checks the forwards.
+//!
+//! SOURCE ONLY: the build image has no rustc/cargo, this crate has never been compiled there.
 #![allow(non_camel_case_types)]
 
-use std::ffi::CStr;
-use std::os::raw::c_char;
+use std::os::raw::{c_char, c_void};
 
 #[repr(C)]
 pub struct RawKmerMinHash {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct RawIndex {
     _private: [u8; 0],
 }
 
@@ -20,10 +29,12 @@ pub struct SourmashStr {
 }
 
 extern "C" {
-    // include/sourmash.h (reference src/ffi.rs)
-    pub fn hash_murmur(kmer: *const c_char, seed: u64) -> u64;
+    // ---- include/sourmash.h (reference src/ffi.rs, src/utils.rs)
     pub fn kmerminhash_new(n: u32, k: u32, prot: bool, seed: u64, mx: u64, track_abundance: bool) -> *mut RawKmerMinHash;
     pub fn kmerminhash_free(ptr: *mut RawKmerMinHash);
+    pub fn kmerminhash_add_hash(ptr: *mut RawKmerMinHash, h: u64);
+    pub fn kmerminhash_merge(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash);
+    pub fn kmerminhash_add_from(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash);
     pub fn kmerminhash_mins_push(ptr: *mut RawKmerMinHash, val: u64);
     pub fn kmerminhash_abunds_push(ptr: *mut RawKmerMinHash, val: u64);
     pub fn kmerminhash_get_mins(ptr: *mut RawKmerMinHash) -> *const u64;
@@ -33,15 +44,22 @@ extern "C" {
     pub fn kmerminhash_track_abundance(ptr: *mut RawKmerMinHash) -> bool;
     pub fn kmerminhash_compare(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash) -> f64;
     pub fn kmerminhash_count_common(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash) -> u64;
-    pub fn kmerminhash_intersection(ptr: *mut RawKmerMinHash, other: *const RawKmerMinHash) -> u64;
     pub fn sourmash_init();
     pub fn sourmash_err_get_last_code() -> u32;
     pub fn sourmash_err_get_last_message() -> SourmashStr;
     pub fn sourmash_err_clear();
     pub fn sourmash_str_free(s: *mut SourmashStr);
-    // include/sourmash_amd.h (additive)
+    // ---- include/sourmash_amd.h (additive)
+    pub fn smh_hash_words(bytes: *const c_char, offsets: *const u64, n: u32, seed: u64, out: *mut u64) -> i32;
+    pub fn smh_check_compatible(ptr: *const RawKmerMinHash, other: *const RawKmerMinHash) -> i32;
     pub fn smh_add_sequence_len(ptr: *mut RawKmerMinHash, seq: *const c_char, len: u64, force: bool) -> i32;
     pub fn smh_add_sequences(ptr: *mut RawKmerMinHash, seq: *const c_char, offsets: *const u64, n_records: u32, force: bool) -> i32;
+    pub fn smh_add_many(ptr: *mut RawKmerMinHash, hashes: *const u64, n: u64) -> i32;
+    pub fn smh_add_many_with_abund(ptr: *mut RawKmerMinHash, hashes: *const u64, abunds: *const u64, n: u64) -> i32;
+    pub fn smh_intersection(
+        ptr: *const RawKmerMinHash, other: *const RawKmerMinHash, common_out: *mut *mut u64, n_common: *mut u64,
+        union_size: *mut u64,
+    ) -> i32;
     pub fn smh_compare_block(
         rows: *const *mut RawKmerMinHash, n_rows: u32, cols: *const *mut RawKmerMinHash, n_cols: u32,
         jaccard: *mut f64, common: *mut u64, size: *mut u64, count_common: *mut u64, containment: *mut f64,
@@ -59,23 +77,20 @@ extern "C" {
     ) -> i32;
 }
 
-#[repr(C)]
-pub struct RawIndex {
-    _private: [u8; 0],
-}
-
 extern "C" {
-    fn free(p: *mut std::os::raw::c_void);
+    fn free(p: *mut c_void);
 }
 
-/// Error codes of reference `src/errors.rs:28-50`.
+/// Error of the library's thread-local slot (codes of reference `src/errors.rs:28-50`).  Stands where
+/// the reference has `failure::Error`.
 #[derive(Debug, Clone, PartialEq)]
-pub struct SourmashError {
+pub struct Error {
     pub code: u32,
     pub message: String,
 }
+pub type SourmashError = Error;
 
-fn take_error() -> SourmashError {
+fn take_error() -> Error {
     unsafe {
         let code = sourmash_err_get_last_code();
         let mut s = sourmash_err_get_last_message();
@@ -86,8 +101,27 @@ fn take_error() -> SourmashError {
         };
         sourmash_str_free(&mut s);
         sourmash_err_clear();
-        SourmashError { code, message }
+        Error { code, message }
     }
+}
+
+fn check(rc: i32) -> Result<(), Error> {
+    if rc != 0 {
+        Err(take_error())
+    } else {
+        Ok(())
+    }
+}
+
+/// Reference `_hash_murmur(kmer: &[u8], seed: u64) -> u64` (`src/lib.rs:33-35`); the bytes may hold NULs.
+pub fn _hash_murmur(kmer: &[u8], seed: u64) -> u64 {
+    let off = [0u64, kmer.len() as u64];
+    let mut out = 0u64;
+    let rc = unsafe { smh_hash_words(kmer.as_ptr() as *const c_char, off.as_ptr(), 1, seed, &mut out) };
+    if rc != 0 {
+        panic!("{}", take_error().message); // no device: the reference's function cannot fail, this one has no CPU path
+    }
+    out
 }
 
 /// Same public fields as the reference struct (`src/lib.rs:37-46`).
@@ -102,6 +136,13 @@ pub struct KmerMinHash {
     pub abunds: Option<Vec<u64>>,
 }
 
+impl Default for KmerMinHash {
+    /// reference `src/lib.rs:48-60`
+    fn default() -> KmerMinHash {
+        KmerMinHash { num: 1000, ksize: 21, is_protein: false, seed: 42, max_hash: 0, mins: Vec::with_capacity(1000), abunds: None }
+    }
+}
+
 struct Handle(*mut RawKmerMinHash);
 impl Drop for Handle {
     fn drop(&mut self) {
@@ -110,8 +151,14 @@ impl Drop for Handle {
 }
 
 impl KmerMinHash {
+    /// reference `src/lib.rs:142-174`
     pub fn new(num: u32, ksize: u32, is_protein: bool, seed: u64, max_hash: u64, track_abundance: bool) -> KmerMinHash {
-        KmerMinHash { num, ksize, is_protein, seed, max_hash, mins: Vec::new(), abunds: if track_abundance { Some(Vec::new()) } else { None } }
+        let cap = if num > 0 { num as usize } else { 1000 };
+        KmerMinHash {
+            num, ksize, is_protein, seed, max_hash,
+            mins: Vec::with_capacity(cap),
+            abunds: if track_abundance { Some(Vec::with_capacity(cap)) } else { None },
+        }
     }
 
     /// Library-side copy of the current state (raw pushes: no ordering check, like the reference ABI).
@@ -135,47 +182,123 @@ impl KmerMinHash {
             let n = kmerminhash_get_mins_size(h.0);
             let p = kmerminhash_get_mins(h.0);
             self.mins = std::slice::from_raw_parts(p, n).to_vec();
-            free(p as *mut _);
+            free(p as *mut c_void);
             if kmerminhash_track_abundance(h.0) {
+                // (`merge` turns tracking on: quirk Q5, reference src/lib.rs:391-401)
                 let na = kmerminhash_get_abunds_size(h.0);
                 let pa = kmerminhash_get_abunds(h.0);
-                self.abunds = Some(std::slice::from_raw_parts(pa, na).to_vec());
-                free(pa as *mut _);
+                self.abunds = Some(if pa.is_null() { Vec::new() } else { std::slice::from_raw_parts(pa, na).to_vec() });
+                free(pa as *mut c_void);
             }
         }
     }
 
-    /// Reference `add_sequence` (`src/lib.rs:252-305`): on `Err` the windows before the offending
-    /// one have been added, exactly as there.
-    pub fn add_sequence(&mut self, seq: &[u8], force: bool) -> Result<(), SourmashError> {
+    /// Run `f` on a library copy of `self`, read the state back, surface the error slot.
+    fn mutate<F: FnOnce(*mut RawKmerMinHash) -> i32>(&mut self, f: F) -> Result<(), Error> {
         let h = self.to_handle();
-        let rc = unsafe { smh_add_sequence_len(h.0, seq.as_ptr() as *const c_char, seq.len() as u64, force) };
+        unsafe { sourmash_err_clear() };
+        let rc = f(h.0);
         self.read_back(&h);
-        if rc != 0 {
+        if rc != 0 || unsafe { sourmash_err_get_last_code() } != 0 {
             return Err(take_error());
         }
         Ok(())
     }
 
-    /// Many records in one device pass (no counterpart in the reference API).
-    pub fn add_sequences(&mut self, records: &[&[u8]], force: bool) -> Result<(), SourmashError> {
-        let mut flat = Vec::new();
-        let mut off = vec![0u64];
-        for r in records {
-            flat.extend_from_slice(r);
-            off.push(flat.len() as u64);
-        }
-        let h = self.to_handle();
-        let rc = unsafe { smh_add_sequences(h.0, flat.as_ptr() as *const c_char, off.as_ptr(), records.len() as u32, force) };
-        self.read_back(&h);
-        if rc != 0 {
-            return Err(take_error());
-        }
-        Ok(())
+    /// reference `src/lib.rs:176-190`
+    pub fn check_compatible(&self, other: &KmerMinHash) -> Result<bool, Error> {
+        let (a, b) = (self.to_handle(), other.to_handle());
+        check(unsafe { smh_check_compatible(a.0, b.0) }).map(|_| true)
     }
 
-    /// Reference `compare` (`src/lib.rs:501-508`).
-    pub fn compare(&self, other: &KmerMinHash) -> Result<f64, SourmashError> {
+    /// reference `src/lib.rs:192-245`
+    pub fn add_hash(&mut self, hash: u64) {
+        let _ = self.mutate(|h| unsafe {
+            kmerminhash_add_hash(h, hash);
+            0
+        });
+    }
+
+    /// reference `src/lib.rs:247-250`
+    pub fn add_word(&mut self, word: &[u8]) {
+        let hash = _hash_murmur(word, self.seed);
+        self.add_hash(hash);
+    }
+
+    /// reference `src/lib.rs:252-305`: on `Err` the windows before the offending one have been added,
+    /// exactly as there.
+    pub fn add_sequence(&mut self, seq: &[u8], force: bool) -> Result<(), Error> {
+        self.mutate(|h| unsafe { smh_add_sequence_len(h, seq.as_ptr() as *const c_char, seq.len() as u64, force) })
+    }
+
+    /// reference `src/lib.rs:307-403`
+    pub fn merge(&mut self, other: &KmerMinHash) -> Result<(), Error> {
+        let o = other.to_handle();
+        self.mutate(|h| unsafe {
+            kmerminhash_merge(h, o.0);
+            0
+        })
+    }
+
+    /// reference `src/lib.rs:405-410`
+    pub fn add_from(&mut self, other: &KmerMinHash) -> Result<(), Error> {
+        let o = other.to_handle();
+        self.mutate(|h| unsafe {
+            kmerminhash_add_from(h, o.0);
+            0
+        })
+    }
+
+    /// reference `src/lib.rs:412-417`
+    pub fn add_many(&mut self, hashes: &[u64]) -> Result<(), Error> {
+        self.mutate(|h| unsafe { smh_add_many(h, hashes.as_ptr(), hashes.len() as u64) })
+    }
+
+    /// reference `src/lib.rs:419-426`
+    pub fn add_many_with_abund(&mut self, hashes: &[(u64, u64)]) -> Result<(), Error> {
+        let hs: Vec<u64> = hashes.iter().map(|p| p.0).collect();
+        let ab: Vec<u64> = hashes.iter().map(|p| p.1).collect();
+        self.mutate(|h| unsafe { smh_add_many_with_abund(h, hs.as_ptr(), ab.as_ptr(), hs.len() as u64) })
+    }
+
+    /// reference `src/lib.rs:428-436`
+    pub fn count_common(&self, other: &KmerMinHash) -> Result<u64, Error> {
+        let (a, b) = (self.to_handle(), other.to_handle());
+        unsafe {
+            sourmash_err_clear();
+            let c = kmerminhash_count_common(a.0, b.0);
+            if sourmash_err_get_last_code() != 0 {
+                return Err(take_error());
+            }
+            Ok(c)
+        }
+    }
+
+    /// reference `src/lib.rs:438-468`: the common hashes and the size of the combined sketch.
+    pub fn intersection(&self, other: &KmerMinHash) -> Result<(Vec<u64>, u64), Error> {
+        let (a, b) = (self.to_handle(), other.to_handle());
+        let mut p: *mut u64 = std::ptr::null_mut();
+        let (mut n, mut size) = (0u64, 0u64);
+        check(unsafe { smh_intersection(a.0, b.0, &mut p, &mut n, &mut size) })?;
+        let common = unsafe { std::slice::from_raw_parts(p, n as usize).to_vec() };
+        unsafe { free(p as *mut c_void) };
+        Ok((common, size))
+    }
+
+    /// reference `src/lib.rs:470-499`
+    pub fn intersection_size(&self, other: &KmerMinHash) -> Result<(u64, u64), Error> {
+        let (a, b) = (self.to_handle(), other.to_handle());
+        let (mut common, mut size) = (0u64, 0u64);
+        let (rp, cp) = ([a.0], [b.0]);
+        check(unsafe {
+            smh_compare_block(rp.as_ptr(), 1, cp.as_ptr(), 1, std::ptr::null_mut(), &mut common, &mut size,
+                              std::ptr::null_mut(), std::ptr::null_mut())
+        })?;
+        Ok((common, size))
+    }
+
+    /// reference `src/lib.rs:501-508`
+    pub fn compare(&self, other: &KmerMinHash) -> Result<f64, Error> {
         let (a, b) = (self.to_handle(), other.to_handle());
         unsafe {
             sourmash_err_clear();
@@ -187,46 +310,42 @@ impl KmerMinHash {
         }
     }
 
-    /// Reference `count_common` (`src/lib.rs:428-436`).
-    pub fn count_common(&self, other: &KmerMinHash) -> Result<u64, SourmashError> {
-        let (a, b) = (self.to_handle(), other.to_handle());
-        unsafe {
-            sourmash_err_clear();
-            let c = kmerminhash_count_common(a.0, b.0);
-            if sourmash_err_get_last_code() != 0 {
-                return Err(take_error());
-            }
-            Ok(c)
+    /// reference `src/lib.rs:510-512`
+    pub fn size(&self) -> usize {
+        let h = self.to_handle();
+        unsafe { kmerminhash_get_mins_size(h.0) }
+    }
+
+    /// Many records in one device pass (no counterpart in the reference API).
+    pub fn add_sequences(&mut self, records: &[&[u8]], force: bool) -> Result<(), Error> {
+        let mut flat = Vec::new();
+        let mut off = vec![0u64];
+        for r in records {
+            flat.extend_from_slice(r);
+            off.push(flat.len() as u64);
         }
+        self.mutate(|h| unsafe { smh_add_sequences(h, flat.as_ptr() as *const c_char, off.as_ptr(), records.len() as u32, force) })
     }
 }
 
-/// Reference `_hash_murmur` (`src/lib.rs:33-35`) for NUL-free input.
-pub fn _hash_murmur(kmer: &CStr, seed: u64) -> u64 {
-    unsafe { hash_murmur(kmer.as_ptr(), seed) }
-}
-
 /// rows x cols Jaccard block in one launch (N^2 calls of `compare` in the reference).
-pub fn compare_matrix(rows: &[KmerMinHash], cols: &[KmerMinHash]) -> Result<Vec<f64>, SourmashError> {
+pub fn compare_matrix(rows: &[KmerMinHash], cols: &[KmerMinHash]) -> Result<Vec<f64>, Error> {
     let rh: Vec<Handle> = rows.iter().map(|m| m.to_handle()).collect();
     let ch: Vec<Handle> = cols.iter().map(|m| m.to_handle()).collect();
     let rp: Vec<*mut RawKmerMinHash> = rh.iter().map(|h| h.0).collect();
     let cp: Vec<*mut RawKmerMinHash> = ch.iter().map(|h| h.0).collect();
     let mut out = vec![0f64; rows.len() * cols.len()];
-    let rc = unsafe {
+    check(unsafe {
         smh_compare_block(rp.as_ptr(), rp.len() as u32, cp.as_ptr(), cp.len() as u32, out.as_mut_ptr(),
                           std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut())
-    };
-    if rc != 0 {
-        return Err(take_error());
-    }
+    })?;
     Ok(out)
 }
 
 /// One signature per group of records (one genome = its contigs) in ONE device pass: the loop
 /// `for file in files { let mut mh = template.clone(); for rec in file { mh.add_sequence(rec) } }`
 /// of the reference's callers.  `groups[r]` is the sketch that record `r` feeds.
-pub fn sketch_groups(sketches: &mut [KmerMinHash], records: &[&[u8]], groups: &[u32], force: bool) -> Result<(), SourmashError> {
+pub fn sketch_groups(sketches: &mut [KmerMinHash], records: &[&[u8]], groups: &[u32], force: bool) -> Result<(), Error> {
     assert_eq!(records.len(), groups.len());
     let mut flat = Vec::new();
     let mut off = vec![0u64];
@@ -243,10 +362,7 @@ pub fn sketch_groups(sketches: &mut [KmerMinHash], records: &[&[u8]], groups: &[
     for (m, h) in sketches.iter_mut().zip(hs.iter()) {
         m.read_back(h);
     }
-    if rc != 0 {
-        return Err(take_error());
-    }
-    Ok(())
+    check(rc)
 }
 
 /// `LinearIndex` (reference `src/index/linear.rs`) whose leaves live in HBM: `find` uploads only
@@ -258,7 +374,7 @@ pub struct ResidentIndex {
 }
 
 impl ResidentIndex {
-    pub fn new(leaves: &[KmerMinHash]) -> Result<ResidentIndex, SourmashError> {
+    pub fn new(leaves: &[KmerMinHash]) -> Result<ResidentIndex, Error> {
         let hs: Vec<Handle> = leaves.iter().map(|m| m.to_handle()).collect();
         let hp: Vec<*mut RawKmerMinHash> = hs.iter().map(|h| h.0).collect();
         let raw = unsafe { smh_index_new(hp.as_ptr(), hp.len() as u32) };
@@ -273,14 +389,11 @@ impl ResidentIndex {
     }
 
     /// Positions of the leaves with similarity (or containment) above `threshold`, ascending.
-    pub fn find(&self, query: &KmerMinHash, threshold: f64, containment: bool) -> Result<Vec<usize>, SourmashError> {
+    pub fn find(&self, query: &KmerMinHash, threshold: f64, containment: bool) -> Result<Vec<usize>, Error> {
         let q = query.to_handle();
         let mut out = vec![0u32; self.len().max(1)];
         let mut n = 0u32;
-        let rc = unsafe { smh_index_find(self.raw, q.0, threshold, containment, out.as_mut_ptr(), &mut n) };
-        if rc != 0 {
-            return Err(take_error());
-        }
+        check(unsafe { smh_index_find(self.raw, q.0, threshold, containment, out.as_mut_ptr(), &mut n) })?;
         Ok(out[..n as usize].iter().map(|&i| i as usize).collect())
     }
 }
