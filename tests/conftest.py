@@ -19,6 +19,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU")
+    # a hung test must fail with a traceback of where it hangs, not stall the whole run in silence
+    # (pytest-timeout is part of the image; without it the option simply does not exist)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
 
 
 @pytest.fixture(scope="session")

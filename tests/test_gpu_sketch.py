@@ -396,6 +396,92 @@ def test_full_size_properties(pkg, coracle):
     same_state(g, o)
 
 
+@pytest.mark.parametrize("n_every", [0, 100000])
+def test_c2_at_full_size(n_every, pkg, coracle):
+    """BASELINE configs[1] at its full size: 10 GB as 10 000 records x 1 MB, k=31, scaled=1000,
+    force=true -- clean, and with one `N` per 10^5 bases.  Size-independent
+    properties: ascending distinct hashes <= max_hash; the retained total follows the binomial
+    law of the number of valid windows; linearity (sketch(all) == merge(sketch(first 4 000
+    records), sketch(rest)), abundances included); and sampled records -- the first, one in the
+    middle, the last -- sketched by the C oracle must be subsets of the whole with abundances no
+    larger than the whole's (equality for the hashes that occur in no other record is implied by
+    linearity + the per-record parity tests)."""
+    import ctypes as C
+    import torch
+    nrec, rlen, mx = 10000, 1_000_000, 18446744073709552
+    total = nrec * rlen
+    buf = torch.empty(total, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, total, 2, n_every, C.c_void_p(0)) == 0
+    torch.cuda.synchronize()
+    off = np.arange(nrec + 1, dtype=np.uint64) * np.uint64(rlen)
+
+    def sketch(r0, r1):
+        mh = pkg.KmerMinHash(0, 31, False, 42, mx, True)
+        mh.add_sequences_dev(buf.data_ptr() + r0 * rlen, (r1 - r0) * rlen, off[r0:r1 + 1] - off[r0], True)
+        return mh
+
+    whole = sketch(0, nrec)
+    m, ab = whole.mins_np(), whole.abunds_np()
+    assert (m[1:] > m[:-1]).all() and m[-1] <= mx
+    # valid windows per record: the generator puts an N at every position = n_every - 1 (mod n_every) and
+    # n_every divides the record length, so a record is rlen / n_every runs of n_every - 1 valid bases
+    windows = nrec * ((rlen // n_every) * (n_every - 1 - 30) if n_every else rlen - 30)
+    exp = windows * ((mx + 1) / 2.0 ** 64)
+    assert abs(int(ab.sum()) - exp) < 6 * exp ** 0.5
+    a, b = sketch(0, 4000), sketch(4000, nrec)
+    a.merge(b)
+    assert (a.mins_np() == m).all() and (a.abunds_np() == ab).all()
+    whole_map = dict(zip(m.tolist(), ab.tolist()))
+    for r in (0, 4999, nrec - 1):
+        o = coracle.MinHash(0, 31, False, 42, mx, True)
+        o.add_sequence(bytes(coracle.synth_dna(r * rlen, rlen, 2, n_every)), True)
+        g = sketch(r, r + 1)
+        same_state(g, o)
+        assert all(whole_map.get(h, 0) >= c for h, c in zip(o.mins, o.abunds))
+
+
+def test_c5_share_at_full_size(pkg, coracle):
+    """BASELINE configs[4], one rank's share: 12.5 GB of DNA (12 500 records x 1 MB) through the
+    protein arm, ksize=27, scaled=1000, abundance tracking -- the one-pass kernel at full size.
+    Properties: ascending, <= max_hash; binomial total over the 2 x 3 x 12 500 frame windows;
+    linearity across a split; two sampled records equal to the C oracle's sketch and contained in the whole."""
+    import ctypes as C
+    import torch
+    nrec, rlen, mx = 12500, 1_000_000, 18446744073709552
+    total = nrec * rlen
+    buf = torch.empty(total + 64, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, total, 5, 0, C.c_void_p(0)) == 0
+    torch.cuda.synchronize()
+    off = np.arange(nrec + 1, dtype=np.uint64) * np.uint64(rlen)
+
+    def sketch(r0, r1):
+        mh = pkg.KmerMinHash(0, 27, True, 42, mx, True)
+        mh.add_sequences_dev(buf.data_ptr() + r0 * rlen, (r1 - r0) * rlen, off[r0:r1 + 1] - off[r0], True)
+        return mh
+
+    L = pkg.lib()
+    L.smh_profile_reset(); L.smh_profile_enable(1)
+    whole = sketch(0, nrec)
+    fused = _profile(pkg, "protein_fused")
+    L.smh_profile_enable(0)
+    assert fused == 1 and _profile(pkg, "translate") == 0, "the share must take the one-pass kernel"
+    m, ab = whole.mins_np(), whole.abunds_np()
+    assert (m[1:] > m[:-1]).all() and m[-1] <= mx
+    windows = sum(2 * ((rlen - f) // 3 - 9 + 1) for f in range(3)) * nrec
+    exp = windows * ((mx + 1) / 2.0 ** 64)
+    assert abs(int(ab.sum()) - exp) < 6 * exp ** 0.5
+    a, b = sketch(0, 6000), sketch(6000, nrec)
+    a.merge(b)
+    assert (a.mins_np() == m).all() and (a.abunds_np() == ab).all()
+    whole_map = dict(zip(m.tolist(), ab.tolist()))
+    for r in (0, nrec - 1):
+        o = coracle.MinHash(0, 27, True, 42, mx, True)
+        o.add_sequence(bytes(coracle.synth_dna(r * rlen, rlen, 5, 0)), True)
+        g = sketch(r, r + 1)
+        same_state(g, o)
+        assert all(whole_map.get(h, 0) >= c for h, c in zip(o.mins, o.abunds))
+
+
 def test_candidate_buffer_overflow_is_rerun(pkg, coracle):
     """Far more survivors than the uniform-hash estimate: poly-A where the single k-mer passes the
     filter.  The first launch overflows its buffer (the counter keeps counting), the library re-runs
