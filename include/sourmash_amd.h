@@ -151,13 +151,6 @@ typedef struct SmhCompareStats {
 } SmhCompareStats;
 void smh_compare_last_stats(SmhCompareStats *out);
 
-/* Test hook, host only (no device needed): the tile planning of the N x M compare block.  comp_*:
- * connected-component id of every row / column (ids < max_comp); outputs: the slot orders and the
- * (row tile, column tile) pairs that would be launched for tr x tc tiles. */
-int smh_test_plan_tiles(const uint32_t *comp_r, uint32_t nrows, const uint32_t *comp_c, uint32_t ncols,
-                        uint32_t max_comp, uint32_t tr, uint32_t tc, bool symmetric, uint32_t *rperm_out,
-                        uint32_t *cperm_out, uint32_t *tiles_out, uint32_t tiles_cap, uint32_t *n_tiles);
-
 /* The library keeps its device workspace (candidate buffers, the six-frame residue buffer, sort
  * scratch) between calls and only ever grows it; a long-running process can hand the memory back
  * after a large batch.  Sketches, resident indexes and their device copies are not touched. */

@@ -111,9 +111,6 @@ _SIGS = {
     "smh_index_most_common": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), u64p]),
     "smh_index_compare": (C.c_int, [C.c_void_p, C.c_void_p, f64p, u64p, u64p, u64p, f64p]),
     "smh_release_workspace": (C.c_int, []),
-    "smh_test_plan_tiles": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
-                                      C.c_uint32, C.c_bool, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
-                                      C.c_uint32, C.POINTER(C.c_uint32)]),
     "smh_compare_last_stats": (None, [C.POINTER(SmhCompareStats)]),
     "smh_compare_get_tuning": (None, [C.POINTER(SmhCompareTuning)]),
     "smh_compare_set_tuning": (C.c_int, [C.POINTER(SmhCompareTuning)]),

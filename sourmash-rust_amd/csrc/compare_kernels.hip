@@ -23,7 +23,6 @@
 
 #include "device.hpp"
 #include "kernels.hpp"
-#include "tile_plan.hpp"
 
 namespace smh {
 namespace {
@@ -276,50 +275,57 @@ __global__ __launch_bounds__(256) void k_compare_few(SketchSet many, SketchSet f
 // the pair exactly like k_compare_few.  No rank encoding is needed on this route, and a pair
 // keeps 64 lanes busy instead of one, which is what a launch of a few thousand pairs needs.
 struct CompWork { uint32_t col, r0, r1; };
+// The work list and its length are produced on the device (see "device-side plan" below): a
+// persistent grid walks it.  rkey[slot] = (component << 32 | row): rows in component order.
 template <bool QLds, bool WantCC>
 __global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet cols, const CompWork* __restrict__ work,
-                                                      const uint32_t* __restrict__ rperm, uint32_t num,
+                                                      const uint32_t* __restrict__ nwork_dev, uint32_t work_cap,
+                                                      const uint64_t* __restrict__ rkey, uint32_t num,
                                                       const uint32_t* __restrict__ row_nums, uint32_t symmetric,
                                                       CompareOut out) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const CompWork wk = work[blockIdx.x];
-  const uint32_t col = wk.col;
-  const uint64_t qo = cols.offsets[col];
-  const uint32_t lq = (uint32_t)(cols.offsets[col + 1] - qo);
-  const uint64_t* Q = cols.hashes + qo;
-  if (QLds) {
-    for (uint32_t t = tid; t < lq; t += 256) lds64[t] = Q[t];
-    __syncthreads();
-    Q = lds64;
-  }
-  for (uint32_t slot = wk.r0 + w; slot < wk.r1; slot += 4) {
-    const uint32_t row = rperm[slot];
-    const uint64_t ao = rows.offsets[row];
-    const uint32_t la = (uint32_t)(rows.offsets[row + 1] - ao);
-    uint32_t n = row_nums ? row_nums[row] : num;
-    n = n ? n : 0xffffffffu;
-    const WavePair r = wave_pair<WantCC>(rows.hashes + ao, la, Q, lq, n, lane);
-    if (lane == 0) {
-      const uint64_t tot_u = (uint64_t)la + lq - r.cc;
-      const uint64_t size = (r.cut || tot_u > n) ? n : tot_u;
-      const double jac = (double)r.cm / (double)(size > 1 ? size : 1);
-      const size_t pid = (size_t)row * cols.n + col;
-      if (out.common) out.common[pid] = r.cm;
-      if (out.size) out.size[pid] = size;
-      if (out.jaccard) out.jaccard[pid] = jac;
-      if (WantCC) {
-        if (out.count_common) out.count_common[pid] = r.cc;
-        if (out.containment) out.containment[pid] = (double)r.cc / (double)la;
-      }
-      if (symmetric && row != col) {   // same list on both axes, one num: also pair (col, row)
-        const size_t pid2 = (size_t)col * cols.n + row;
-        if (out.common) out.common[pid2] = r.cm;
-        if (out.size) out.size[pid2] = size;
-        if (out.jaccard) out.jaccard[pid2] = jac;
+  const uint32_t nwork = min(*nwork_dev, work_cap);
+  for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const CompWork wk = work[wi];
+    const uint32_t col = wk.col;
+    const uint64_t qo = cols.offsets[col];
+    const uint32_t lq = (uint32_t)(cols.offsets[col + 1] - qo);
+    const uint64_t* Q = cols.hashes + qo;
+    if (QLds) {
+      __syncthreads();                       // the previous item's column is no longer being read
+      for (uint32_t t = tid; t < lq; t += 256) lds64[t] = Q[t];
+      __syncthreads();
+      Q = lds64;
+    }
+    for (uint32_t slot = wk.r0 + w; slot < wk.r1; slot += 4) {
+      const uint32_t row = (uint32_t)rkey[slot];
+      const uint64_t ao = rows.offsets[row];
+      const uint32_t la = (uint32_t)(rows.offsets[row + 1] - ao);
+      uint32_t n = row_nums ? row_nums[row] : num;
+      n = n ? n : 0xffffffffu;
+      const WavePair r = wave_pair<WantCC>(rows.hashes + ao, la, Q, lq, n, lane);
+      if (lane == 0) {
+        const uint64_t tot_u = (uint64_t)la + lq - r.cc;
+        const uint64_t size = (r.cut || tot_u > n) ? n : tot_u;
+        const double jac = (double)r.cm / (double)(size > 1 ? size : 1);
+        const size_t pid = (size_t)row * cols.n + col;
+        if (out.common) out.common[pid] = r.cm;
+        if (out.size) out.size[pid] = size;
+        if (out.jaccard) out.jaccard[pid] = jac;
         if (WantCC) {
-          if (out.count_common) out.count_common[pid2] = r.cc;
-          if (out.containment) out.containment[pid2] = (double)r.cc / (double)lq;
+          if (out.count_common) out.count_common[pid] = r.cc;
+          if (out.containment) out.containment[pid] = (double)r.cc / (double)la;
+        }
+        if (symmetric && row != col) {   // same list on both axes, one num: also pair (col, row)
+          const size_t pid2 = (size_t)col * cols.n + row;
+          if (out.common) out.common[pid2] = r.cm;
+          if (out.size) out.size[pid2] = size;
+          if (out.jaccard) out.jaccard[pid2] = jac;
+          if (WantCC) {
+            if (out.count_common) out.count_common[pid2] = r.cc;
+            if (out.containment) out.containment[pid2] = (double)r.cc / (double)lq;
+          }
         }
       }
     }
@@ -344,18 +350,36 @@ __global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet 
 constexpr int kTB = 64;          // columns per tile (= lanes of a wave); rows per tile = WPB * RPW
 constexpr uint32_t kSent = 0xffffffffu;
 
+// What the device-side plan of a block compare decides (see "device-side plan" below); the kernels
+// read it, the host reads it back once, at the end of the call.
+struct PlanState {
+  unsigned long long pairs;      // sum over the components of rows x columns: pairs that CAN share a hash
+  unsigned long long ovf_steps;  // tiled: (tile, range) steps that did not fit the LDS stage and merged from global memory
+  uint32_t route;                // kRouteComponents or kRouteTiled
+  uint32_t skip_tiled;           // 1: the tiled pre-pass and kernels do nothing
+  uint32_t skip_comp;            // 1: the per-component pair kernel does nothing
+  uint32_t rpw;                  // rows per wave of the tiled instantiation that runs (4, 2 or 1)
+  uint32_t ntiles;               // tiles in the list
+  uint32_t nwork;                // work items of the per-component kernel
+  uint32_t nruns;                // distinct hashes of the pool (dense ranks)
+  uint32_t count16;              // tiles that hold sharing pairs at the 16-row geometry
+  uint32_t next_tile[8];         // tiled: tiles handed out so far, per XCD stretch of the list
+};
+
 struct TiledArgs {
   const uint32_t* rrank; const uint64_t* roff; const uint32_t* rpart; uint32_t nrows;
   const uint32_t* crank; const uint64_t* coff; const uint32_t* cpart; uint32_t ncols;
   uint32_t R, num;
   const uint32_t* row_nums;
-  const uint32_t* tiles;   // (row tile, column tile) of every workgroup: only tiles that can hold sharing pairs
-  const uint32_t* rperm;   // row slot -> row; column slot -> column: sketches of one component are adjacent
-  const uint32_t* cperm;
-  uint32_t xcd_chunk;      // tiles per XCD stretch (0 = list order)
+  const uint32_t* tiles;   // (row tile, column tile) pairs: only tiles that can hold sharing pairs
+  uint32_t tiles_cap;
+  const uint64_t* rkey;    // row slot -> (component << 32 | row); column slot -> ...: sketches of one component are adjacent
+  const uint64_t* ckey;
+  PlanState* st;
+  uint32_t use_xcd;        // give every XCD a contiguous stretch of the tile list
   uint32_t symmetric;      // rows and columns are the same sketches with one num: pair (i, j) also writes (j, i)
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
-  unsigned long long* ovf_steps;   // (tile, range) steps that did not fit the LDS stage and merged from global memory
+  unsigned long long* ovf_steps;   // = &st->ovf_steps
   CompareOut out;
 };
 
@@ -379,15 +403,39 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
   uint32_t* Bt = poolA + a.capA;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD a
-  // contiguous stretch of the tile list, so that the tiles it works on share rows and columns
-  uint32_t tix = blockIdx.x;
-  if (tix < 8u * a.xcd_chunk) tix = (tix & 7u) * a.xcd_chunk + (tix >> 3);   // the tail (< 8 tiles) keeps list order
+  // the plan picks ONE of the launched instantiations (rows per wave) -- or none of them
+  if (a.st->skip_tiled || a.st->rpw != (uint32_t)RPW) return;
+  const uint32_t ntiles = min(a.st->ntiles, a.tiles_cap);
+  // A persistent grid pulls tiles off the list (tile times differ: a static split left the chip
+  // half idle at the end).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
+  // workgroup b first serves stretch b % 8 of the list, so that the tiles an XCD works on share
+  // rows and columns, and helps the other stretches out once its own is exhausted.
+  const uint32_t nstretch = (a.use_xcd && ntiles >= 64) ? 8u : 1u;
+  const uint32_t chunk = (ntiles + nstretch - 1) / nstretch;
+  uint32_t steal = 0;     // (thread 0) stretches given up so far
+  while (true) {
+  __syncthreads();                 // the previous tile's tables and stage are no longer being read
+  if (tid == 0) {
+    uint32_t t = 0xffffffffu;
+    while (steal < nstretch) {
+      const uint32_t x = ((blockIdx.x & 7u) + steal) % nstretch;
+      const uint32_t lo = x * chunk, hi = min(lo + chunk, ntiles);
+      if (lo < hi) {
+        const uint32_t k = atomicAdd(&a.st->next_tile[x], 1u);
+        if (lo + k < hi) { t = lo + k; break; }
+      }
+      steal++;
+    }
+    ctl[2] = t;
+  }
+  __syncthreads();
+  const uint32_t tix = ctl[2];
+  if (tix == 0xffffffffu) break;
   const uint32_t bi = a.tiles[2 * tix], bj = a.tiles[2 * tix + 1];
   if (tid < 64) {
     const uint32_t rs = bi * kTR + tid, cs = bj * kTB + tid;
-    rowid[tid] = (tid < kTR && rs < a.nrows) ? a.rperm[rs] : 0xffffffffu;
-    colid[tid] = cs < a.ncols ? a.cperm[cs] : 0xffffffffu;
+    rowid[tid] = (tid < kTR && rs < a.nrows) ? (uint32_t)a.rkey[rs] : 0xffffffffu;
+    colid[tid] = cs < a.ncols ? (uint32_t)a.ckey[cs] : 0xffffffffu;
   }
   __syncthreads();
   const uint32_t col = colid[lane];
@@ -569,6 +617,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       }
     }
   }
+  }   // tiles of this workgroup
 }
 
 // ---- pre-pass kernels ---------------------------------------------------------------------
@@ -577,10 +626,11 @@ __global__ void k_iota(uint32_t* p, uint64_t n) {
   if (i < n) p[i] = (uint32_t)i;
 }
 // bound[r] = rank of the pooled element at sorted position r*n/R (bound[0] = 0, bound[R] = nruns)
-__global__ void k_bounds(const uint32_t* __restrict__ starts, uint32_t nruns, uint32_t n, uint32_t R,
+__global__ void k_bounds(const uint32_t* __restrict__ starts, const PlanState* __restrict__ st, uint32_t n, uint32_t R,
                          uint32_t* __restrict__ bound) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > R) return;
+  if (r > R || st->skip_tiled) return;
+  const uint32_t nruns = st->nruns;
   if (r == 0) { bound[0] = 0; return; }
   if (r == R) { bound[R] = nruns; return; }
   uint32_t pos = (uint32_t)(((uint64_t)r * n) / R);
@@ -593,9 +643,10 @@ __global__ void k_bounds(const uint32_t* __restrict__ starts, uint32_t nruns, ui
 }
 // part[s][r] = first index in sketch s whose rank is >= bound[r]
 __global__ void k_partition(const uint32_t* __restrict__ rank, const uint64_t* __restrict__ off, uint32_t nsk,
-                            const uint32_t* __restrict__ bound, uint32_t R, uint32_t* __restrict__ part) {
+                            const uint32_t* __restrict__ bound, uint32_t R, uint32_t* __restrict__ part,
+                            const PlanState* __restrict__ st) {
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint64_t)nsk * (R + 1)) return;
+  if (g >= (uint64_t)nsk * (R + 1) || st->skip_tiled) return;
   uint32_t s = (uint32_t)(g / (R + 1)), r = (uint32_t)(g % (R + 1));
   const uint32_t* v = rank + off[s];
   uint32_t len = (uint32_t)(off[s + 1] - off[s]);
@@ -704,8 +755,153 @@ __global__ __launch_bounds__(256) void k_fill_disjoint(const uint64_t* __restric
   if (out.containment) out.containment[pid] = 0.0 / (double)la;
 }
 
+// ---- device-side plan ----------------------------------------------------------------------------
+// Everything between the union-find and the compare kernels is decided on the device, so that a
+// block compare has ONE host synchronisation, at its end:
+//   k_plan_keys      (component << 32 | sketch) keys, sorted: slot order = sketches of a component adjacent
+//   k_plan_ranges    per row slot the column slots of its component (and vice versa); pairs = sum
+//   k_plan_route     few sharing pairs -> per-component pair kernel, else the tiled kernel
+//   k_comp_count / scan / k_comp_fill     the pair kernel's work list
+//   k_tiles_count16, k_plan_geometry      how many 16-row tiles hold sharing pairs -> rows per tile
+//   k_flag_tiles     the tile list of that geometry (ordered inside 256-tile chunks)
+// The compare kernels are launched unconditionally with persistent grids and return at once when the
+// plan did not pick them; the tiled pre-pass (ranks, ranges, partition table) is skipped the same way.
+__global__ __launch_bounds__(256) void k_plan_keys(const uint32_t* __restrict__ root, uint32_t n, uint64_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = ((uint64_t)root[i] << 32) | i;
+}
+// first slot of `keys` whose component is >= comp
+__device__ __forceinline__ uint32_t comp_lower_bound(const uint64_t* __restrict__ keys, uint32_t n, uint64_t comp) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((keys[mid] >> 32) < comp) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// other_lo/hi[i] = slots of `other` that hold the component of slot i of `mine`
+__global__ __launch_bounds__(256) void k_plan_ranges(const uint64_t* __restrict__ mine, uint32_t n_mine,
+                                                     const uint64_t* __restrict__ other, uint32_t n_other,
+                                                     uint32_t* __restrict__ other_lo, uint32_t* __restrict__ other_hi,
+                                                     PlanState* st) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t mine_pairs = 0;
+  if (i < n_mine) {
+    const uint64_t comp = mine[i] >> 32;
+    const uint32_t lo = comp_lower_bound(other, n_other, comp), hi = comp_lower_bound(other, n_other, comp + 1);
+    other_lo[i] = lo; other_hi[i] = hi;
+    mine_pairs = hi - lo;
+  }
+  if (st) {
+    const uint64_t wsum = wave_sum64(mine_pairs);
+    if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&st->pairs, (unsigned long long)wsum);
+  }
+}
+__global__ void k_plan_route(PlanState* st, uint32_t forced_route, uint32_t visit_all, unsigned long long comp_pairs_limit) {
+  uint32_t route = forced_route;
+  if (route != kRouteComponents && route != kRouteTiled)
+    route = (st->pairs <= comp_pairs_limit && !visit_all) ? (uint32_t)kRouteComponents : (uint32_t)kRouteTiled;
+  st->route = route;
+  st->skip_tiled = route != kRouteTiled;
+  st->skip_comp = route != kRouteComponents;
+}
+// work items of the per-component kernel: (column, <= 32 rows of its component)
+constexpr uint32_t kRowsPerItem = 32;
+__device__ __forceinline__ uint32_t comp_items_of(uint32_t c, const uint32_t* row_lo, const uint32_t* row_hi, uint32_t symmetric,
+                                                  uint32_t* first_row) {
+  const uint32_t rs = symmetric ? max(row_lo[c], c) : row_lo[c];   // same order on both axes: upper triangle only
+  *first_row = rs;
+  return row_hi[c] > rs ? (row_hi[c] - rs + kRowsPerItem - 1) / kRowsPerItem : 0u;
+}
+__global__ __launch_bounds__(256) void k_comp_count(uint32_t ncols, const uint32_t* __restrict__ row_lo,
+                                                    const uint32_t* __restrict__ row_hi, uint32_t symmetric,
+                                                    uint32_t* __restrict__ cnt, const PlanState* __restrict__ st) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  uint32_t rs;
+  cnt[c] = st->skip_comp ? 0u : comp_items_of(c, row_lo, row_hi, symmetric, &rs);
+}
+__global__ __launch_bounds__(256) void k_comp_fill(const uint64_t* __restrict__ ckey, uint32_t ncols,
+                                                   const uint32_t* __restrict__ row_lo, const uint32_t* __restrict__ row_hi,
+                                                   uint32_t symmetric, const uint32_t* __restrict__ off, CompWork* __restrict__ work,
+                                                   uint32_t work_cap, const PlanState* __restrict__ st) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols || st->skip_comp) return;
+  uint32_t rs;
+  const uint32_t n = comp_items_of(c, row_lo, row_hi, symmetric, &rs);
+  const uint32_t col = (uint32_t)ckey[c];
+  for (uint32_t k = 0; k < n; k++)
+    if (off[c] + k < work_cap) work[off[c] + k] = CompWork{col, rs + k * kRowsPerItem, min(row_hi[c], rs + (k + 1) * kRowsPerItem)};
+}
+// does the tr x 64 tile (ti, tj) of the slot orders hold a pair of one component?
+__device__ __forceinline__ bool tile_shares(uint32_t ti, uint32_t tj, uint32_t tr, uint32_t nrows, uint32_t ncols,
+                                            const uint32_t* __restrict__ col_lo, const uint32_t* __restrict__ col_hi,
+                                            uint32_t symmetric, uint32_t all_on) {
+  // a tile wholly below the diagonal: its pairs are written as mirrors of the tile above
+  if (symmetric && (uint64_t)tj * kTB + kTB - 1 < (uint64_t)ti * tr) return false;
+  if (all_on) return true;
+  const uint32_t cbeg = tj * kTB, cend = min(cbeg + (uint32_t)kTB, ncols);
+  const uint32_t r1 = min((ti + 1) * tr, nrows);
+  for (uint32_t i = ti * tr; i < r1; i++)
+    if (col_lo[i] < cend && col_hi[i] > cbeg) return true;
+  return false;
+}
+__global__ __launch_bounds__(256) void k_tiles_count16(uint32_t nrows, uint32_t ncols, const uint32_t* __restrict__ col_lo,
+                                                       const uint32_t* __restrict__ col_hi, uint32_t symmetric, PlanState* st) {
+  if (st->skip_tiled) return;
+  const uint32_t tiles_r = (nrows + 15) / 16, tiles_c = (ncols + kTB - 1) / kTB;
+  const uint64_t all = (uint64_t)tiles_r * tiles_c;
+  uint32_t mine = 0;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < all; t += (uint64_t)gridDim.x * blockDim.x)
+    mine += tile_shares((uint32_t)(t / tiles_c), (uint32_t)(t % tiles_c), 16, nrows, ncols, col_lo, col_hi, symmetric, 0) ? 1u : 0u;
+  const uint32_t wsum = (uint32_t)wave_sum64(mine);
+  if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&st->count16, wsum);
+}
+// rows per wave (x 4 waves = rows per tile): 16-row tiles amortise the staging best; when few tiles
+// hold sharing pairs, shorter ones keep the chip full (the kernel is latency bound)
+__global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t fill_tiles) {
+  uint32_t rpw = forced_rpw;
+  if (!rpw) rpw = st->count16 >= fill_tiles ? 4u : (2 * st->count16 >= fill_tiles ? 2u : 1u);
+  st->rpw = rpw;
+}
+__global__ __launch_bounds__(256) void k_flag_tiles(uint32_t nrows, uint32_t ncols, const uint32_t* __restrict__ col_lo,
+                                                    const uint32_t* __restrict__ col_hi, uint32_t symmetric, uint32_t all_on,
+                                                    uint32_t wpb, uint32_t* __restrict__ tiles, uint32_t tiles_cap, PlanState* st) {
+  __shared__ uint32_t wcnt[4], base_s;
+  if (st->skip_tiled) return;
+  const uint32_t tr = st->rpw * wpb;
+  const uint32_t tiles_r = (nrows + tr - 1) / tr, tiles_c = (ncols + kTB - 1) / kTB;
+  const uint64_t all = (uint64_t)tiles_r * tiles_c;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // chunks of 256 consecutive tiles; inside a chunk the list keeps tile order
+  for (uint64_t c0 = (uint64_t)blockIdx.x * 256; c0 < all; c0 += (uint64_t)gridDim.x * 256) {
+    const uint64_t t = c0 + threadIdx.x;
+    uint32_t ti = 0, tj = 0;
+    bool on = false;
+    if (t < all) {
+      ti = (uint32_t)(t / tiles_c); tj = (uint32_t)(t % tiles_c);
+      on = tile_shares(ti, tj, tr, nrows, ncols, col_lo, col_hi, symmetric, all_on);
+    }
+    const uint64_t m = __ballot(on);
+    if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      base_s = tot ? atomicAdd(&st->ntiles, tot) : 0u;
+    }
+    __syncthreads();
+    if (on) {
+      uint32_t pos = base_s + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      for (int k = 0; k < w; k++) pos += wcnt[k];
+      if (pos < tiles_cap) { tiles[2 * pos] = ti; tiles[2 * pos + 1] = tj; }
+    }
+    __syncthreads();
+  }
+}
+
 struct TiledScratch {
-  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, perm, ovf;
+  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, work, plan,
+      pk0, pk1, pk2, pk3, rng, cnt;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -725,7 +921,7 @@ CompareStats compare_last_stats() { return g_stats; }
 struct TiledExperiments {
   uint32_t per_range = 24;            // pooled elements per sketch per range
   uint32_t capA = 1024, capB = 48;    // LDS dwords of the row pool; column elements per range
-  int rpw = 0, wpb = 4, minw = 8;     // rpw 0 = chosen from the block's shape
+  int rpw = 0, wpb = 4, minw = 8;     // rpw 0 = chosen by the plan
   bool xcd = true;
 };
 static const TiledExperiments& tiled_experiments() {
@@ -748,25 +944,41 @@ static const TiledExperiments& tiled_experiments() {
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
-                          &T.node, &T.parent, &T.root, &T.tiles, &T.perm, &T.ovf})
+                          &T.node, &T.parent, &T.root, &T.tiles, &T.work, &T.plan, &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt})
     b->release();
+}
+
+// byte passes of a radix sort that can differ among keys (component << 32 | index) with
+// component < M and index < n
+static uint32_t plan_key_passes(uint32_t M, uint32_t n) {
+  uint32_t mask = 0;
+  for (int b = 0; b < 4; b++) {
+    if (b == 0 || (n - 1) >> (8 * b)) mask |= 1u << b;
+    if (b == 0 || (M - 1) >> (8 * b)) mask |= 1u << (4 + b);
+  }
+  return mask;
 }
 
 static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
                          uint32_t max_len, uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
                          hipStream_t s, bool same_sets) {
   TiledScratch& T = tiled_scratch();
-  // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
-  const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
   const CompareTuning tune = g_tuning;
   const TiledExperiments& ex = tiled_experiments();
+  // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
+  const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
   const bool symmetric = same && row_nums == nullptr && tune.use_symmetry != 0;
   // a row block that is a slice of the column set (one rank's rows of the gathered signatures):
   // its ranks are a slice of the columns' ranks, nothing extra to sort
   const bool inside = !same && rows.hashes >= cols.hashes && rows.hashes + nr_elems <= cols.hashes + nc_elems;
   const uint64_t n = same ? nr_elems : (inside ? nc_elems : nr_elems + nc_elems);
   if (n >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
-  // ---- dictionary-encode: sort (hash, origin), run ids -> rank[origin]
+  const bool want_cc = out.count_common || out.containment;
+  T.plan.ensure(sizeof(PlanState));
+  PlanState* st = T.plan.as<PlanState>();
+  HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PlanState), s));
+
+  // ---- dictionary-encode: sort (hash, origin); run ids -> rank[origin] come later, if the tiled kernel runs
   T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 4); T.org1.ensure(n * 4);   // origins: element indices < 2^31
   if (inside) {
     HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
@@ -775,11 +987,13 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
   }
   hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint32_t>(), n);
+  // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
   int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), n,
-                               dev.scratch, s);
+                               dev.scratch, s, 0xffu);
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
-  // ---- components: which tiles can hold a pair that shares a hash
+
+  // ---- components of the "shares a hash" graph (lock-free union-find over the runs of equal hashes)
   const uint32_t M = same ? cols.n : rows.n + cols.n;
   T.node.ensure((size_t)(n + (inside ? nr_elems : 0)) * 4);
   T.parent.ensure((size_t)M * 4); T.root.ensure((size_t)M * 4);
@@ -803,181 +1017,186 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
                        (uint64_t)(rows.hashes - cols.hashes), T.parent.as<uint32_t>());
   hipLaunchKernelGGL(k_uf_roots, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M, T.root.as<uint32_t>());
   HIP_CHECK(hipGetLastError());
-  std::vector<uint32_t> h_root(M);
-  HIP_CHECK(hipMemcpyAsync(h_root.data(), T.root.ptr, (size_t)M * 4, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
-  const uint32_t* comp_r = h_root.data();
-  const uint32_t* comp_c = same ? h_root.data() : h_root.data() + rows.n;
-  TilePlan plan;
-  plan_order(comp_r, rows.n, comp_c, cols.n, M, &plan);
-  const bool want_cc = out.count_common || out.containment;
 
-  // ---- few sharing pairs: one workgroup per (column, its component's rows), no rank encoding
-  {
-    const std::vector<uint32_t>& rp = plan.rperm;
-    const std::vector<uint32_t>& cp = plan.cperm;
-    struct Box { uint32_t r0, r1, c0, c1; };
-    std::vector<Box> boxes;
-    uint64_t pairs = 0;
-    for (uint32_t i = 0, j = 0; i < rows.n && j < cols.n;) {
-      const uint32_t cr = comp_r[rp[i]], cc = comp_c[cp[j]];
-      if (cr < cc) { i++; continue; }
-      if (cc < cr) { j++; continue; }
-      uint32_t i1 = i, j1 = j;
-      while (i1 < rows.n && comp_r[rp[i1]] == cr) i1++;
-      while (j1 < cols.n && comp_c[cp[j1]] == cr) j1++;
-      boxes.push_back({i, i1, j, j1});
-      pairs += (uint64_t)(i1 - i) * (j1 - j);
-      i = i1; j = j1;
-    }
-    const bool take_comp = tune.route == kRouteComponents ? true
-                           : tune.route == kRouteTiled   ? false
-                                                         : (pairs <= tune.comp_pairs_limit && !tune.visit_all_tiles);
-    if (take_comp) {
-      constexpr uint32_t kRowsPerItem = 32;
-      std::vector<CompWork> work;
-      for (const Box& b : boxes)
-        for (uint32_t c = b.c0; c < b.c1; c++) {
-          const uint32_t rs = symmetric ? std::max(b.r0, c) : b.r0;   // same order on both axes: upper triangle only
-          for (uint32_t r = rs; r < b.r1; r += kRowsPerItem) work.push_back({cp[c], r, std::min(b.r1, r + kRowsPerItem)});
-        }
-      g_stats = CompareStats{};
-      g_stats.route = kRouteComponents;
-      g_stats.tiles_visited = pairs; g_stats.tiles_total = (uint64_t)rows.n * cols.n; g_stats.pairs_per_tile = 1;
-      const uint64_t np = (uint64_t)rows.n * cols.n;
-      dev.prof_begin(s);
-      hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
-                         cols.n, num, row_nums, out);
-      HIP_CHECK(hipGetLastError());
-      dev.prof_end("compare_fill", s);
-      if (!work.empty()) {
-        T.perm.ensure((size_t)rows.n * 4 + 8);
-        T.tiles.ensure(work.size() * sizeof(CompWork));
-        HIP_CHECK(hipMemcpyAsync(T.perm.ptr, rp.data(), (size_t)rows.n * 4, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(T.tiles.ptr, work.data(), work.size() * sizeof(CompWork), hipMemcpyHostToDevice, s));
-        const uint32_t col_max = max_len;   // bound on the longest column (max over both sides)
-        const bool q_lds = col_max <= 8192;
-        const size_t lds = q_lds ? (size_t)(col_max ? col_max : 1) * 8 : 16;
-        dev.prof_begin(s);
-#define SMH_CC(L_, C_) hipLaunchKernelGGL((k_compare_comp<L_, C_>), dim3((unsigned)work.size()), dim3(256), lds, s, rows, cols, \
-                                          reinterpret_cast<const CompWork*>(T.tiles.ptr), T.perm.as<uint32_t>(), num, row_nums, \
-                                          symmetric ? 1u : 0u, out)
-        if (q_lds) { if (want_cc) SMH_CC(true, true); else SMH_CC(true, false); }
-        else { if (want_cc) SMH_CC(false, true); else SMH_CC(false, false); }
-#undef SMH_CC
-        HIP_CHECK(hipGetLastError());
-        dev.prof_end("compare_comp", s);
-      }
-      HIP_CHECK(hipStreamSynchronize(s));   // work / perm staging vectors are stack-lifetime
-      return;
-    }
-  }
-
-  T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
-  const uint32_t nruns = run_length_encode_u64(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so,
-                                               T.rank.as<uint32_t>());
-  // ---- ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords
-  // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
-  // sketches walk several ranges per step
-  uint64_t avg = max_len;
-  const uint32_t per_range = ex.per_range;
-  uint32_t R = (uint32_t)((avg + per_range - 1) / per_range);
-  if (R < 1) R = 1;
-  if (R > 8192) R = 8192;
-  T.bound.ensure((size_t)(R + 1) * 4);
-  hipLaunchKernelGGL(k_bounds, dim3((R + 1 + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), nruns, (uint32_t)n, R,
-                     T.bound.as<uint32_t>());
-  const uint32_t* rrank = T.rank.as<uint32_t>();
-  const uint32_t* crank = same ? rrank : rrank + nr_elems;
-  if (inside) { crank = T.rank.as<uint32_t>(); rrank = crank + (rows.hashes - cols.hashes); }
-  T.rpart.ensure((size_t)rows.n * (R + 1) * 4);
-  hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)rows.n * (R + 1) + 255) / 256)), dim3(256), 0, s, rrank, rows.offsets,
-                     rows.n, T.bound.as<uint32_t>(), R, T.rpart.as<uint32_t>());
-  const uint32_t* cpart = T.rpart.as<uint32_t>();
+  // ---- slot orders: sketches sorted by component (stable: the index is the low half of the key)
+  const uint32_t* root_r = T.root.as<uint32_t>();
+  const uint32_t* root_c = same ? root_r : root_r + rows.n;
+  T.pk0.ensure((size_t)rows.n * 8); T.pk1.ensure((size_t)rows.n * 8);
+  hipLaunchKernelGGL(k_plan_keys, dim3((rows.n + 255) / 256), dim3(256), 0, s, root_r, rows.n, T.pk0.as<uint64_t>());
+  const uint64_t* rkey = radix_sort_u64_keys(T.pk0.as<uint64_t>(), T.pk1.as<uint64_t>(), rows.n, dev.scratch, s,
+                                             plan_key_passes(M, rows.n)) ? T.pk1.as<uint64_t>() : T.pk0.as<uint64_t>();
+  const uint64_t* ckey = rkey;
   if (!same) {
-    T.cpart.ensure((size_t)cols.n * (R + 1) * 4);
-    hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)cols.n * (R + 1) + 255) / 256)), dim3(256), 0, s, crank, cols.offsets,
-                       cols.n, T.bound.as<uint32_t>(), R, T.cpart.as<uint32_t>());
-    cpart = T.cpart.as<uint32_t>();
+    T.pk2.ensure((size_t)cols.n * 8); T.pk3.ensure((size_t)cols.n * 8);
+    hipLaunchKernelGGL(k_plan_keys, dim3((cols.n + 255) / 256), dim3(256), 0, s, root_c, cols.n, T.pk2.as<uint64_t>());
+    ckey = radix_sort_u64_keys(T.pk2.as<uint64_t>(), T.pk3.as<uint64_t>(), cols.n, dev.scratch, s, plan_key_passes(M, cols.n))
+               ? T.pk3.as<uint64_t>() : T.pk2.as<uint64_t>();
   }
+  // ---- per slot, the other side's slots of the same component; pairs that can share a hash
+  T.rng.ensure(((size_t)rows.n + cols.n) * 2 * 4);
+  uint32_t* col_lo = T.rng.as<uint32_t>();           // by row slot
+  uint32_t* col_hi = col_lo + rows.n;
+  uint32_t* row_lo = same ? col_lo : col_hi + rows.n; // by column slot
+  uint32_t* row_hi = same ? col_hi : row_lo + cols.n;
+  hipLaunchKernelGGL(k_plan_ranges, dim3((rows.n + 255) / 256), dim3(256), 0, s, rkey, rows.n, ckey, cols.n, col_lo, col_hi, st);
+  if (!same)
+    hipLaunchKernelGGL(k_plan_ranges, dim3((cols.n + 255) / 256), dim3(256), 0, s, ckey, cols.n, rkey, rows.n, row_lo, row_hi,
+                       (PlanState*)nullptr);
+  hipLaunchKernelGGL(k_plan_route, dim3(1), dim3(1), 0, s, st, tune.route, tune.visit_all_tiles, (unsigned long long)tune.comp_pairs_limit);
   HIP_CHECK(hipGetLastError());
-  TiledArgs a;
-  a.rrank = rrank; a.roff = rows.offsets; a.rpart = T.rpart.as<uint32_t>(); a.nrows = rows.n;
-  a.crank = crank; a.coff = cols.offsets; a.cpart = cpart; a.ncols = cols.n;
-  a.R = R; a.num = num; a.row_nums = row_nums;
-  // LDS budget per workgroup ~18 KB so that 8 workgroups of 4 waves fit a CU: the merge loop is a
-  // dependent LDS-read -> compare -> advance chain, and occupancy is what hides its latency
-  // (profiles/r01_compare_geometry.txt: 575 -> 1000 M pairs/s from 3 to 8 waves per SIMD)
-  a.capA = ex.capA;         // 16 rows x (~24 elements + sentinel) with 2.5x head-room
-  a.capBt = ex.capB * kTB;  // columns up to 47 elements in one range
-  a.out = out;
-  T.ovf.ensure(8);
-  HIP_CHECK(hipMemsetAsync(T.ovf.ptr, 0, 8, s));
-  a.ovf_steps = T.ovf.as<unsigned long long>();
-  const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;
-  // rows per wave: 16 (64-row tiles) amortises staging best; small problems use shorter tiles so
-  // that the launch still covers the chip several times
-  int rpw = 4, wpb = ex.wpb, minw = ex.minw;
-  // fewer than ~4 rounds of 16-row tiles over the chip: 8-row tiles keep all wave slots busy
-  // (1000 x 1000: 2.47 -> 2.20 ms, profiles/r01_compare_small_geometry.txt)
-  if ((uint64_t)((rows.n + 15) / 16) * ((cols.n + kTB - 1) / kTB) < (uint64_t)dev.cu_count() * 32) rpw = 2;
-  if (ex.rpw) rpw = ex.rpw;
-  // sketches of one component become adjacent (stable: original order inside a component); then
-  // the tiles that can hold a same-component pair (tile_plan.cpp, host only)
-  const bool all_on = tune.visit_all_tiles != 0;
-  uint32_t tr = (uint32_t)(rpw * wpb);
-  plan_tiles(comp_r, rows.n, comp_c, cols.n, tr, kTB, symmetric, all_on, &plan);
-  if (ex.rpw == 0 && wpb == 4 && minw == 8) {
-    // few tiles left: shorter ones fill the chip better (the kernel is latency bound, a
-    // workgroup per CU leaves 7/8 of the wave slots empty)
-    while (rpw > 1 && plan.tiles.size() / 2 < (size_t)dev.cu_count() * 32) {
-      rpw >>= 1; tr = (uint32_t)(rpw * wpb);
-      plan_tiles(comp_r, rows.n, comp_c, cols.n, tr, kTB, symmetric, all_on, &plan);
-    }
-  }
-  const std::vector<uint32_t>& rperm = plan.rperm;
-  const std::vector<uint32_t>& cperm = plan.cperm;
-  const std::vector<uint32_t>& tile_list = plan.tiles;
-  const uint32_t tiles = (uint32_t)(tile_list.size() / 2);
-  const uint64_t all_tiles = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
-  g_stats = CompareStats{};
-  g_stats.route = kRouteTiled; g_stats.rows_per_tile = tr;
-  g_stats.tiles_visited = tiles; g_stats.tiles_total = all_tiles; g_stats.pairs_per_tile = (uint64_t)tr * kTB;
-  T.perm.ensure(((size_t)rows.n + cols.n) * 4 + 8);
-  T.tiles.ensure(tile_list.size() * 4 + 8);
-  HIP_CHECK(hipMemcpyAsync(T.perm.ptr, rperm.data(), (size_t)rows.n * 4, hipMemcpyHostToDevice, s));
-  HIP_CHECK(hipMemcpyAsync(T.perm.as<uint32_t>() + rows.n, cperm.data(), (size_t)cols.n * 4, hipMemcpyHostToDevice, s));
-  if (tiles) HIP_CHECK(hipMemcpyAsync(T.tiles.ptr, tile_list.data(), tile_list.size() * 4, hipMemcpyHostToDevice, s));
-  a.rperm = T.perm.as<uint32_t>(); a.cperm = T.perm.as<uint32_t>() + rows.n; a.tiles = T.tiles.as<uint32_t>();
-  a.symmetric = symmetric ? 1u : 0u;
-  if (tiles < all_tiles) {
-    const uint64_t np = (uint64_t)rows.n * cols.n;
+
+  // ---- every pair as if it shared nothing; the compare kernels overwrite the pairs they walk
+  // (with every tile launched nothing would be left: skipped)
+  const uint64_t np = (uint64_t)rows.n * cols.n;
+  if (!(tune.visit_all_tiles && tune.route == kRouteTiled)) {
     dev.prof_begin(s);
     hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
                        cols.n, num, row_nums, out);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("compare_fill", s);
   }
-  if (tiles == 0) { HIP_CHECK(hipStreamSynchronize(s)); return; }
-  a.xcd_chunk = (tiles >= 64 && ex.xcd) ? tiles / 8 : 0;
-  dev.prof_begin(s);
-  bool launched = false;
-#define SMH_CT(R_, W_, M_)                                                                              \
-  if (!launched && rpw == R_ && wpb == W_ && minw == M_) {                                              \
-    launched = true;                                                                                    \
-    if (want_cc) hipLaunchKernelGGL((k_compare_tiled<true, R_, W_, M_>), dim3(tiles), dim3(64 * W_), lds, s, a);  \
-    else hipLaunchKernelGGL((k_compare_tiled<false, R_, W_, M_>), dim3(tiles), dim3(64 * W_), lds, s, a);        \
+
+  // ---- per-component pair kernel: one workgroup per (column, <= 32 rows of its component)
+  uint32_t work_cap = 0;
+  if (tune.route != kRouteTiled) {
+    // the route is taken when pairs <= comp_pairs_limit: every item holds a pair, every column adds at most one
+    // partly filled item.  (A forced route on a huge block is capped; the overflow is reported.)
+    uint64_t cap = (tune.route == kRouteComponents ? ((uint64_t)cols.n * ((rows.n + kRowsPerItem - 1) / kRowsPerItem))
+                                                   : tune.comp_pairs_limit) + cols.n;
+    if (cap > (1ull << 26)) cap = 1ull << 26;
+    work_cap = (uint32_t)cap;
+    T.cnt.ensure((size_t)cols.n * 4);
+    T.work.ensure((size_t)work_cap * sizeof(CompWork));
+    hipLaunchKernelGGL(k_comp_count, dim3((cols.n + 255) / 256), dim3(256), 0, s, cols.n, row_lo, row_hi, symmetric ? 1u : 0u,
+                       T.cnt.as<uint32_t>(), st);
+    exclusive_scan_u32_dev(T.cnt.as<uint32_t>(), cols.n, &st->nwork, dev.scratch, s);
+    hipLaunchKernelGGL(k_comp_fill, dim3((cols.n + 255) / 256), dim3(256), 0, s, ckey, cols.n, row_lo, row_hi, symmetric ? 1u : 0u,
+                       T.cnt.as<uint32_t>(), reinterpret_cast<CompWork*>(T.work.ptr), work_cap, st);
+    const uint32_t col_max = max_len;   // bound on the longest column (max over both sides)
+    const bool q_lds = col_max <= 8192;
+    const size_t lds = q_lds ? (size_t)(col_max ? col_max : 1) * 8 : 16;
+    const unsigned grid = (unsigned)std::min<uint64_t>(work_cap, (uint64_t)dev.cu_count() * 8);
+    dev.prof_begin(s);
+#define SMH_CC(L_, C_) hipLaunchKernelGGL((k_compare_comp<L_, C_>), dim3(grid), dim3(256), lds, s, rows, cols, \
+                                          reinterpret_cast<const CompWork*>(T.work.ptr), &st->nwork, work_cap, rkey, num, row_nums, \
+                                          symmetric ? 1u : 0u, out)
+    if (q_lds) { if (want_cc) SMH_CC(true, true); else SMH_CC(true, false); }
+    else { if (want_cc) SMH_CC(false, true); else SMH_CC(false, false); }
+#undef SMH_CC
+    HIP_CHECK(hipGetLastError());
+    dev.prof_end("compare_comp", s);
   }
-  SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
-  SMH_CT(4, 4, 8) SMH_CT(2, 4, 8) SMH_CT(1, 4, 8) SMH_CT(1, 8, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
+
+  // ---- tiled kernel: dense ranks, ranges of rank space, partition table, tile list, launch
+  const int wpb = ex.wpb, minw = ex.minw;
+  uint32_t tiles_cap = 0;
+  if (tune.route != kRouteComponents) {
+    const uint32_t* skip = &st->skip_tiled;
+    T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
+    run_length_encode_u64_async(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so, T.rank.as<uint32_t>(),
+                                &st->nruns, skip);
+    // ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords;
+    // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
+    // sketches walk several ranges per step
+    uint32_t R = (uint32_t)(((uint64_t)max_len + ex.per_range - 1) / ex.per_range);
+    if (R < 1) R = 1;
+    if (R > 8192) R = 8192;
+    T.bound.ensure((size_t)(R + 1) * 4);
+    hipLaunchKernelGGL(k_bounds, dim3((R + 1 + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), st, (uint32_t)n, R,
+                       T.bound.as<uint32_t>());
+    const uint32_t* rrank = T.rank.as<uint32_t>();
+    const uint32_t* crank = same ? rrank : rrank + nr_elems;
+    if (inside) { crank = T.rank.as<uint32_t>(); rrank = crank + (rows.hashes - cols.hashes); }
+    T.rpart.ensure((size_t)rows.n * (R + 1) * 4);
+    hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)rows.n * (R + 1) + 255) / 256)), dim3(256), 0, s, rrank, rows.offsets,
+                       rows.n, T.bound.as<uint32_t>(), R, T.rpart.as<uint32_t>(), st);
+    const uint32_t* cpart = T.rpart.as<uint32_t>();
+    if (!same) {
+      T.cpart.ensure((size_t)cols.n * (R + 1) * 4);
+      hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)cols.n * (R + 1) + 255) / 256)), dim3(256), 0, s, crank, cols.offsets,
+                         cols.n, T.bound.as<uint32_t>(), R, T.cpart.as<uint32_t>(), st);
+      cpart = T.cpart.as<uint32_t>();
+    }
+    // rows per tile: decided on the device from the number of 16-row tiles that hold sharing pairs
+    // (fewer than ~4 rounds over the chip: 8-row, then 4-row tiles keep all wave slots busy;
+    // profiles/r01_compare_small_geometry.txt).  With every tile launched the count is known here.
+    const uint32_t fill_tiles = (uint32_t)dev.cu_count() * 32;
+    const uint32_t tiles_c = (cols.n + kTB - 1) / kTB;
+    uint32_t forced_rpw = ex.rpw > 0 ? (uint32_t)ex.rpw : 0u;
+    if (!forced_rpw && tune.visit_all_tiles) {
+      const uint64_t all16 = (uint64_t)((rows.n + 15) / 16) * tiles_c * (symmetric ? 1 : 2) / 2;
+      forced_rpw = all16 >= fill_tiles ? 4u : (2 * all16 >= fill_tiles ? 2u : 1u);
+    }
+    if (!forced_rpw)
+      hipLaunchKernelGGL(k_tiles_count16, dim3((unsigned)std::min<uint64_t>(((uint64_t)((rows.n + 15) / 16) * tiles_c + 255) / 256, 4096)),
+                         dim3(256), 0, s, rows.n, cols.n, col_lo, col_hi, symmetric ? 1u : 0u, st);
+    hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, fill_tiles);
+    // the list: at 16 rows per tile at most every tile; shorter tiles are only chosen when fewer than
+    // fill_tiles 16-row tiles are flagged (each splits into at most 4)
+    const uint32_t rows_min = (forced_rpw ? forced_rpw : 1u) * (uint32_t)wpb;
+    uint64_t cap = forced_rpw ? (uint64_t)((rows.n + rows_min - 1) / rows_min) * tiles_c
+                              : std::max<uint64_t>((uint64_t)((rows.n + 4 * wpb - 1) / (4 * wpb)) * tiles_c, 4ull * fill_tiles);
+    if (cap >= (1ull << 30)) throw_internal("compare block: too many tiles");
+    tiles_cap = (uint32_t)cap;
+    T.tiles.ensure((size_t)tiles_cap * 8 + 8);
+    const uint64_t flag_tiles = (uint64_t)((rows.n + rows_min - 1) / rows_min) * tiles_c;   // the finest geometry the plan may pick
+    hipLaunchKernelGGL(k_flag_tiles, dim3((unsigned)std::min<uint64_t>((flag_tiles + 255) / 256, 8192)), dim3(256), 0, s, rows.n, cols.n,
+                       col_lo, col_hi, symmetric ? 1u : 0u, tune.visit_all_tiles ? 1u : 0u, (uint32_t)wpb, T.tiles.as<uint32_t>(),
+                       tiles_cap, st);
+    HIP_CHECK(hipGetLastError());
+    TiledArgs a;
+    a.rrank = rrank; a.roff = rows.offsets; a.rpart = T.rpart.as<uint32_t>(); a.nrows = rows.n;
+    a.crank = crank; a.coff = cols.offsets; a.cpart = cpart; a.ncols = cols.n;
+    a.R = R; a.num = num; a.row_nums = row_nums;
+    a.tiles = T.tiles.as<uint32_t>(); a.tiles_cap = tiles_cap; a.rkey = rkey; a.ckey = ckey; a.st = st;
+    a.use_xcd = ex.xcd ? 1u : 0u;
+    a.symmetric = symmetric ? 1u : 0u;
+    // LDS budget per workgroup ~18 KB so that 8 workgroups of 4 waves fit a CU: the merge loop is a
+    // dependent LDS-read -> compare -> advance chain, and occupancy is what hides its latency
+    // (profiles/r01_compare_geometry.txt: 575 -> 1000 M pairs/s from 3 to 8 waves per SIMD)
+    a.capA = ex.capA;         // 16 rows x (~24 elements + sentinel) with 2.5x head-room
+    a.capBt = ex.capB * kTB;  // columns up to 47 elements in one range
+    a.ovf_steps = &st->ovf_steps;
+    a.out = out;
+    const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;
+    const unsigned grid = (unsigned)dev.cu_count() * 8;   // a multiple of 8: one stretch of the list per XCD
+    dev.prof_begin(s);
+    bool launched = false;
+#define SMH_CT(R_, W_, M_)                                                                                           \
+  if ((forced_rpw == 0 || forced_rpw == R_) && wpb == W_ && minw == M_) {                                          \
+    launched = true;                                                                                                 \
+    if (want_cc) hipLaunchKernelGGL((k_compare_tiled<true, R_, W_, M_>), dim3(grid), dim3(64 * W_), lds, s, a);    \
+    else hipLaunchKernelGGL((k_compare_tiled<false, R_, W_, M_>), dim3(grid), dim3(64 * W_), lds, s, a);           \
+  }
+    SMH_CT(4, 4, 8) SMH_CT(2, 4, 8) SMH_CT(1, 4, 8)
+#ifdef SMH_EXPERIMENTS
+    SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
+    SMH_CT(1, 8, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
+#endif
 #undef SMH_CT
-  if (!launched) throw_internal("compare geometry not instantiated");
-  HIP_CHECK(hipGetLastError());
-  dev.prof_end("compare_tiled", s);
-  unsigned long long ovf = 0;
-  HIP_CHECK(hipMemcpyAsync(&ovf, T.ovf.ptr, 8, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));   // tile_list / rperm / cperm are stack-lifetime staging vectors
-  g_stats.lds_overflow_steps = ovf;
+    if (!launched) throw_internal("compare geometry not instantiated");
+    HIP_CHECK(hipGetLastError());
+    dev.prof_end("compare_tiled", s);
+  }
+
+  // ---- the one synchronisation of the call: what the plan decided, for the record
+  PlanState h;
+  HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(PlanState), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  g_stats = CompareStats{};
+  g_stats.route = h.route;
+  if (h.route == kRouteComponents) {
+    if (h.nwork > work_cap) throw_internal("compare block: the per-component route was forced on a block with too many sharing pairs");
+    g_stats.tiles_visited = h.pairs; g_stats.tiles_total = np; g_stats.pairs_per_tile = 1;
+  } else {
+    if (h.ntiles > tiles_cap) throw_internal("compare block: tile list overflow");
+    const uint32_t tr = h.rpw * (uint32_t)wpb;
+    g_stats.rows_per_tile = tr;
+    g_stats.tiles_visited = h.ntiles;
+    g_stats.tiles_total = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
+    g_stats.pairs_per_tile = (uint64_t)tr * kTB;
+    g_stats.lds_overflow_steps = h.ovf_steps;
+  }
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,

@@ -9,7 +9,6 @@
 
 #include "../../include/sourmash_amd.h"
 #include "minhash.hpp"
-#include "tile_plan.hpp"
 #include "signature.hpp"
 
 using smh::Error;
@@ -775,21 +774,6 @@ int smh_compare_set_tuning(const SmhCompareTuning* in) {
 }
 
 // test hook (host only, no device): the compare block's tile planning
-int smh_test_plan_tiles(const uint32_t* comp_r, uint32_t nrows, const uint32_t* comp_c, uint32_t ncols, uint32_t max_comp,
-                        uint32_t tr, uint32_t tc, bool symmetric, uint32_t* rperm_out, uint32_t* cperm_out,
-                        uint32_t* tiles_out, uint32_t tiles_cap, uint32_t* n_tiles) {
-  return pad_code([&] {
-    require(n_tiles, "n_tiles");
-    smh::TilePlan plan;
-    smh::plan_order(comp_r, nrows, comp_c, ncols, max_comp, &plan);
-    smh::plan_tiles(comp_r, nrows, comp_c, ncols, tr, tc, symmetric, false, &plan);
-    *n_tiles = (uint32_t)(plan.tiles.size() / 2);
-    if (rperm_out) std::copy(plan.rperm.begin(), plan.rperm.end(), rperm_out);
-    if (cperm_out) std::copy(plan.cperm.begin(), plan.cperm.end(), cperm_out);
-    if (tiles_out && plan.tiles.size() <= (size_t)tiles_cap * 2) std::copy(plan.tiles.begin(), plan.tiles.end(), tiles_out);
-  });
-}
-
 int smh_release_workspace(void) {
   return pad_code([&] { smh::Engine::get().release_workspace(); });
 }

@@ -91,8 +91,18 @@ void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed,
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
                    DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8);
 // the same with a 32-bit payload (indices): a quarter less traffic per pass
+// pass_mask != 0: run exactly the byte passes whose bit is set instead of reading the digit histograms
+// back to skip constant bytes -- no host synchronisation inside the sort
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                       hipStream_t s);
+                       hipStream_t s, uint32_t pass_mask = 0);
+int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask);
+// run_length_encode_u64 without its read-back: *nruns_dev (device) receives the number of runs;
+// skip (device, nullable): non-zero = the launches do nothing
+void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
+                                 hipStream_t s, const uint32_t* origin, uint32_t* rank_out, uint32_t* nruns_dev,
+                                 const uint32_t* skip);
+// in-place exclusive scan of m u32 counters; *total (device, nullable) receives their sum
+void exclusive_scan_u32_dev(uint32_t* d, size_t m, uint32_t* total, DeviceBuffer& scratch, hipStream_t s);
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).
 // origin / rank_out (optional): also write rank_out[origin[i]] = run id of sorted position i.
 // key2 / uniq2 (optional): a more significant second key (array sorted by (key2, keys)); a run

@@ -301,8 +301,10 @@ __device__ __forceinline__ bool is_head(const uint64_t* keys, const uint64_t* ke
 
 __global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __restrict__ keys,
                                                            const uint64_t* __restrict__ key2, int sh2,
-                                                           size_t n, uint32_t* __restrict__ bc) {
+                                                           size_t n, uint32_t* __restrict__ bc,
+                                                           const uint32_t* __restrict__ skip) {
   __shared__ uint32_t wsum[kRleThreads / 64];
+  if (skip && *skip) return;   // a device-side plan decided that this result is not needed
   size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
   uint32_t c = 0;
 #pragma unroll
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
                                                            uint64_t* __restrict__ uniq,
                                                            uint32_t* __restrict__ starts,
                                                            const uint32_t* __restrict__ origin,
-                                                           uint32_t* __restrict__ rank_out) {
+                                                           uint32_t* __restrict__ rank_out,
+                                                           const uint32_t* __restrict__ skip) {
   __shared__ uint32_t wsum[kRleThreads / 64];
+  if (skip && *skip) return;
   size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
   uint32_t flags = 0, c = 0;
 #pragma unroll
@@ -430,8 +434,10 @@ static void exclusive_scan_u32(uint32_t* d, size_t m, uint32_t* total, uint32_t*
 }
 static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanChunk + 1; }
 
+// pass_mask != 0: run exactly the byte passes whose bit is set (the caller knows which bytes of the
+// keys can differ) -- no digit-histogram read-back, so no host synchronisation inside the sort.
 static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
-                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
+                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
   if (n <= (size_t)kSmallSortMax && first_pass == 0 && last_pass == 8) {
@@ -450,22 +456,26 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   auto* blockhist = (uint32_t*)((char*)scratch.ptr + hist_bytes);
   auto* scan_tmp = (uint32_t*)((char*)scratch.ptr + hist_bytes + bh_bytes);
 
-  HIP_CHECK(hipMemsetAsync(ghist, 0, hist_bytes, s));
-  int hb = (int)((n + 255) / 256);
-  if (hb > 2048) hb = 2048;
-  hipLaunchKernelGGL(k_hist_all, dim3(hb), dim3(256), 0, s, k0, n, ghist);
-  HIP_CHECK(hipGetLastError());
   unsigned long long hh[8 * 256];
-  HIP_CHECK(hipMemcpyAsync(hh, ghist, hist_bytes, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
+  if (!pass_mask) {
+    HIP_CHECK(hipMemsetAsync(ghist, 0, hist_bytes, s));
+    int hb = (int)((n + 255) / 256);
+    if (hb > 2048) hb = 2048;
+    hipLaunchKernelGGL(k_hist_all, dim3(hb), dim3(256), 0, s, k0, n, ghist);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(hh, ghist, hist_bytes, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
 
   int cur = 0;
   uint64_t* kk[2] = {k0, k1};
   void* vv[2] = {v0, v1};
   for (int p = first_pass; p < last_pass; p++) {
     bool trivial = false;
-    for (int d = 0; d < 256; d++)
-      if (hh[p * 256 + d] == n) { trivial = true; break; }
+    if (pass_mask) trivial = !((pass_mask >> p) & 1u);
+    else
+      for (int d = 0; d < 256; d++)
+        if (hh[p * 256 + d] == n) { trivial = true; break; }
     if (trivial) continue;  // every key has the same digit: the pass is the identity
     hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
                        blockhist, nblocks);
@@ -490,8 +500,29 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
   return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass);
 }
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                       hipStream_t s) {
-  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8);
+                       hipStream_t s, uint32_t pass_mask) {
+  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask);
+}
+int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask) {
+  return radix_sort_impl(k0, k1, nullptr, nullptr, 0, n, scratch, s, 0, 8, pass_mask);
+}
+
+// the launches of run_length_encode_u64 without the read-back: *nruns_dev receives the number of runs.
+// skip (device, nullable): non-zero = do nothing (the caller's device-side plan does not need the result)
+void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
+                                 hipStream_t s, const uint32_t* origin, uint32_t* rank_out, uint32_t* nruns_dev,
+                                 const uint32_t* skip) {
+  if (n == 0) { HIP_CHECK(hipMemsetAsync(nruns_dev, 0, 4, s)); return; }
+  if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
+  const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
+  scratch.ensure((size_t)(nblocks + 1 + scan_tmp_entries(nblocks)) * sizeof(uint32_t));
+  auto* bc = (uint32_t*)scratch.ptr;
+  hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, n, bc, skip);
+  exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
+  hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, (uint64_t*)nullptr, n, bc,
+                     uniq, starts, origin, rank_out, skip);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(nruns_dev, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 }
 
 uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts,
@@ -502,10 +533,10 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
   scratch.ensure((size_t)(nblocks + 1 + scan_tmp_entries(nblocks)) * sizeof(uint32_t));
   auto* bc = (uint32_t*)scratch.ptr;
-  hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, n, bc);
+  hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, n, bc, (const uint32_t*)nullptr);
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, uniq2, n, bc, uniq,
-                     starts, origin, rank_out);
+                     starts, origin, rank_out, (const uint32_t*)nullptr);
   HIP_CHECK(hipGetLastError());
   uint32_t nruns = 0;
   HIP_CHECK(hipMemcpyAsync(&nruns, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -513,7 +544,13 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   return nruns;
 }
 
-// positions -> group ids, in place: record = last r with rec_starts[r] <= pos
+// exclusive scan of m counters in place (+ their total), for the compare planner
+void exclusive_scan_u32_dev(uint32_t* d, size_t m, uint32_t* total, DeviceBuffer& scratch, hipStream_t s) {
+  if (m == 0) { if (total) HIP_CHECK(hipMemsetAsync(total, 0, 4, s)); return; }
+  scratch.ensure(scan_tmp_entries(m) * sizeof(uint32_t));
+  exclusive_scan_u32(d, m, total, (uint32_t*)scratch.ptr, s);
+}
+
 __global__ __launch_bounds__(256) void k_pos_to_group(uint64_t* __restrict__ pos, uint64_t n,
                                                       const uint64_t* __restrict__ rec_starts, uint32_t nrec,
                                                       const uint32_t* __restrict__ group_of_rec, int keep_bits) {

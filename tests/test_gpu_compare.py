@@ -264,6 +264,55 @@ def test_matrix_at_c4_size_vs_oracle(pkg, coracle):
     _full_size_matrix_check(pkg, coracle, 10000, 4, rows, [(dict(), "tiled")])
 
 
+@pytest.mark.parametrize("n,n_fam,sym", [(700, 7, True), (1500, 50, True), (900, 13, False)])
+def test_device_plan_matches_an_independent_tile_count(n, n_fam, sym, pkg):
+    """The block compare plans on the device (slot order by connected component, tiles that can hold
+    sharing pairs, rows per tile).  For a collection whose components are known by construction --
+    interleaved families, one hash pool each -- the number of tiles it launched must equal the count
+    worked out here with numpy from that structure alone (component id = smallest member, slots in
+    (component, index) order, a tile is launched iff some row slot and some column slot of it share a
+    component, tiles wholly below the diagonal are mirrored when rows == columns with one num)."""
+    import torch
+    from sourmash_rust_amd import synth
+    sigs = synth.family_signatures(0, n, num=300, n_families=n_fam, pool=600, private=100, seed=11)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(300)
+    if sym:
+        rows_t, ro, row_idx = t, off, np.arange(n)
+    else:
+        row_idx = np.arange(0, n, 3)                       # a different row set: every third signature
+        rows_t = t[torch.from_numpy(row_idx).cuda()].contiguous()
+        ro = np.arange(len(row_idx) + 1, dtype=np.uint64) * np.uint64(300)
+    with pkg.matrix.tuning(route="tiled"):
+        out = pkg.matrix.compare_block_dev(rows_t, ro, t, off, 300, want=("jaccard",))
+        st = pkg.matrix.last_stats()
+    assert st["route"] == "tiled"
+    fam_c = np.arange(n) % n_fam                            # family == component (pools are disjoint, members overlap)
+    fam_r = row_idx % n_fam
+    # component id = root of the union-find = smallest node id in the component; rows are nodes 0.., columns follow
+    # (or ARE the rows when both sides are one list): the relative ORDER of components is all that matters here
+    first_r = {f: int(np.flatnonzero(fam_r == f)[0]) for f in range(n_fam)}
+    comp_key = {f: first_r[f] for f in range(n_fam)} if not sym else {f: f for f in range(n_fam)}
+    rslots = sorted(range(len(row_idx)), key=lambda i: (comp_key[fam_r[i]], i))
+    cslots = sorted(range(n), key=lambda j: (comp_key[fam_c[j]], j))
+    tr, tc = st["rows_per_tile"], 64
+    tiles_r, tiles_c = -(-len(rslots) // tr), -(-n // tc)
+    assert st["tiles_total"] == tiles_r * tiles_c
+    rf = np.array([fam_r[i] for i in rslots]); cf = np.array([fam_c[j] for j in cslots])
+    count = 0
+    for ti in range(tiles_r):
+        fr = set(rf[ti * tr:(ti + 1) * tr].tolist())
+        for tj in range(tiles_c):
+            if sym and tj * tc + tc - 1 < ti * tr:
+                continue
+            if fr & set(cf[tj * tc:(tj + 1) * tc].tolist()):
+                count += 1
+    assert st["tiles_visited"] == count, (st, count)
+    j = out["jaccard"].cpu().numpy()
+    same = fam_r[:, None] == fam_c[None, :]
+    assert (j[~same] == 0).all() and (j[same] > 0).all()
+
+
 def test_tiled_global_merge_branch(pkg, coracle):
     """A range whose segments do not fit the tiled kernel's LDS stage is merged straight from global
     memory.  Sketches that pack 2 000 hashes into a sliver of hash space (where everything else is
