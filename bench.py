@@ -250,7 +250,7 @@ def main():
     # Counter-derived figures come from the committed rocprofv3 --pmc passes of exactly this workload
     # (profiles/), NOT from this run: HBM bytes per launch (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and
     # VALU wave-instructions per 64 k-mers (SQ_INSTS_VALU / wave steps).
-    traffic, traffic_src, valu = None, None, None
+    traffic, traffic_src, valu, half_share = None, None, None, None
     for name in ("r02_pmc_dna_rolling.json", "r01_pmc_dna_rolling.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -259,6 +259,8 @@ def main():
         if abs(total - 10e9) < 1 and launches_per_step == 1.0:
             traffic = pmc.get("hbm_bytes_per_launch")
             valu = pmc.get("valu_insts_per_64_kmers")
+            if pmc.get("static_half_rate_per_kmer") is not None:
+                half_share = pmc["static_half_rate_per_kmer"] / (pmc["static_half_rate_per_kmer"] + pmc["static_full_rate_per_kmer"])
             traffic_src = "profiles/%s: separate rocprofv3 --pmc passes of this command, committed; not measured in this run" % name
         break
     valu_bound = None
@@ -268,7 +270,15 @@ def main():
                       "clock_hz": MAX_CLOCK_HZ, "floor_ms": floor_ms, "frac": floor_ms / kern_ms,
                       "kernel_kmers_per_s": kmers_per_launch / (kern_ms * 1e-3),
                       "label": "VALU issue floor from MI355X_MICROARCH.md (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz) "
-                               "for the kernel's measured instruction count; frac = floor / measured kernel time"}
+                               "for the kernel's measured instruction count (SQ_INSTS_VALU, committed PMC pass); "
+                               "frac = floor / measured kernel time.  NB: relative to the kernel's OWN instruction count -- "
+                               "removing instructions lowers it; kernel_kmers_per_s is the absolute figure"}
+        if half_share is not None:
+            # the share of half-rate instructions (multiplies, v_mad_u64_u32, three-operand forms: 4 cycles each) from the
+            # static count of the loop (tools/isa_count.py), applied to the measured instruction count
+            wfloor = floor_ms * (1.0 + half_share)
+            valu_bound["rate_weighted"] = {"half_rate_share": half_share, "floor_ms": wfloor, "frac": wfloor / kern_ms,
+                                           "label": "the same floor with the kernel's half-rate instructions priced at 4 cycles"}
 
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
