@@ -22,7 +22,7 @@ def pytest_configure(config):
     # a hung test must fail with a traceback of where it hangs, not stall the whole run in silence
     # (pytest-timeout is part of the image; without it the option simply does not exist)
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
-        config.option.timeout = 600
+        config.option.timeout = 840
 
 
 @pytest.fixture(scope="session")
