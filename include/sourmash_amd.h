@@ -135,6 +135,9 @@ typedef struct SmhCompareTuning {
   uint32_t visit_all_tiles;   /* tiled route: 1 = launch every tile, not only those that can hold pairs sharing a hash */
   uint32_t use_symmetry;      /* default 1: all-vs-all with one num computes the upper triangle and mirrors it */
   uint64_t comp_pairs_limit;  /* AUTO: at most this many sharing pairs -> per-component pair kernel (default 2^18) */
+  uint32_t split_frequent;    /* default 1: hashes held by more than a quarter of the sketches (at most 64 of them) do not
+                                 connect sketches; pairs that share only such hashes are decided from per-sketch records
+                                 instead of being walked */
 } SmhCompareTuning;
 void smh_compare_get_tuning(SmhCompareTuning *out);
 int smh_compare_set_tuning(const SmhCompareTuning *tuning);   /* NULL restores the defaults; process-wide */
@@ -148,6 +151,7 @@ typedef struct SmhCompareStats {
   uint64_t tiles_total;         /* tiled: tiles in the block; components: pairs in the block */
   uint64_t pairs_per_tile;
   uint64_t lds_overflow_steps;  /* tiled: (tile, range) steps merged from global memory instead of the LDS stage */
+  uint32_t frequent_hashes;     /* hashes set aside as frequent in this block (0 = none, or too many to set aside) */
 } SmhCompareStats;
 void smh_compare_last_stats(SmhCompareStats *out);
 

@@ -19,12 +19,13 @@ class SourmashStr(C.Structure):
 
 class SmhCompareTuning(C.Structure):
     _fields_ = [("route", C.c_uint32), ("visit_all_tiles", C.c_uint32), ("use_symmetry", C.c_uint32),
-                ("comp_pairs_limit", C.c_uint64)]
+                ("comp_pairs_limit", C.c_uint64), ("split_frequent", C.c_uint32)]
 
 
 class SmhCompareStats(C.Structure):
     _fields_ = [("route", C.c_uint32), ("rows_per_tile", C.c_uint32), ("tiles_visited", C.c_uint64),
-                ("tiles_total", C.c_uint64), ("pairs_per_tile", C.c_uint64), ("lds_overflow_steps", C.c_uint64)]
+                ("tiles_total", C.c_uint64), ("pairs_per_tile", C.c_uint64), ("lds_overflow_steps", C.c_uint64),
+                ("frequent_hashes", C.c_uint32)]
 
 
 def build(force=False):

@@ -364,7 +364,11 @@ struct PlanState {
   uint32_t nruns;                // distinct hashes of the pool (dense ranks)
   uint32_t count16;              // tiles that hold sharing pairs at the 16-row geometry
   uint32_t next_tile[8];         // tiled: tiles handed out so far, per XCD stretch of the list
+  uint32_t nfreq_seen;           // runs of the pool longer than the frequency threshold
+  uint32_t nfreq;                // frequent hashes set aside (0 when there were more than kMaxFreq: nothing is set aside)
+  uint32_t freq_run[64];         // their run ids, ascending (= ascending hash) once k_freq_finalize has run
 };
+constexpr uint32_t kMaxFreq = 64;
 
 struct TiledArgs {
   const uint32_t* rrank; const uint64_t* roff; const uint32_t* rpart; uint32_t nrows;
@@ -713,10 +717,12 @@ __global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
 // view prove the two are connected -- and only the few that are not go to the atomic path.
 template <int Shift, bool Filter>
 __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
-                                                 const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent) {
+                                                 const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent,
+                                                 const uint32_t* __restrict__ runid, const uint8_t* __restrict__ isfreq) {
   uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) << Shift;
   if (i == 0 || i >= n) return;
   if (keys[i] != keys[i - 1]) return;
+  if (isfreq && isfreq[runid[i]]) return;   // a frequent hash connects nothing (see "frequent hashes" below)
   uint32_t a = node[origin[i]], b = node[origin[i - 1]];
   if (a == b) return;
   if (Filter) {
@@ -737,22 +743,99 @@ __global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, 
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) root[i] = uf_find(parent, i);
 }
-// every pair as if it shared nothing; the tiled kernel then overwrites the tiles it visits
+// ---- frequent hashes --------------------------------------------------------------------------------
+// One hash held by every sketch (a contaminant, an adapter k-mer) makes one component out of unrelated
+// genomes, and every pair would have to be walked.  Hashes whose run in the sorted pool is longer than a
+// share of the sketches are therefore set aside (at most kMaxFreq of them, else none): they do not unite
+// anything in the union-find, so the components are the clusters of everything else.  Two sketches in
+// different clusters can then share ONLY frequent hashes, and their pair follows from two small per-sketch
+// records -- a bit mask of the frequent hashes the sketch holds and the position of each inside it: for the
+// k-th shared one (ascending), the union holds posA + posB - k smaller elements, which decides whether it
+// lies inside the first n of the union (reference src/lib.rs:470-499); |A u B| = |A| + |B| - shared.
+// Exact for any threshold: the threshold only moves work between the walk and this rule.
+__global__ __launch_bounds__(256) void k_freq_mark(const uint32_t* __restrict__ starts, uint32_t n, uint32_t threshold,
+                                                   PlanState* st) {
+  const uint32_t nruns = st->nruns;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += gridDim.x * blockDim.x) {
+    const uint32_t len = (r + 1 < nruns ? starts[r + 1] : n) - starts[r];
+    if (len > threshold) {
+      const uint32_t k = atomicAdd(&st->nfreq_seen, 1u);
+      if (k < kMaxFreq) st->freq_run[k] = r;
+    }
+  }
+}
+// one wave: sort the (at most 64) run ids, decide, mark
+__global__ __launch_bounds__(64) void k_freq_finalize(PlanState* st, uint8_t* __restrict__ isfreq) {
+  const uint32_t seen = st->nfreq_seen, lane = threadIdx.x;
+  if (seen == 0 || seen > kMaxFreq) { if (lane == 0) st->nfreq = 0; return; }
+  const uint32_t mine = lane < seen ? st->freq_run[lane] : 0xffffffffu;
+  uint32_t rank = 0;
+  for (uint32_t k = 0; k < seen; k++) rank += (uint32_t)__shfl((int)mine, (int)k) < mine ? 1u : 0u;   // run ids are distinct
+  if (lane < seen) { st->freq_run[rank] = mine; isfreq[mine] = (uint8_t)(rank + 1); }
+  if (lane == 0) st->nfreq = seen;
+}
+// mask / position records of every sketch (node): walks the elements of the frequent runs
+__global__ __launch_bounds__(256) void k_freq_fill(const uint32_t* __restrict__ starts, uint32_t n, const uint32_t* __restrict__ origin,
+                                                   const uint32_t* __restrict__ node, const uint64_t* __restrict__ node_first,
+                                                   const uint32_t* __restrict__ alias_node, uint64_t alias_lo, uint64_t alias_n,
+                                                   const PlanState* __restrict__ st, unsigned long long* __restrict__ mask,
+                                                   uint32_t* __restrict__ pos) {
+  const uint32_t b = blockIdx.y;
+  if (b >= st->nfreq) return;
+  const uint32_t r = st->freq_run[b], nruns = st->nruns;
+  const uint32_t lo = starts[r], hi = r + 1 < nruns ? starts[r + 1] : n;
+  for (uint32_t e = lo + blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += gridDim.x * blockDim.x) {
+    const uint32_t o = origin[e];                     // pooled element index
+    const uint32_t nd = node[o];
+    atomicOr(&mask[nd], 1ull << b);
+    pos[(size_t)nd * kMaxFreq + b] = (uint32_t)(o - node_first[nd]);
+    if (alias_node && o >= alias_lo && o - alias_lo < alias_n) {
+      // a row block that is a view of the columns: the element is also element o - alias_lo of the rows
+      const uint32_t rn = alias_node[o - alias_lo];
+      atomicOr(&mask[rn], 1ull << b);
+      pos[(size_t)rn * kMaxFreq + b] = (uint32_t)(o - alias_lo - node_first[rn]);
+    }
+  }
+}
+// pooled index of the first element of every node (sketch)
+__global__ __launch_bounds__(256) void k_node_first(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t pool_base, uint32_t node_base,
+                                                    uint64_t* __restrict__ node_first) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nsk) node_first[node_base + i] = pool_base + (off[i] - off[0]);
+}
+
+// every pair as if it shared nothing but frequent hashes (none, usually); the compare kernels then
+// overwrite the pairs they walk
 __global__ __launch_bounds__(256) void k_fill_disjoint(const uint64_t* __restrict__ roff, uint32_t nrows,
                                                        const uint64_t* __restrict__ coff, uint32_t ncols, uint32_t num,
-                                                       const uint32_t* __restrict__ row_nums, CompareOut out) {
+                                                       const uint32_t* __restrict__ row_nums, CompareOut out,
+                                                       const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ pos,
+                                                       uint32_t col_node_base) {
   const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= (uint64_t)nrows * ncols) return;
   const uint32_t i = (uint32_t)(pid / ncols), j = (uint32_t)(pid % ncols);
   const uint64_t la = roff[i + 1] - roff[i], lb = coff[j + 1] - coff[j];
   const uint64_t n = row_nums ? row_nums[i] : num;
-  const uint64_t tot = la + lb;
+  uint64_t cc = 0, common = 0;
+  if (mask) {
+    unsigned long long m = mask[i] & mask[col_node_base + j];
+    const uint32_t* pa = pos + (size_t)i * kMaxFreq;
+    const uint32_t* pb = pos + (size_t)(col_node_base + j) * kMaxFreq;
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const uint64_t u = (uint64_t)pa[b] + pb[b] - cc;   // union elements smaller than this shared hash
+      if (n == 0 || u < n) common++;
+      cc++;
+    }
+  }
+  const uint64_t tot = la + lb - cc;
   const uint64_t size = (n != 0 && tot > n) ? n : tot;
-  if (out.common) out.common[pid] = 0;
+  if (out.common) out.common[pid] = common;
   if (out.size) out.size[pid] = size;
-  if (out.jaccard) out.jaccard[pid] = 0.0 / (double)(size > 1 ? size : 1);
-  if (out.count_common) out.count_common[pid] = 0;
-  if (out.containment) out.containment[pid] = 0.0 / (double)la;
+  if (out.jaccard) out.jaccard[pid] = (double)common / (double)(size > 1 ? size : 1);
+  if (out.count_common) out.count_common[pid] = cc;
+  if (out.containment) out.containment[pid] = (double)cc / (double)la;
 }
 
 // ---- device-side plan ----------------------------------------------------------------------------
@@ -901,7 +984,7 @@ __global__ __launch_bounds__(256) void k_flag_tiles(uint32_t nrows, uint32_t nco
 
 struct TiledScratch {
   DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, work, plan,
-      pk0, pk1, pk2, pk3, rng, cnt;
+      pk0, pk1, pk2, pk3, rng, cnt, runid, isfreq, fmask, fpos, nfirst;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -944,7 +1027,7 @@ static const TiledExperiments& tiled_experiments() {
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
-                          &T.node, &T.parent, &T.root, &T.tiles, &T.work, &T.plan, &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt})
+                          &T.node, &T.parent, &T.root, &T.tiles, &T.work, &T.plan, &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt, &T.runid, &T.isfreq, &T.fmask, &T.fpos, &T.nfirst})
     b->release();
 }
 
@@ -978,7 +1061,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   PlanState* st = T.plan.as<PlanState>();
   HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PlanState), s));
 
-  // ---- dictionary-encode: sort (hash, origin); run ids -> rank[origin] come later, if the tiled kernel runs
+  // ---- dictionary-encode: sort (hash, origin), then run ids -> rank[origin]
   T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 4); T.org1.ensure(n * 4);   // origins: element indices < 2^31
   if (inside) {
     HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
@@ -993,8 +1076,25 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
 
-  // ---- components of the "shares a hash" graph (lock-free union-find over the runs of equal hashes)
+  // ---- runs of equal hashes: dense ranks (for the tiled kernel) and run lengths (document frequencies)
   const uint32_t M = same ? cols.n : rows.n + cols.n;
+  T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4); T.runid.ensure(n * 4);
+  run_length_encode_u64_async(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so, T.rank.as<uint32_t>(),
+                              &st->nruns, nullptr, T.runid.as<uint32_t>());
+  // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
+  const bool split = tune.split_frequent != 0 && M >= 32;
+  const uint8_t* isfreq = nullptr;
+  if (split) {
+    T.isfreq.ensure(n);
+    HIP_CHECK(hipMemsetAsync(T.isfreq.ptr, 0, n, s));
+    const uint32_t threshold = std::max<uint32_t>(16u, M / 4);
+    hipLaunchKernelGGL(k_freq_mark, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, T.starts.as<uint32_t>(),
+                       (uint32_t)n, threshold, st);
+    hipLaunchKernelGGL(k_freq_finalize, dim3(1), dim3(64), 0, s, st, T.isfreq.as<uint8_t>());
+    isfreq = T.isfreq.as<uint8_t>();
+  }
+
+  // ---- components of the "shares a hash" graph (lock-free union-find over the runs of equal hashes)
   T.node.ensure((size_t)(n + (inside ? nr_elems : 0)) * 4);
   T.parent.ensure((size_t)M * 4); T.root.ensure((size_t)M * 4);
   uint32_t* d_node = T.node.as<uint32_t>();
@@ -1007,11 +1107,11 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   hipLaunchKernelGGL(k_uf_init, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M);
   // 1/256 sample straight to the atomic path, then 1/16 and everything through the cached filter
   hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((n / 256 + 256) / 256)), dim3(256), 0, s, sk, so, d_node, n,
-                     T.parent.as<uint32_t>());
+                     T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
   hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, s, sk, so, d_node, n,
-                     T.parent.as<uint32_t>());
+                     T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
   hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sk, so, d_node, n,
-                     T.parent.as<uint32_t>());
+                     T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
   if (inside && nr_elems)
     hipLaunchKernelGGL(k_uf_alias, dim3((unsigned)((nr_elems + 255) / 256)), dim3(256), 0, s, d_node + n, d_node, nr_elems,
                        (uint64_t)(rows.hashes - cols.hashes), T.parent.as<uint32_t>());
@@ -1045,13 +1145,36 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   hipLaunchKernelGGL(k_plan_route, dim3(1), dim3(1), 0, s, st, tune.route, tune.visit_all_tiles, (unsigned long long)tune.comp_pairs_limit);
   HIP_CHECK(hipGetLastError());
 
-  // ---- every pair as if it shared nothing; the compare kernels overwrite the pairs they walk
+  // ---- the per-sketch records of the frequent hashes (which of them it holds, and where)
+  const unsigned long long* fmask = nullptr;
+  if (split) {
+    T.nfirst.ensure((size_t)M * 8); T.fmask.ensure((size_t)M * 8); T.fpos.ensure((size_t)M * kMaxFreq * 4);
+    HIP_CHECK(hipMemsetAsync(T.fmask.ptr, 0, (size_t)M * 8, s));
+    uint64_t* nf = T.nfirst.as<uint64_t>();
+    if (same) {
+      hipLaunchKernelGGL(k_node_first, dim3((cols.n + 255) / 256), dim3(256), 0, s, cols.offsets, cols.n, (uint64_t)0, 0u, nf);
+    } else {
+      // rows are nodes 0 .. rows.n-1 (their elements start the pool, or -- a view of the columns -- are counted from the
+      // view's first element); columns are nodes rows.n ..
+      hipLaunchKernelGGL(k_node_first, dim3((rows.n + 255) / 256), dim3(256), 0, s, rows.offsets, rows.n, (uint64_t)0, 0u, nf);
+      hipLaunchKernelGGL(k_node_first, dim3((cols.n + 255) / 256), dim3(256), 0, s, cols.offsets, cols.n,
+                         (uint64_t)(inside ? 0 : nr_elems), rows.n, nf);
+    }
+    hipLaunchKernelGGL(k_freq_fill, dim3((unsigned)std::min<uint32_t>((M + 255) / 256, 64u), kMaxFreq), dim3(256), 0, s,
+                       T.starts.as<uint32_t>(), (uint32_t)n, so, d_node, nf, inside ? d_node + n : (const uint32_t*)nullptr,
+                       inside ? (uint64_t)(rows.hashes - cols.hashes) : 0ull, inside ? nr_elems : 0ull, st,
+                       T.fmask.as<unsigned long long>(), T.fpos.as<uint32_t>());
+    HIP_CHECK(hipGetLastError());
+    fmask = T.fmask.as<unsigned long long>();
+  }
+
+  // ---- every pair as if it shared nothing but frequent hashes; the compare kernels overwrite the pairs they walk
   // (with every tile launched nothing would be left: skipped)
   const uint64_t np = (uint64_t)rows.n * cols.n;
   if (!(tune.visit_all_tiles && tune.route == kRouteTiled)) {
     dev.prof_begin(s);
     hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
-                       cols.n, num, row_nums, out);
+                       cols.n, num, row_nums, out, fmask, T.fpos.as<uint32_t>(), same ? 0u : rows.n);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("compare_fill", s);
   }
@@ -1091,10 +1214,6 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   const int wpb = ex.wpb, minw = ex.minw;
   uint32_t tiles_cap = 0;
   if (tune.route != kRouteComponents) {
-    const uint32_t* skip = &st->skip_tiled;
-    T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4);
-    run_length_encode_u64_async(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so, T.rank.as<uint32_t>(),
-                                &st->nruns, skip);
     // ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords;
     // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
     // sketches walk several ranges per step
@@ -1197,6 +1316,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     g_stats.pairs_per_tile = (uint64_t)tr * kTB;
     g_stats.lds_overflow_steps = h.ovf_steps;
   }
+  g_stats.frequent_hashes = h.nfreq;
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,

@@ -754,12 +754,13 @@ void smh_compare_last_stats(SmhCompareStats* out) {
   out->route = st.route; out->rows_per_tile = st.rows_per_tile;
   out->tiles_visited = st.tiles_visited; out->tiles_total = st.tiles_total; out->pairs_per_tile = st.pairs_per_tile;
   out->lds_overflow_steps = st.lds_overflow_steps;
+  out->frequent_hashes = st.frequent_hashes;
 }
 void smh_compare_get_tuning(SmhCompareTuning* out) {
   if (!out) return;
   const smh::CompareTuning t = smh::compare_get_tuning();
   out->route = t.route; out->visit_all_tiles = t.visit_all_tiles; out->use_symmetry = t.use_symmetry;
-  out->comp_pairs_limit = t.comp_pairs_limit;
+  out->comp_pairs_limit = t.comp_pairs_limit; out->split_frequent = t.split_frequent;
 }
 int smh_compare_set_tuning(const SmhCompareTuning* in) {
   return pad_code([&] {
@@ -767,7 +768,7 @@ int smh_compare_set_tuning(const SmhCompareTuning* in) {
     if (in) {
       if (in->route > smh::kRouteTiled) smh::throw_internal("smh_compare_set_tuning: unknown route");
       t.route = in->route; t.visit_all_tiles = in->visit_all_tiles; t.use_symmetry = in->use_symmetry;
-      t.comp_pairs_limit = in->comp_pairs_limit;
+      t.comp_pairs_limit = in->comp_pairs_limit; t.split_frequent = in->split_frequent;
     }
     smh::compare_set_tuning(t);
   });

@@ -100,7 +100,7 @@ int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scra
 // skip (device, nullable): non-zero = the launches do nothing
 void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
                                  hipStream_t s, const uint32_t* origin, uint32_t* rank_out, uint32_t* nruns_dev,
-                                 const uint32_t* skip);
+                                 const uint32_t* skip, uint32_t* runid_out = nullptr);   // runid_out[i] = run of sorted position i
 // in-place exclusive scan of m u32 counters; *total (device, nullable) receives their sum
 void exclusive_scan_u32_dev(uint32_t* d, size_t m, uint32_t* total, DeviceBuffer& scratch, hipStream_t s);
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).
@@ -150,6 +150,7 @@ struct CompareTuning {
                                            // are told apart by comp_pairs_limit
   uint32_t visit_all_tiles = 0;            // 1: launch every tile, not only those that can hold sharing pairs
   uint32_t use_symmetry = 1;               // all-vs-all with one num: compute the upper triangle, mirror the rest
+  uint32_t split_frequent = 1;             // hashes held by a large share of the sketches do not make components
   uint64_t comp_pairs_limit = 1ull << 18;  // at most this many sharing pairs: per-component pair kernel, else tiled
 };
 struct CompareStats {                      // of the last block compare
@@ -157,6 +158,7 @@ struct CompareStats {                      // of the last block compare
   uint32_t rows_per_tile = 0;
   uint64_t tiles_visited = 0, tiles_total = 0, pairs_per_tile = 0;   // components route: pairs walked / pairs / 1
   uint64_t lds_overflow_steps = 0;         // tiled: (tile, range) steps merged from global memory instead of LDS
+  uint32_t frequent_hashes = 0;            // hashes set aside as frequent (decided from per-sketch positions, not walked)
 };
 void compare_set_tuning(const CompareTuning& t);
 CompareTuning compare_get_tuning();

@@ -334,7 +334,8 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
                                                            uint32_t* __restrict__ starts,
                                                            const uint32_t* __restrict__ origin,
                                                            uint32_t* __restrict__ rank_out,
-                                                           const uint32_t* __restrict__ skip) {
+                                                           const uint32_t* __restrict__ skip,
+                                                           uint32_t* __restrict__ runid_out) {
   __shared__ uint32_t wsum[kRleThreads / 64];
   if (skip && *skip) return;
   size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
       o++;
     }
     if (rank_out && base + i < n) rank_out[origin[base + i]] = o - 1;
+    if (runid_out && base + i < n) runid_out[base + i] = o - 1;     // the same by sorted position
   }
 }
 
@@ -511,7 +513,7 @@ int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scra
 // skip (device, nullable): non-zero = do nothing (the caller's device-side plan does not need the result)
 void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
                                  hipStream_t s, const uint32_t* origin, uint32_t* rank_out, uint32_t* nruns_dev,
-                                 const uint32_t* skip) {
+                                 const uint32_t* skip, uint32_t* runid_out) {
   if (n == 0) { HIP_CHECK(hipMemsetAsync(nruns_dev, 0, 4, s)); return; }
   if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
   const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
@@ -520,7 +522,7 @@ void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq,
   hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, n, bc, skip);
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, (uint64_t*)nullptr, n, bc,
-                     uniq, starts, origin, rank_out, skip);
+                     uniq, starts, origin, rank_out, skip, runid_out);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(nruns_dev, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 }
@@ -536,7 +538,7 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, n, bc, (const uint32_t*)nullptr);
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, uniq2, n, bc, uniq,
-                     starts, origin, rank_out, (const uint32_t*)nullptr);
+                     starts, origin, rank_out, (const uint32_t*)nullptr, (uint32_t*)nullptr);
   HIP_CHECK(hipGetLastError());
   uint32_t nruns = 0;
   HIP_CHECK(hipMemcpyAsync(&nruns, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -14,10 +14,10 @@ ROUTES = {"auto": 0, "wave": 1, "few": 2, "components": 3, "tiled": 4}
 
 
 @contextlib.contextmanager
-def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=1 << 18):
+def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=1 << 18, split_frequent=True):
     """Pins which kernel serves the block compares inside the `with` (additive ABI
     smh_compare_set_tuning; results never depend on it), then restores the defaults."""
-    t = SmhCompareTuning(ROUTES[route], int(visit_all_tiles), int(use_symmetry), comp_pairs_limit)
+    t = SmhCompareTuning(ROUTES[route], int(visit_all_tiles), int(use_symmetry), comp_pairs_limit, int(split_frequent))
     call(lib().smh_compare_set_tuning, C.byref(t))
     try:
         yield
@@ -30,7 +30,8 @@ def last_stats():
     lib().smh_compare_last_stats(C.byref(st))
     names = {v: k for k, v in ROUTES.items()}
     return {"route": names.get(st.route, "none"), "rows_per_tile": st.rows_per_tile, "tiles_visited": st.tiles_visited,
-            "tiles_total": st.tiles_total, "pairs_per_tile": st.pairs_per_tile, "lds_overflow_steps": st.lds_overflow_steps}
+            "tiles_total": st.tiles_total, "pairs_per_tile": st.pairs_per_tile, "lds_overflow_steps": st.lds_overflow_steps,
+            "frequent_hashes": st.frequent_hashes}
 
 
 def compare_block(rows, cols, want=("jaccard",)):

@@ -21,6 +21,8 @@ ROUTES = [
     pytest.param(dict(route="tiled"), "tiled", id="tiled"),
     pytest.param(dict(route="tiled", visit_all_tiles=True), "tiled", id="tiled-all-tiles"),
     pytest.param(dict(route="tiled", visit_all_tiles=True, use_symmetry=False), "tiled", id="tiled-all-tiles-nosym"),
+    pytest.param(dict(split_frequent=False), None, id="auto-no-frequent-split"),
+    pytest.param(dict(route="tiled", split_frequent=False), "tiled", id="tiled-no-frequent-split"),
 ]
 
 
@@ -232,8 +234,10 @@ def _full_size_matrix_check(pkg, coracle, n, seed, sample_rows, tunes):
         for tune, expect in tunes:
             out = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard", "common", "size")))
             st = pkg.matrix.last_stats()
-            if contaminated and st["route"] == "tiled":
+            if contaminated and st["route"] == "tiled" and not tune.get("split_frequent", True):
                 assert st["tiles_visited"] * 2 >= st["tiles_total"], st        # one component: (the upper half of) every tile
+            if contaminated and tune.get("split_frequent", True):
+                assert st["frequent_hashes"] == 1, st                          # the shared hash is set aside
             j = out["jaccard"]
             assert bool((j == j.T).all()) and bool((j.diagonal() == 1.0).all())
             assert bool((out["size"] == 2000).all())
@@ -252,7 +256,8 @@ def test_matrix_at_benchmark_size_vs_oracle(pkg, coracle):
     columns against the C oracle."""
     rows = sorted(set([0, 1, 49, 50, 51, 999] + list(range(7, 1000, 29))))
     tunes = [(dict(), None), (dict(route="components"), "components"), (dict(route="tiled"), "tiled"),
-             (dict(route="tiled", visit_all_tiles=True), "tiled"), (dict(route="tiled", use_symmetry=False), "tiled")]
+             (dict(route="tiled", visit_all_tiles=True), "tiled"), (dict(route="tiled", use_symmetry=False), "tiled"),
+             (dict(route="tiled", split_frequent=False), "tiled")]
     _full_size_matrix_check(pkg, coracle, 1000, 3, rows, tunes)
 
 
@@ -261,7 +266,7 @@ def test_matrix_at_c4_size_vs_oracle(pkg, coracle):
     tiled kernel: > 2^18 sharing pairs) on the family collection and on the one-component
     collection, 32 sampled rows x all 10 000 columns against the C oracle."""
     rows = sorted(set([0, 1, 49, 50, 4999, 5000, 9999] + list(range(13, 10000, 400))))
-    _full_size_matrix_check(pkg, coracle, 10000, 4, rows, [(dict(), "tiled")])
+    _full_size_matrix_check(pkg, coracle, 10000, 4, rows, [(dict(), "tiled"), (dict(split_frequent=False), "tiled")])
 
 
 @pytest.mark.parametrize("n,n_fam,sym", [(700, 7, True), (1500, 50, True), (900, 13, False)])
@@ -311,6 +316,63 @@ def test_device_plan_matches_an_independent_tile_count(n, n_fam, sym, pkg):
     j = out["jaccard"].cpu().numpy()
     same = fam_r[:, None] == fam_c[None, :]
     assert (j[~same] == 0).all() and (j[same] > 0).all()
+
+
+@pytest.mark.parametrize("n_contaminants,where", [(1, "low"), (3, "spread"), (64, "spread"), (70, "spread")])
+@pytest.mark.parametrize("tune", [dict(), dict(route="components"), dict(route="tiled"), dict(split_frequent=False)],
+                         ids=["auto", "components", "tiled", "no-split"])
+def test_frequent_hashes_are_set_aside_exactly(n_contaminants, where, tune, pkg, coracle):
+    """Hashes held by (nearly) every sketch -- a contaminant k-mer -- would glue unrelated sketches into one
+    component.  The block compare sets up to 64 such hashes aside and decides pairs that share nothing else
+    from per-sketch records (which frequent hashes, at which position); more than 64 and nothing is set
+    aside.  Either way every output equals the oracle's: ragged sketches, per-row nums (bottom-num cuts
+    that fall before, between and after the contaminants), num = 0, rows != columns, empty sketches."""
+    rng = np.random.RandomState(100 + n_contaminants)
+    n_fam = 6
+    pools = [np.unique(rng.randint(1 << 20, 1 << 62, size=700, dtype=np.int64).astype(np.uint64)) for _ in range(n_fam)]
+    if where == "low":
+        cont = np.arange(1, n_contaminants + 1, dtype=np.uint64) * np.uint64(7)
+    else:
+        cont = np.unique(rng.randint(1, 1 << 62, size=n_contaminants, dtype=np.int64).astype(np.uint64))
+        cont[0] = 3                                         # one below everything, the rest anywhere
+
+    def make(count, shift, frac):
+        out = []
+        for i in range(count):
+            if (i + shift) % 17 == 16:
+                out.append(np.zeros(0, dtype=np.uint64))    # empty
+                continue
+            fam = (i * 5 + shift) % n_fam
+            own = rng.choice(pools[fam], rng.choice([40, 300, 500]), replace=False)
+            keep = cont[rng.random_sample(len(cont)) < frac]
+            out.append(np.unique(np.concatenate([own, keep])))
+        return out
+
+    rows = make(70, 0, 0.95)
+    cols = make(150, 3, 0.9)
+    nums = [0, 5, 60, 300, 5000]
+    gr, orr = zip(*[_pair(pkg, coracle, nums[i % 5], r) for i, r in enumerate(rows)])
+    gc, oc = zip(*[_pair(pkg, coracle, 77, c) for c in cols])
+    want = ("jaccard", "common", "size", "count_common", "containment")
+    with pkg.matrix.tuning(**tune):
+        out = pkg.matrix.compare_block(list(gr), list(gc), want=want)
+        st = pkg.matrix.last_stats()
+    if tune.get("split_frequent", True):
+        # set aside when at most 64 of them pass the threshold (a quarter of the 220 sketches), none otherwise
+        assert st["frequent_hashes"] == (len(cont) if len(cont) <= 64 else 0), st
+        if len(cont) <= 64 and st["route"] == "tiled":
+            assert st["tiles_visited"] < st["tiles_total"]          # unrelated families are not walked
+    else:
+        assert st["frequent_hashes"] == 0
+    for i in range(len(rows)):
+        for j in range(len(cols)):
+            assert (int(out["common"][i, j]), int(out["size"][i, j])) == orr[i].intersection_size(oc[j]), (i, j)
+            assert out["jaccard"][i, j] == orr[i].compare(oc[j])
+            assert int(out["count_common"][i, j]) == orr[i].count_common(oc[j])
+            if len(rows[i]):
+                assert out["containment"][i, j] == orr[i].containment(oc[j])
+            else:
+                assert np.isnan(out["containment"][i, j])
 
 
 def test_tiled_global_merge_branch(pkg, coracle):
