@@ -98,13 +98,10 @@ def cpu_worker(argv):
         print(json.dumps({"sketch_seconds": t1 - t0, "kmers": REC_LEN - K + 1, "compare_seconds": (t2 - t1) / reps,
                           "self_compare": j}))
     elif kind == "compare":
-        n_sig, first, last, budget, contaminated = int(argv[2]), int(argv[3]), int(argv[4]), float(argv[5]), int(argv[6])
+        n_sig, first, last, budget, kind_id = int(argv[2]), int(argv[3]), int(argv[4]), float(argv[5]), int(argv[6])
         from __graft_entry__ import load_package
         load_package()
-        from sourmash_rust_amd import synth
-        sigs = synth.family_signatures(0, n_sig, num=NUM, seed=3)
-        if contaminated:
-            sigs[:, 0] = CONTAMINANT
+        sigs = collection(kind_id, 0, n_sig)
         cols = [sigs[i] for i in range(n_sig)]
         rows_done, spent, jac = 0, 0.0, []
         for r in range(first, last):
@@ -119,6 +116,18 @@ def cpu_worker(argv):
         print(json.dumps({"rows": rows_done, "seconds": spent}))
     else:
         raise SystemExit("unknown worker kind " + kind)
+
+
+def collection(kind_id, lo, hi):
+    """Signatures lo..hi-1 of the compare collections: 0 = 50 families; 1 = the same with one hash
+    shared by every signature; 2 = ONE family (every pair shares hundreds of hashes)."""
+    from sourmash_rust_amd import synth
+    if kind_id == 2:
+        return synth.family_signatures(lo, hi, num=NUM, n_families=1, seed=3)
+    sigs = synth.family_signatures(lo, hi, num=NUM, seed=3)
+    if kind_id == 1:
+        sigs[:, 0] = CONTAMINANT       # (uniform 64-bit hashes: the smallest possible value keeps rows ascending)
+    return sigs
 
 
 def run_workers(specs):
@@ -282,14 +291,12 @@ def main():
 
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
-    sigs_host = None
     if not args.no_compare:
-        from sourmash_rust_amd import distributed as D, matrix as MX, synth
+        from sourmash_rust_amd import distributed as D, matrix as MX
         n_sig = args.compare_n or {1: 1000, 2: 2500, 4: 5000, 8: 10000}.get(world, 1000 * world)
         lo, hi, per = D.shard_range(n_sig, world, rank)
         local_sigs = np.zeros((per, NUM), dtype=np.uint64)
-        local_sigs[: hi - lo] = synth.family_signatures(lo, hi, num=NUM, seed=3)
-        sigs_host = local_sigs
+        local_sigs[: hi - lo] = collection(0, lo, hi)
 
         def time_collection(sig_block):
             mine = torch.from_numpy(sig_block.view(np.int64)).cuda()
@@ -323,17 +330,24 @@ def main():
                          "rank0_pairs_walked_per_s": walked / cdt,
                          "rank0_union_elements_walked_per_s": walked * NUM / cdt}
 
+        def local_block(kind_id):
+            blk = np.zeros((per, NUM), dtype=np.uint64)
+            blk[: hi - lo] = collection(kind_id, lo, hi)
+            return blk
+
         out_fam, fam = time_collection(local_sigs)
-        one = local_sigs.copy()
-        one[:, 0] = CONTAMINANT        # (uniform 64-bit hashes: the smallest possible value keeps rows ascending)
-        out_one, onec = time_collection(one)
+        out_one, onec = time_collection(local_block(1))
+        out_den, dense = time_collection(local_block(2))
         compare = {"metric": "signature pairs compared/sec (ordered pairs, num=%d)" % NUM, "value": fam["pairs_per_s"],
                    "unit": "pairs/s", "n_signatures": n_sig, "seconds": fam["seconds"], "self_jaccard_is_1": fam["self_jaccard_is_1"],
                    "collection": "50 families of related signatures (SURVEY.md 8d): pairs across families share no hash and are "
                                  "filled without being walked (DESIGN.md 3.4) -- a property of the collection, not of the kernel",
                    "families": fam,
-                   "one_component": dict(onec, collection="the same signatures with one hash (a contaminant k-mer) shared by all: "
-                                                          "one connected component, every pair has to be walked"),
+                   "one_component": dict(onec, collection="the same signatures with one hash (a contaminant k-mer) shared by all: one "
+                                                          "connected component; the frequent hash is set aside and pairs that share "
+                                                          "nothing else are decided from per-sketch records (DESIGN.md 3.4)"),
+                   "one_family": dict(dense, collection="ONE family: every pair shares hundreds of hashes, every pair has to be walked -- "
+                                                        "the kernel's own rate"),
                    "note": "'union elements walked' = pairs walked x num: with two full num-sketches the truncated union walk ends "
                            "after exactly num elements (reference src/lib.rs:470-499); per walked pair the effective traffic of "
                            "SURVEY.md 8d is 32 008 B served from LDS/L2, compulsory HBM traffic is N*16 KB in + N^2*8 B out"}
@@ -377,13 +391,13 @@ def main():
                            "self_compare": r0["self_compare"], "cores": 1, "gpu_sketch_equal": True}}
         if compare is not None:
             n_sig = compare["n_signatures"]
-            for key, contaminated, gpu_out in (("families", 0, out_fam), ("one_component", 1, out_one)):
+            for key, contaminated, gpu_out in (("families", 0, out_fam), ("one_component", 1, out_one), ("one_family", 2, out_den)):
                 gj = gpu_out["jaccard"].cpu().numpy()
-                (rc1, pc1), = run_workers([["compare", n_sig, 0, n_sig, 3.0 * scale, contaminated]])
+                (rc1, pc1), = run_workers([["compare", n_sig, 0, n_sig, 2.0 * scale, contaminated]])
                 j1 = np.load(pc1)
                 assert (gj[: j1.shape[0]] == j1).all(), "GPU matrix differs from the CPU oracle (%s, 1-core rows)" % key
                 per_w = max(1, n_sig // cores)
-                cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, 3.0 * scale, contaminated] for w in range(cores)
+                cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, 2.0 * scale, contaminated] for w in range(cores)
                                   if (w + 1) * per_w <= n_sig])
                 for w, (r, p) in enumerate(cw):
                     jw = np.load(p)
