@@ -878,25 +878,29 @@ __device__ __noinline__ void hash_spliced_windows(SplicedArgs A, uint32_t win, u
 // murmur64 of a W-byte string held in dwords D[0..3] (bytes past W are zero), 1 <= W <= 16: no
 // full block, k1 = bytes 0..7, k2 = bytes 8..W-1 (reference src/lib.rs:33-35 on aa.windows())
 template <int W>
-__device__ __forceinline__ uint64_t murmur_short(const uint32_t (&D)[4], uint64_t seed, const uint64_t* k2tab) {
-  W2 h1{(uint32_t)seed, (uint32_t)(seed >> 32)}, h2 = h1;
-  if (W == 9) {
-    // k2 is one byte: its whole mix comes from a 256-entry table (2 of the hash's 8 multiplies)
-    const uint64_t m = k2tab[D[2] & 0xffu];
-    h2 = w2_xor(h2, W2{(uint32_t)m, (uint32_t)(m >> 32)});
-  } else if (W > 8) {
-    h2 = w2_xor(h2, w2_mul(w2_rotl(w2_mul(W2{D[2], D[3]}, kC2), 33), kC1));
+__device__ __forceinline__ uint64_t murmur_short(const uint32_t (&D)[4], uint64_t seed, uint64_t h2_ready) {
+  // W == 9: k2 is one byte, so its whole contribution -- seed ^ mix_k2(byte) ^ W -- comes from a table (2 of the
+  // hash's 8 multiplies and the xors with it)
+  W2 h1{(uint32_t)seed ^ (uint32_t)W, (uint32_t)(seed >> 32)}, h2{(uint32_t)h2_ready, (uint32_t)(h2_ready >> 32)};
+  if (W != 9) {
+    h2 = W2{(uint32_t)seed ^ (uint32_t)W, (uint32_t)(seed >> 32)};
+    if (W > 8) h2 = w2_xor(h2, w2_mul(w2_rotl(w2_mul(W2{D[2], D[3]}, kC2), 33), kC1));
   }
   h1 = w2_xor(h1, w2_mul(w2_rotl(w2_mul(W2{D[0], D[1]}, kC1), 31), kC2));
-  h1.lo ^= (uint32_t)W; h2.lo ^= (uint32_t)W;
   h1 = w2_add(h1, h2); h2 = w2_add(h2, h1);
   h1 = w2_fmix(h1); h2 = w2_fmix(h2);
   const W2 r = w2_add(h1, h2);
   return ((uint64_t)r.hi << 32) | r.lo;
 }
 
+#ifndef SMH_PF_MINW
+#define SMH_PF_MINW 4
+#endif
+#ifndef SMH_PF_LOGR
+#define SMH_PF_LOGR 7
+#endif
 template <int W, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS / 128) void k_protein_fused(SeqBatch b, HashParams hp, CandSink sink, int logR,
+__global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch b, HashParams hp, CandSink sink, int logR,
                                                                           uint32_t stage_cap, uint32_t* __restrict__ high_flag) {
   constexpr int KB = 3 * W;                          // bases per window
   constexpr int ND = (W + 3) / 4;                    // dwords of a residue string
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_protein_fused(SeqBat
     const int d0 = (tid >> 4) & 3, d1 = (tid >> 2) & 3, d2 = tid & 3;
     ctab[tid] = aa_of_digits(d0, d1, d2) | (aa_of_digits(3 - d2, 3 - d1, 3 - d0) << 8);
   }
-  if (W == 9) for (int e = tid; e < 256; e += THREADS) k2tab[e] = mix_k2((uint64_t)e);
+  if (W == 9) for (int e = tid; e < 256; e += THREADS) k2tab[e] = hp.seed ^ mix_k2((uint64_t)e) ^ (uint64_t)W;
   if (tid == 0) st_ctl[0] = 0;
 
   const uint64_t ntiles = (b.len + TILE - 1) / TILE;
@@ -1021,11 +1025,17 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_protein_fused(SeqBat
         }
         set_clean_window(!kHash);
       }
+      // the four codon look-ups of the group are issued together, ahead of the hashing they feed
+      uint32_t ent[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        w4 = ((w4 << 2) | (((code4 >> (8 * q)) & 3u) << 2)) & 0xfcu;
+        ent[q] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctab) + w4);
+      }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int t = (4 * PH + q) % 3;                    // reading frame completed by this base (lane-relative)
-        w4 = ((w4 << 2) | (((code4 >> (8 * q)) & 3u) << 2)) & 0xfcu;
-        const uint32_t e = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctab) + w4);
+        const uint32_t e = ent[q];
         const uint32_t af = e & 0xffu, ar = (e >> 8) & 0xffu;
         // forward string: drop the oldest residue (byte 0), the new one becomes byte W-1
 #pragma unroll
@@ -1036,12 +1046,12 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void k_protein_fused(SeqBat
         for (int dd = ND - 1; dd > 0; dd--) Sr[t][dd] = __builtin_amdgcn_alignbyte(Sr[t][dd], Sr[t][dd - 1], 3);
         Sr[t][0] = (Sr[t][0] << 8) | ar;
         if ((W & 3) != 0) Sr[t][ND - 1] &= (1u << (8 * (W & 3))) - 1u;
-        if (kHash && i0 + q + 1 >= (uint32_t)KB) {          // uniform: a window can be complete here
+        if (kHash && i0 + q + 1 >= (uint32_t)KB && i0 + q < R + (uint32_t)KB - 1) {   // uniform: a window of some lane's run can be complete here
           uint32_t Df[4] = {0, 0, 0, 0}, Dr[4] = {0, 0, 0, 0};
 #pragma unroll
           for (int dd = 0; dd < ND; dd++) { Df[dd] = Sf[t][dd]; Dr[dd] = Sr[t][dd]; }
-          const uint64_t hf = murmur_short<W>(Df, hp.seed, k2tab);
-          const uint64_t hr = murmur_short<W>(Dr, hp.seed, k2tab);
+          const uint64_t hf = murmur_short<W>(Df, hp.seed, W == 9 ? k2tab[Df[2] & 0xffu] : 0ull);
+          const uint64_t hr = murmur_short<W>(Dr, hp.seed, W == 9 ? k2tab[Dr[2] & 0xffu] : 0ull);
           if (hf <= hp.thr || hr <= hp.thr) {                // ~2 in `scaled` positions get here
             uint32_t om = okmask;
             asm volatile("" : "+v"(om));
@@ -1372,7 +1382,7 @@ bool launch_protein_fused(const SeqBatch& b, const uint64_t* seg_offsets, uint32
                           const CandSink& sink, uint32_t* high_flag, Device& dev, hipStream_t s) {
   if (b.len == 0) return true;
   if (!(win == 7 || win == 9 || win == 10)) return false;     // the usual protein k-mer sizes (ksize 21 / 27 / 30)
-  int logR = 7;
+  int logR = SMH_PF_LOGR;
   while (logR > 5 && (b.len >> logR) < (uint64_t)dev.cu_count() * 512 * 2) logR--;
   const uint64_t tile = 512ull << logR;
   const uint64_t ntiles = (b.len + tile - 1) / tile;

@@ -4,7 +4,7 @@ Checks linearity at full size: sketch(all records) == merge(sketch(first half), 
 (scaled mode: hash sets unite, abundances add).  python tools/bench_c5.py [n_records]"""
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from __graft_entry__ import load_package
 pkg = load_package()
