@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 #include <cstdlib>
 
@@ -994,11 +995,14 @@ TiledScratch& tiled_scratch() {
 }  // namespace
 
 // tuning (which kernel serves a block; never a result) and the record of the last block
+// (process-wide; block compares run under the device mutex, these accessors take a lock of their own)
+static std::mutex g_tune_mu;
 static CompareTuning g_tuning;
 static CompareStats g_stats;
-void compare_set_tuning(const CompareTuning& t) { g_tuning = t; }
-CompareTuning compare_get_tuning() { return g_tuning; }
-CompareStats compare_last_stats() { return g_stats; }
+void compare_set_tuning(const CompareTuning& t) { std::lock_guard<std::mutex> l(g_tune_mu); g_tuning = t; }
+CompareTuning compare_get_tuning() { std::lock_guard<std::mutex> l(g_tune_mu); return g_tuning; }
+CompareStats compare_last_stats() { std::lock_guard<std::mutex> l(g_tune_mu); return g_stats; }
+static void set_stats(const CompareStats& st) { std::lock_guard<std::mutex> l(g_tune_mu); g_stats = st; }
 
 // Geometry experiments (tools/): compiled in only with -DSMH_EXPERIMENTS, read once.
 struct TiledExperiments {
@@ -1046,7 +1050,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
                          uint32_t max_len, uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
                          hipStream_t s, bool same_sets) {
   TiledScratch& T = tiled_scratch();
-  const CompareTuning tune = g_tuning;
+  const CompareTuning tune = compare_get_tuning();
   const TiledExperiments& ex = tiled_experiments();
   // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
   const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
@@ -1302,21 +1306,22 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   PlanState h;
   HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(PlanState), hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
-  g_stats = CompareStats{};
-  g_stats.route = h.route;
+  CompareStats rec;
+  rec.route = h.route;
   if (h.route == kRouteComponents) {
     if (h.nwork > work_cap) throw_internal("compare block: the per-component route was forced on a block with too many sharing pairs");
-    g_stats.tiles_visited = h.pairs; g_stats.tiles_total = np; g_stats.pairs_per_tile = 1;
+    rec.tiles_visited = h.pairs; rec.tiles_total = np; rec.pairs_per_tile = 1;
   } else {
     if (h.ntiles > tiles_cap) throw_internal("compare block: tile list overflow");
     const uint32_t tr = h.rpw * (uint32_t)wpb;
-    g_stats.rows_per_tile = tr;
-    g_stats.tiles_visited = h.ntiles;
-    g_stats.tiles_total = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
-    g_stats.pairs_per_tile = (uint64_t)tr * kTB;
-    g_stats.lds_overflow_steps = h.ovf_steps;
+    rec.rows_per_tile = tr;
+    rec.tiles_visited = h.ntiles;
+    rec.tiles_total = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
+    rec.pairs_per_tile = (uint64_t)tr * kTB;
+    rec.lds_overflow_steps = h.ovf_steps;
   }
-  g_stats.frequent_hashes = h.nfreq;
+  rec.frequent_hashes = h.nfreq;
+  set_stats(rec);
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
@@ -1345,7 +1350,7 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
                           uint64_t nc_elems, bool same_sets) {
   const uint64_t npairs = (uint64_t)rows.n * cols.n;
   if (npairs == 0) return;
-  const uint32_t route = g_tuning.route;
+  const uint32_t route = compare_get_tuning().route;
   // big blocks: dictionary-encode once, then the tiled kernel; small ones: one wavefront per pair
   const bool block_ok = nr_elems + nc_elems > 0;
   if (block_ok && (route == kRouteAuto ? (npairs >= 4096 && rows.n >= 8 && cols.n >= 16)
@@ -1375,8 +1380,9 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
 #undef SMH_CF
       HIP_CHECK(hipGetLastError());
       dev.prof_end("compare_few", s);
-      g_stats = CompareStats{};
-      g_stats.route = kRouteFew;
+      CompareStats rec;
+      rec.route = kRouteFew;
+      set_stats(rec);
       return;
     }
   }
@@ -1392,8 +1398,9 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
   }
   HIP_CHECK(hipGetLastError());
   dev.prof_end("compare_wave", s);
-  g_stats = CompareStats{};
-  g_stats.route = kRouteWave;
+  CompareStats rec;
+  rec.route = kRouteWave;
+  set_stats(rec);
 }
 
 }  // namespace smh
