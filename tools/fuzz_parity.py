@@ -226,6 +226,12 @@ while time.time() < t_end:
                 out.append(np.sort(np.random.RandomState(rng.getrandbits(31)).choice(uni, sz, replace=False)))
             return out
         rows, cols = mk(nrow), mk(ncol)
+        if rng.random() < 0.4 and nrow + ncol >= 32:      # frequent hashes: held by most sketches (set aside by the block compare)
+            freq = np.unique(np.array([rng.getrandbits(63) for _ in range(rng.choice([1, 2, 5, 64, 80]))], dtype=np.uint64))
+            def add(lst):
+                return [np.unique(np.concatenate([x, freq[np.random.RandomState(rng.getrandbits(31)).random_sample(len(freq)) < 0.8]]))
+                        if len(x) else x for x in lst]
+            rows, cols = add(rows), add(cols)
         nums = [rng.choice([0, 1, 10, 300, 5000]) for _ in rows]
         same_num = rng.random() < 0.5
         if same_num:
@@ -247,7 +253,8 @@ while time.time() < t_end:
         want_cc = rng.random() < 0.6   # without count_common the kernels take their early-exit instantiation
         # any way the block can be served must give the same numbers (smh_compare_set_tuning)
         tune = rng.choice([dict(), dict(), dict(route="components"), dict(route="tiled"), dict(route="tiled", visit_all_tiles=True),
-                           dict(route="tiled", visit_all_tiles=True, use_symmetry=False), dict(comp_pairs_limit=0)])
+                           dict(route="tiled", visit_all_tiles=True, use_symmetry=False), dict(comp_pairs_limit=0),
+                           dict(split_frequent=False), dict(route="tiled", split_frequent=False)])
         with pkg.matrix.tuning(**tune):
             out = pkg.matrix.compare_block(gm, gc, want=("jaccard", "common", "size") + (("count_common",) if want_cc else ()))
         for i in range(nrow):
