@@ -12,7 +12,11 @@
 //                     diagonals by a merge-path binary search, every lane walks its diagonal, and
 //                     a wave prefix sum over the per-lane union counts places the truncation point.
 //                     Serves the pairwise C ABI and small / ragged blocks.
-//   k_compare_tiled   see below: the N x N matrix kernel.
+//   k_pair_block/grid one ordered pair from plain pointers (the pairwise reference API).
+//   k_compare_few     a few sketches against many (LinearIndex::find, scaffold arg-max).
+//   k_compare_comp    N x M block, few sharing pairs: one workgroup per (column, rows of its component).
+//   k_compare_tiled   the N x M matrix kernel (see below), over the tiles a device-side plan selects;
+//                     frequent hashes are set aside and decided by k_fill_disjoint from per-sketch records.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -1,20 +1,23 @@
 // sketch_kernels.hip -- gfx950 kernels for KmerMinHash::add_sequence
 // (reference src/lib.rs:252-305) and its helpers:
 //
-//   k_dna_rolling<K>   DNA arm, ksize <= 128 (2, 4 or 8 32-bit limbs per packed window).  One lane owns a run of R consecutive k-mer start
-//                      positions; the tile is read from HBM once with coalesced 16-byte loads
-//                      and staged in LDS; each lane rolls two 2-bit packed windows (forward in
-//                      big- and little-endian digit order; the reverse complement is their
-//                      bitwise complement), picks the canonical strand with one 64-bit compare,
-//                      takes the first multiply of every murmur word from LDS product tables
-//                      indexed by the 2-bit digits (the ASCII bytes are never formed) and runs the
-//                      rest of MurmurHash3 x64_128 (first word) in registers.
+//   k_dna_rolling<K>   DNA arm, ksize <= 128 (2, 4 or 8 32-bit limbs per packed window).  One lane owns a run of R
+//                      consecutive k-mer start positions; the tile is read from HBM once with coalesced
+//                      16-byte loads and staged in LDS; each lane rolls two 2-bit packed windows (the forward
+//                      k-mer, first base least significant, and its complement, first base most significant
+//                      = the reverse complement, first base least significant), picks the canonical strand
+//                      with one 64-bit compare, takes the first multiply of every murmur word from LDS
+//                      product tables indexed by the 2-bit digits (the ASCII bytes are never formed) and
+//                      runs the rest of MurmurHash3 x64_128 (first word) on 32-bit halves in registers.
 //                      replaces: src/lib.rs:260-267 (+ revcomp 677-689, _checkdna 795-804,
 //                      _hash_murmur 33-35) and the `hash <= max_hash` filter of add_hash 198.
 //   k_dna_generic      same contract for any ksize, one lane per k-mer, byte-wise.
 //   k_first_invalid    first byte outside [ACGTacgt] per record (force=false, lib.rs:268-273).
-//   k_translate        six-frame translation, unknown codons marked (lib.rs:277-301, 779-793).
-//   k_hash_windows     every window of `win` residues, skipping dropped codons (lib.rs:289-300).
+//   k_protein_fused<W> protein arm in one pass: translation + hashing of both strands' windows, no residue
+//                      buffer (lib.rs:275-302, 691-793); k_protein_positions rewrites candidate positions.
+//   k_translate        six-frame translation into a residue buffer, unknown codons marked (lib.rs:277-301,
+//   k_hash_windows     779-793) + every window of `win` residues, skipping dropped codons (lib.rs:289-300):
+//                      the two-pass path for batches with non-ASCII bytes, partial ranges, other window lengths.
 //   k_hash_segments    murmur64 of whole byte strings (add_word lib.rs:247-250, ffi.rs:15-24).
 //   k_synth_dna        benchmark input generator.
 //
