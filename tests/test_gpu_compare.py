@@ -587,7 +587,21 @@ def test_row_block_that_is_a_slice_of_the_columns(tune, expect, pkg, coracle):
     pool = np.unique(rng.randint(0, 1 << 62, size=5000, dtype=np.int64).astype(np.uint64))
     n, width = 240, 300
     sigs = np.stack([np.sort(rng.choice(pool, width, replace=False)) for _ in range(n)])
+    _row_block_views(pkg, coracle, sigs, tune, expect)
+    # the same with two hashes held by every signature (set aside as frequent; the row view's records come
+    # from the columns' elements)
+    sigs2 = sigs.copy()
+    sigs2[:, 0] = 5; sigs2[:, -1] = (1 << 63) - 1
+    st = _row_block_views(pkg, coracle, sigs2, tune, expect)
+    if tune.get("split_frequent", True):
+        assert st["frequent_hashes"] == 2, st
+
+
+def _row_block_views(pkg, coracle, sigs, tune, expect):
+    import torch
+    n, width = sigs.shape
     allt = torch.from_numpy(sigs.view(np.int64)).cuda()
+    st = None
     for lo, hi in ((0, 80), (80, 160), (170, 240)):
         rows = allt[lo:hi]
         ro = np.arange(hi - lo + 1, dtype=np.uint64) * np.uint64(width)
@@ -600,6 +614,8 @@ def test_row_block_that_is_a_slice_of_the_columns(tune, expect, pkg, coracle):
         assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
         assert (out["jaccard"].cpu().numpy() == jac).all()
         assert (out["jaccard"].cpu().numpy()[np.arange(hi - lo), np.arange(lo, hi)] == 1.0).all()
+        st = pkg.matrix.last_stats()
+    return st
 
 
 @pytest.mark.parametrize("tune,expect", ROUTES)
