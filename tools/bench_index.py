@@ -2,7 +2,7 @@
 HBM-resident index (smh_index_find).  Run on the GPU box: python tools/bench_index.py [n]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401  (maps torch's HIP runtime first)
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -1,7 +1,7 @@
 """k-mer size sweep on 2 GB (k=31/21/51 are compile-time instantiations, the rest run-time k)."""
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from __graft_entry__ import load_package
 pkg = load_package()

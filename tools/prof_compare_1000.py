@@ -1,7 +1,7 @@
 """C3: 1000 x 1000 num=2000 matrix on device-resident signatures, repeated; for rocprofv3 --kernel-trace --stats."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -1,6 +1,6 @@
 import ctypes as C, os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from __graft_entry__ import load_package
 pkg = load_package()
