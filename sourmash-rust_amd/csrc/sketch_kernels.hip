@@ -290,18 +290,16 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     for (int j = 0; j < nb; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
     ptab[e] = (uint64_t)v * (ent < 256 ? kC1 : (ent < 512 ? kC2 : c_last));
   }
-  // table base (bytes) and digit mask (already scaled by the 8-byte entry size) of every 4-letter
-  // group: compile-time constants for a compile-time k, fixed for the launch otherwise, so that the
-  // per-k-mer code is the same straight line either way
-  uint32_t gbase[4 * L], gmask8[4 * L];
+  // table base (bytes) of every 4-letter group: a compile-time constant for a compile-time k, fixed for
+  // the launch otherwise, so that the per-k-mer code is the same straight line either way
+  uint32_t gbase[4 * L];
 #pragma unroll
   for (int g = 0; g < 4 * L; g++) {
     const int nb = K - 4 * g;
-    uint32_t ent0 = 576u, mask = 0u;                                   // past the k-mer: the zero entry
-    if (nb >= 4) { ent0 = ((g >> 1) & 1) ? 256u : 0u; mask = 0xffu; }
-    else if (nb > 0) { ent0 = 512u; mask = (1u << (2 * nb)) - 1u; }
+    uint32_t ent0 = 576u;                                              // past the k-mer: the zero entry
+    if (nb >= 4) ent0 = ((g >> 1) & 1) ? 256u : 0u;
+    else if (nb > 0) ent0 = 512u;
     gbase[g] = ent0 * 8u;
-    gmask8[g] = mask << 3;
   }
   if (tid == 0) st_ctl[0] = 0;
 
@@ -470,21 +468,15 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
                 // the digits that belong to the k-mer; P1 / P2 by word parity, the partial table, or
                 // (run-time k only) the zero entry
                 const uint32_t xw = X[q][g >> 2];
-                const int sb = 8 * (g & 3) - 3;
+                // byte (g & 3) of the limb, times 8, in ONE sub-dword-addressed shift (SDWA issues at full
+                // rate on gfx950: 32.0 -> 30.8 ms per 10 GB).  No mask is needed, for any k: both windows are
+                // zero above their 2k bits, so a partial group indexes inside its 4^nb-entry table and a
+                // group past the k-mer reads entry 0 of the zero table.
                 uint32_t off;
-                if (KT != 0) {
-                  // compile-time k: byte (g & 3) of the limb, times 8, in ONE sub-dword-addressed shift (SDWA
-                  // issues at full rate on gfx950: 32.0 -> 30.8 ms per 10 GB).  The last, partial group needs no
-                  // mask: both windows are zero above their 2k bits.
-                  if ((g & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(xw));
-                  else if ((g & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(xw));
-                  else if ((g & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(xw));
-                  else asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(xw));
-                } else {
-                  off = sb < 0 ? xw << 3 : xw >> sb;
-                  asm("" : "+v"(off));                                 // shift, then mask: two full-rate ops (not v_bfe + v_lshl_add)
-                  off &= gmask8[g];
-                }
+                if ((g & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(xw));
+                else if ((g & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(xw));
+                else if ((g & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(xw));
+                else asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(xw));
                 const char* at = reinterpret_cast<const char*>(lut) + gbase[g] + off;
                 if ((g & 1) == 0) {                                  // low half of the word: full product
                   const uint2 e = *reinterpret_cast<const uint2*>(at);
