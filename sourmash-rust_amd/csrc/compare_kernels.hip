@@ -630,6 +630,12 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 }
 
 // ---- pre-pass kernels ---------------------------------------------------------------------
+// dense rank of every pooled element, back in pool order: rank[origin[i]] = run of sorted position i
+__global__ __launch_bounds__(256) void k_rank_scatter(const uint32_t* __restrict__ runid, const uint32_t* __restrict__ origin,
+                                                      uint64_t n, uint32_t* __restrict__ rank, const PlanState* __restrict__ st) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !st->skip_tiled) rank[origin[i]] = runid[i];
+}
 __global__ void k_iota(uint32_t* p, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (uint32_t)i;
@@ -1087,8 +1093,8 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // ---- runs of equal hashes: dense ranks (for the tiled kernel) and run lengths (document frequencies)
   const uint32_t M = same ? cols.n : rows.n + cols.n;
   T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4); T.runid.ensure(n * 4);
-  run_length_encode_u64_async(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so, T.rank.as<uint32_t>(),
-                              &st->nruns, nullptr, T.runid.as<uint32_t>());
+  run_length_encode_u64_async(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr,
+                              &st->nruns, nullptr, T.runid.as<uint32_t>());   // (ranks by origin: k_rank_scatter, tiled route only)
   // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
   const bool split = tune.split_frequent != 0 && M >= 32;
   const uint8_t* isfreq = nullptr;
@@ -1222,6 +1228,8 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   const int wpb = ex.wpb, minw = ex.minw;
   uint32_t tiles_cap = 0;
   if (tune.route != kRouteComponents) {
+    hipLaunchKernelGGL(k_rank_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.runid.as<uint32_t>(), so, n,
+                       T.rank.as<uint32_t>(), st);
     // ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords;
     // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
     // sketches walk several ranges per step

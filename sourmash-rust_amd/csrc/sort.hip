@@ -11,6 +11,8 @@
 //
 // Wave = 64 lanes everywhere; masks are 64-bit.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "device.hpp"
@@ -134,6 +136,36 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_add(uint32_t* __restrict_
     if (base + i < m) data[base + i] += add;
 }
 
+// Offsets of a pass in ONE small launch (tiles <= kRowScanMax): workgroup d scans row d of the digit-major
+// per-tile counts in place and leaves the digit's total; the scatter kernel adds the exclusive prefix of
+// the 256 totals itself.  (The generic three-launch scan of 256 * tiles counters is pure latency for the
+// few thousand tiles of a 2 M-key sort: 15 of the 41 us of a pass.)
+constexpr uint32_t kRowScanMax = 16384;
+__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ blockhist, uint32_t nblocks,
+                                                       uint32_t* __restrict__ digit_tot) {
+  __shared__ uint32_t wt[4];
+  uint32_t* row = blockhist + (size_t)blockIdx.x * nblocks;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < nblocks ? row[i] : 0u;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wt[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (int k = 0; k < 4; k++) { if (k < w) before += wt[k]; tot += wt[k]; }
+    if (i < nblocks) row[i] = carry + before + incl - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) digit_tot[blockIdx.x] = carry;
+}
+
 // stable scatter of one digit.  Wave w of the workgroup owns the contiguous sub-tile
 // [w*512, (w+1)*512) of the tile and walks it 64 keys per round, so (wave, round, lane)
 // order is index order and equal digits keep their relative order.
@@ -145,8 +177,9 @@ template <int VB>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout, const void* __restrict__ vin_,
     void* __restrict__ vout_, size_t n, int shift, const uint32_t* __restrict__ scanned,
-    uint32_t nblocks) {
+    uint32_t nblocks, const uint32_t* __restrict__ digit_tot) {
   __shared__ uint32_t wcount[kWaves][256];
+  __shared__ uint32_t wtot2[kWaves];
   __shared__ uint32_t lbase[kWaves][256];   // position in the digit-ordered tile of (wave, digit)'s first key
   __shared__ uint32_t dexcl[256];           // first position of digit d in the digit-ordered tile
   __shared__ uint32_t gbase[256];           // first global position of digit d for this workgroup
@@ -198,7 +231,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     for (int ww = 0; ww < w; ww++) before += wtot[ww];
     const uint32_t ex = before + incl - tot;
     dexcl[t] = ex;
-    gbase[t] = scanned[(size_t)t * nblocks + blockIdx.x];
+    // rows scanned one by one (k_radix_rowscan): add the exclusive prefix of the digit totals
+    uint32_t dbase = 0;
+    if (digit_tot) {
+      const uint32_t dt = digit_tot[t];
+      uint32_t inc2 = dt;
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc2, off);
+        if (lane >= off) inc2 += o;
+      }
+      if (lane == 63) wtot2[w] = inc2;
+      __syncthreads();
+      for (int ww = 0; ww < w; ww++) dbase += wtot2[ww];
+      dbase += inc2 - dt;
+    }
+    gbase[t] = dbase + scanned[(size_t)t * nblocks + blockIdx.x];
     uint32_t run = ex;
 #pragma unroll
     for (int ww = 0; ww < kWaves; ww++) {
@@ -452,7 +499,7 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
   const size_t hist_bytes = 8 * 256 * sizeof(unsigned long long);
   const size_t bh_bytes = (size_t)256 * nblocks * sizeof(uint32_t);
-  const size_t tmp_bytes = scan_tmp_entries((size_t)256 * nblocks) * sizeof(uint32_t);
+  const size_t tmp_bytes = std::max<size_t>(scan_tmp_entries((size_t)256 * nblocks), 256) * sizeof(uint32_t);   // (>= the 256 digit totals)
   scratch.ensure(hist_bytes + bh_bytes + tmp_bytes);
   auto* ghist = (unsigned long long*)scratch.ptr;
   auto* blockhist = (uint32_t*)((char*)scratch.ptr + hist_bytes);
@@ -481,16 +528,22 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
     if (trivial) continue;  // every key has the same digit: the pass is the identity
     hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
                        blockhist, nblocks);
-    exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, scan_tmp, s);
+    const uint32_t* dtot = nullptr;
+    if (nblocks <= kRowScanMax) {
+      hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, blockhist, nblocks, scan_tmp);
+      dtot = scan_tmp;
+    } else {
+      exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, scan_tmp, s);
+    }
     if (v0 && vbytes == 8)
       hipLaunchKernelGGL(k_radix_scatter<8>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks);
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot);
     else if (v0 && vbytes == 4)
       hipLaunchKernelGGL(k_radix_scatter<4>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks);
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot);
     else
       hipLaunchKernelGGL(k_radix_scatter<0>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks);
+                         kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks, dtot);
     HIP_CHECK(hipGetLastError());
     cur ^= 1;
   }
