@@ -11,15 +11,81 @@ void throw_hip(hipError_t e, const char* what, const char* file, int line) {
   throw_internal(m);
 }
 
+// ---- block pool -----------------------------------------------------------------------------
+// hipMalloc / hipFree of the buffers a sketch is made of cost hundreds of microseconds each at
+// the sizes of the benchmark configurations (a 10 GB batch leaves 80 MB of hashes, the protein
+// share 270 MB) -- more than the sort that fills them.  Freed blocks are kept by size class
+// (eight classes per power of two: at most 12.5 % slack) up to kPoolLimit bytes and handed out again.
+namespace {
+std::mutex g_pool_mu;
+std::map<size_t, std::vector<void*>> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolLimit = 4ull << 30;
+
+size_t size_class(size_t need) {
+  if (need <= 4096) return 4096;
+  const int lg = 63 - __builtin_clzll((unsigned long long)(need - 1));   // need in (2^lg, 2^(lg+1)]
+  const size_t step = (size_t)1 << (lg - 3);
+  return (need + step - 1) / step * step;
+}
+}  // namespace
+
+void* device_pool_alloc(size_t need, size_t* cap) {
+  const size_t c = size_class(need);
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto it = g_pool.find(c);
+    if (it != g_pool.end() && !it->second.empty()) {
+      void* p = it->second.back();
+      it->second.pop_back();
+      g_pool_bytes -= c;
+      *cap = c;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, c);
+  if (e == hipErrorOutOfMemory) {                         // give the pooled blocks back and try once more
+    (void)hipGetLastError();
+    device_pool_trim();
+    e = hipMalloc(&p, c);
+  }
+  HIP_CHECK(e);
+  *cap = c;
+  return p;
+}
+
+void device_pool_free(void* ptr, size_t cap, bool sync) {
+  if (!ptr) return;
+  // hipFree waits for the device; a block that goes back to the pool instead may be handed to work on
+  // another stream at once, so the callers whose block may still be in use keep that wait
+  if (sync) (void)hipDeviceSynchronize();
+  if (cap >= 4096 && size_class(cap) == cap) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (g_pool_bytes + cap <= kPoolLimit) {
+      g_pool[cap].push_back(ptr);
+      g_pool_bytes += cap;
+      return;
+    }
+  }
+  (void)hipFree(ptr);
+}
+
+void device_pool_trim() {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (auto& kv : g_pool) for (void* p : kv.second) (void)hipFree(p);
+  g_pool.clear();
+  g_pool_bytes = 0;
+}
+
 void DeviceBuffer::ensure(size_t need) {
   if (need <= bytes) return;
-  size_t want = need + need / 4 + 4096;
-  if (ptr) { HIP_CHECK(hipFree(ptr)); ptr = nullptr; bytes = 0; }
-  HIP_CHECK(hipMalloc(&ptr, want));
-  bytes = want;
+  const size_t want = need + need / 4 + 4096;
+  release();
+  ptr = device_pool_alloc(want, &bytes);
 }
 void DeviceBuffer::release() {
-  if (ptr) (void)hipFree(ptr);
+  if (ptr) device_pool_free(ptr, bytes, true);
   ptr = nullptr;
   bytes = 0;
 }

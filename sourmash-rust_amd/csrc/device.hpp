@@ -23,7 +23,14 @@ namespace smh {
     if (e_ != hipSuccess) ::smh::throw_hip(e_, #expr, __FILE__, __LINE__); \
   } while (0)
 
-// grow-only device allocation (never shrinks; freed with the context or explicitly)
+// Device blocks come from a pool of freed blocks kept by size class (device.cpp).  `cap` is the
+// block's real size; give it back with the same value.  sync = wait for the device first, as
+// hipFree would (for blocks that work still in flight may be using).
+void* device_pool_alloc(size_t need, size_t* cap);
+void device_pool_free(void* ptr, size_t cap, bool sync);
+void device_pool_trim();   // hipFree everything the pool holds
+
+// grow-only device allocation (never shrinks; released with the context or explicitly)
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;

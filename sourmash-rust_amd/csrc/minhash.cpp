@@ -42,45 +42,11 @@ KmerMinHash& KmerMinHash::operator=(const KmerMinHash& o) {
   return *this;
 }
 
-// Mirror buffers come from a small pool keyed by power-of-two size: a sketch that is created,
-// compared once and dropped must not pay a hipMalloc + hipFree per compare.
-namespace {
-std::mutex g_pool_mu;
-std::map<size_t, std::vector<void*>> g_pool;
-size_t g_pool_bytes = 0;
-constexpr size_t kPoolLimit = 256u << 20;
-
-void mirror_alloc(size_t need, void** ptr, size_t* cap) {
-  size_t c = 4096;
-  while (c < need) c <<= 1;
-  {
-    std::lock_guard<std::mutex> lock(g_pool_mu);
-    auto it = g_pool.find(c);
-    if (it != g_pool.end() && !it->second.empty()) {
-      *ptr = it->second.back();
-      it->second.pop_back();
-      g_pool_bytes -= c;
-      *cap = c;
-      return;
-    }
-  }
-  HIP_CHECK(hipMalloc(ptr, c));
-  *cap = c;
-}
-}  // namespace
-
+// Mirror buffers come from the device block pool: a sketch that is created, compared once and
+// dropped must not pay a hipMalloc + hipFree per compare.  (No wait for the device when one goes
+// back: every call that reads a mirror has synchronised before it returns.)
 DeviceMirror::~DeviceMirror() {
-  if (!ptr) return;
-  const bool pow2 = (cap & (cap - 1)) == 0 && cap >= 4096;
-  if (pow2) {
-    std::lock_guard<std::mutex> lock(g_pool_mu);
-    if (g_pool_bytes + cap <= kPoolLimit) {
-      g_pool[cap].push_back(ptr);
-      g_pool_bytes += cap;
-      return;
-    }
-  }
-  (void)hipFree(ptr);
+  if (ptr) device_pool_free(ptr, cap, false);
 }
 
 // order-sensitive 64-bit checksum of a word array, four independent lanes
@@ -1297,12 +1263,7 @@ void Engine::release_workspace() {
                           &cmp_oa, &cmp_ob, &cmp_out, &pair_out, &dev.scratch})
     b->release();
   release_compare_scratch();
-  {
-    std::lock_guard<std::mutex> pl(g_pool_mu);
-    for (auto& kv : g_pool) for (void* p : kv.second) (void)hipFree(p);
-    g_pool.clear();
-    g_pool_bytes = 0;
-  }
+  device_pool_trim();
 }
 
 void Engine::pack_sketches(const std::vector<const KmerMinHash*>& v, DeviceBuffer& data, DeviceBuffer& offs,
@@ -1413,7 +1374,7 @@ const uint64_t* Engine::mirror_of(const KmerMinHash& mh, hipStream_t s) {
   const uint64_t sum = words_checksum(mh.mins.data(), n);
   if (!mh.mirror || mh.mirror->n != n || mh.mirror->sum != sum) {
     auto m = std::make_shared<DeviceMirror>();
-    mirror_alloc(n * 8 + 8, &m->ptr, &m->cap);
+    m->ptr = device_pool_alloc(n * 8 + 8, &m->cap);
     if (n) HIP_CHECK(hipMemcpyAsync(m->ptr, mh.mins.data(), n * 8, hipMemcpyHostToDevice, s));  // pageable source: staged before return
     m->n = n;
     m->sum = sum;

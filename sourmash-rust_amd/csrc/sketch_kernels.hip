@@ -182,7 +182,11 @@ __device__ __forceinline__ W2 w2_mul(W2 x, uint64_t c) {
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(t), "=s"(cy) : "v"(x.hi), "s"(cl));
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(u), "=s"(cy) : "v"(x.lo), "s"(ch), "v"(t));
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(p), "=s"(cy) : "v"(x.lo), "s"(cl));
-  return {(uint32_t)p, (uint32_t)(p >> 32) + (uint32_t)u};
+  // (the add as asm too: left to the compiler it sometimes becomes a 64-bit add of p and {0, u.lo} -- two moves
+  // to build the pair and a half-rate v_lshl_add_u64)
+  uint32_t hi;
+  asm("v_add_u32 %0, %1, %2" : "=v"(hi) : "v"((uint32_t)(p >> 32)), "v"((uint32_t)u));
+  return {(uint32_t)p, hi};
 }
 __device__ __forceinline__ W2 w2_xor(W2 a, W2 b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
 // 64-bit values the compiler must treat as whole register pairs (an empty asm hides how they were
@@ -194,6 +198,12 @@ __device__ __forceinline__ uint64_t w2_pair(W2 a) {
 }
 __device__ __forceinline__ W2 w2_split(uint64_t v) { return {(uint32_t)v, (uint32_t)(v >> 32)}; }
 __device__ __forceinline__ W2 w2_add(W2 a, W2 b) { return w2_split(w2_pair(a) + w2_pair(b)); }   // one v_lshl_add_u64
+// h1 += h2; h2 += h1 (each value becomes a whole pair once)
+__device__ __forceinline__ void w2_cross_add(W2& h1, W2& h2) {
+  uint64_t a = w2_pair(h1), b = w2_pair(h2);
+  a += b; b += a;
+  h1 = w2_split(a); h2 = w2_split(b);
+}
 // x * 5 + c as (x << 2) + x, then + c: two v_lshl_add_u64
 __device__ __forceinline__ W2 w2_mul5_add(W2 x, uint64_t c) {
   const uint64_t v = w2_pair(x);
@@ -201,18 +211,32 @@ __device__ __forceinline__ W2 w2_mul5_add(W2 x, uint64_t c) {
   asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(t) : "v"(v));   // (left to itself the compiler multiplies by 5: two v_mad_u64_u32 and two moves)
   return w2_split(t + c);
 }
-__device__ __forceinline__ W2 w2_fmix(W2 k) {
+// fmix64 WITHOUT its last `k ^= k >> 33`.  That step only touches the low dword, and whether the digest
+// h = fmix(h1) + fmix(h2) can be <= a threshold is settled by the high dwords up to one carry (open_may_pass):
+// the windows that cannot pass -- all but ~1/scaled of them -- skip the last step of both mixes and the 64-bit sum.
+__device__ __forceinline__ W2 w2_fmix_open(W2 k) {
   k.lo ^= k.hi >> 1;                                   // k ^= k >> 33
   k = w2_mul(k, 0xff51afd7ed558ccdULL);
   k.lo ^= k.hi >> 1;
   k = w2_mul(k, 0xc4ceb9fe1a85ec53ULL);
-  k.lo ^= k.hi >> 1;
   return k;
 }
+// thr_hi1 = open_thr(thr).  h.hi is a.hi + b.hi or that + 1 (mod 2^32), so h <= thr needs a.hi + b.hi + 1 (mod 2^32)
+// <= thr.hi + 1; a superset of the passing windows (exact test: open_finish() <= thr), everything when thr.hi is all ones.
+__device__ __forceinline__ uint32_t open_thr(uint64_t thr) {
+  const uint32_t hi = (uint32_t)(thr >> 32);
+  return hi == 0xffffffffu ? hi : hi + 1u;
+}
+__device__ __forceinline__ bool open_may_pass(W2 a, W2 b, uint32_t thr_hi1) { return a.hi + b.hi + 1u <= thr_hi1; }
+__device__ __forceinline__ uint64_t open_finish(W2 a, W2 b) {
+  a.lo ^= a.hi >> 1; b.lo ^= b.hi >> 1;
+  return ((((uint64_t)a.hi << 32) | a.lo) + (((uint64_t)b.hi << 32) | b.lo));
+}
 // murmur64 from premultiplied words: M[w] = word_w * (w even ? c1 : c2)
+// The digest is left OPEN: (a, b) with h = open_finish(a, b).
 template <int L>
-__device__ __forceinline__ uint64_t murmur_kmer_pre(const W2 (&M)[2 * L], int K, uint64_t seed) {
-  W2 h1{(uint32_t)seed, (uint32_t)(seed >> 32)}, h2 = h1;
+__device__ __forceinline__ void murmur_kmer_pre(const W2 (&M)[2 * L], int K, uint64_t seed, W2 seedv, W2& a, W2& b) {
+  W2 h1 = seedv, h2 = seedv;                            // (seedv: the seed's halves in vector registers, see k_dna_rolling)
   const int nblocks = K >> 4, tail = K & 15;
 #pragma unroll
   for (int blk = 0; blk < L; blk++) {
@@ -229,10 +253,8 @@ __device__ __forceinline__ uint64_t murmur_kmer_pre(const W2 (&M)[2 * L], int K,
     }
   }
   h1.lo ^= (uint32_t)K; h2.lo ^= (uint32_t)K;          // ^= len (K <= 128)
-  h1 = w2_add(h1, h2); h2 = w2_add(h2, h1);
-  h1 = w2_fmix(h1); h2 = w2_fmix(h2);
-  const W2 r = w2_add(h1, h2);                         // first word of the digest
-  return ((uint64_t)r.hi << 32) | r.lo;
+  w2_cross_add(h1, h2);
+  a = w2_fmix_open(h1); b = w2_fmix_open(h2);         // first word of the digest = open_finish(a, b)
 }
 
 // KT > 0: ksize fixed at compile time; KT == 0: any ksize the limb count allows, at run time.
@@ -312,6 +334,11 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
   for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const uint64_t T0 = hp.range_lo + tix * TILE;
     const uint64_t thr = hp.thr;
+    const uint32_t thr_hi1 = open_thr(hp.thr);
+    // An operand in a scalar register halves the issue rate of a plain two-operand instruction (tools/instr_rate.hip):
+    // what the hash xors in per k-mer lives in vector registers.
+    W2 seedv{(uint32_t)hp.seed, (uint32_t)(hp.seed >> 32)};
+    asm volatile("" : "+v"(seedv.lo), "+v"(seedv.hi));
     uint64_t lthr = hp.thr;   // PR: threshold of the record the lane is in
 
     // ---- stage [T0, T0 + TILE + K - 1) in LDS: aligned 16-byte loads, one pad dword per R bytes
@@ -455,7 +482,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
           }
         }
         if (kHash && i0 + g0b + HB >= (uint32_t)K) {  // uniform: some window of this block is complete
-          uint64_t h[HB];
+          W2 ha[HB], hb[HB];
 #pragma unroll
           for (int q = 0; q < HB; q++) {
             W2 M[2 * L];
@@ -486,15 +513,16 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
                 }
               }
             }
-            h[q] = murmur_kmer_pre<L>(M, K, hp.seed);
+            murmur_kmer_pre<L>(M, K, hp.seed, seedv, ha[q], hb[q]);
           }
 #pragma unroll
           for (int q = 0; q < HB; q++)
-            if (h[q] <= (PR ? tq[g0b + q] : thr)) {       // ~1 in `scaled` windows gets here
+            if (open_may_pass(ha[q], hb[q], PR ? open_thr(tq[g0b + q]) : thr_hi1)) {   // ~1 in `scaled` windows gets here
               uint32_t om = okmask;
               asm volatile("" : "+v"(om));                  // keeps the mask test inside this rare block
-              if ((om >> (g0b + q)) & 1u)
-                stage_emit(stage, sink, h[q], hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K));
+              const uint64_t h = open_finish(ha[q], hb[q]);
+              if (h <= (PR ? tq[g0b + q] : thr) && ((om >> (g0b + q)) & 1u))
+                stage_emit(stage, sink, h, hp.pos_base + p0 + (i0 + g0b + q + 1 - (uint32_t)K));
             }
         }
       }
@@ -870,22 +898,32 @@ __device__ __noinline__ void hash_spliced_windows(SplicedArgs A, uint32_t win, u
   }
 }
 
-// murmur64 of a W-byte string held in dwords D[0..3] (bytes past W are zero), 1 <= W <= 16: no
-// full block, k1 = bytes 0..7, k2 = bytes 8..W-1 (reference src/lib.rs:33-35 on aa.windows())
+// murmur64 of a W-byte string, 1 <= W <= 16: no full block, k1 = bytes 0..7, k2 = bytes 8..W-1 (reference
+// src/lib.rs:33-35 on aa.windows()).  k1c1 = k1 * c1 is handed in (the two strands get it differently, see
+// k_protein_fused); k2 = the bytes past the eighth as they are; the digest is left open (w2_fmix_open).
+// W == 9: k2 is one byte, so its whole contribution -- seed ^ mix_k2(byte) ^ W -- comes from a table (h2_ready).
 template <int W>
-__device__ __forceinline__ uint64_t murmur_short(const uint32_t (&D)[4], uint64_t seed, uint64_t h2_ready) {
-  // W == 9: k2 is one byte, so its whole contribution -- seed ^ mix_k2(byte) ^ W -- comes from a table (2 of the
-  // hash's 8 multiplies and the xors with it)
-  W2 h1{(uint32_t)seed ^ (uint32_t)W, (uint32_t)(seed >> 32)}, h2{(uint32_t)h2_ready, (uint32_t)(h2_ready >> 32)};
+__device__ __forceinline__ void murmur_short(W2 k1c1, W2 k2, W2 seedw /* seed ^ W, in vector registers */, uint64_t h2_ready, W2& a, W2& b) {
+  W2 h1 = seedw, h2{(uint32_t)h2_ready, (uint32_t)(h2_ready >> 32)};
   if (W != 9) {
-    h2 = W2{(uint32_t)seed ^ (uint32_t)W, (uint32_t)(seed >> 32)};
-    if (W > 8) h2 = w2_xor(h2, w2_mul(w2_rotl(w2_mul(W2{D[2], D[3]}, kC2), 33), kC1));
+    h2 = seedw;
+    if (W > 8) h2 = w2_xor(h2, w2_mul(w2_rotl(w2_mul(k2, kC2), 33), kC1));
   }
-  h1 = w2_xor(h1, w2_mul(w2_rotl(w2_mul(W2{D[0], D[1]}, kC1), 31), kC2));
-  h1 = w2_add(h1, h2); h2 = w2_add(h2, h1);
-  h1 = w2_fmix(h1); h2 = w2_fmix(h2);
-  const W2 r = w2_add(h1, h2);
-  return ((uint64_t)r.hi << 32) | r.lo;
+  h1 = w2_xor(h1, w2_mul(w2_rotl(k1c1, 31), kC2));
+  w2_cross_add(h1, h2);
+  a = w2_fmix_open(h1); b = w2_fmix_open(h2);
+}
+
+// byte BYTE of x, shifted left by SH, in one sub-dword-addressed instruction (full rate; see k_dna_rolling)
+template <int SH, int BYTE>
+__device__ __forceinline__ uint32_t byte_shl(uint32_t x) {
+  static_assert((SH == 3 || SH == 5) && BYTE >= 0 && BYTE < 4, "byte_shl");
+  uint32_t r;
+#define SMH_BSHL(SH_, B_) asm("v_lshlrev_b32_sdwa %0, " #SH_ ", %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B_ : "=v"(r) : "v"(x))
+  if (SH == 3) { if (BYTE == 0) SMH_BSHL(3, 0); else if (BYTE == 1) SMH_BSHL(3, 1); else if (BYTE == 2) SMH_BSHL(3, 2); else SMH_BSHL(3, 3); }
+  else         { if (BYTE == 0) SMH_BSHL(5, 0); else if (BYTE == 1) SMH_BSHL(5, 1); else if (BYTE == 2) SMH_BSHL(5, 2); else SMH_BSHL(5, 3); }
+#undef SMH_BSHL
+  return r;
 }
 
 #ifndef SMH_PF_MINW
@@ -899,8 +937,10 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
                                                                           uint32_t stage_cap, uint32_t* __restrict__ high_flag) {
   constexpr int KB = 3 * W;                          // bases per window
   constexpr int ND = (W + 3) / 4;                    // dwords of a residue string
-  // static LDS: codon table (digits -> residue | residue of the reverse complement << 8), mix_k2 of a byte
-  __shared__ uint32_t ctab[64];
+  // static LDS: codon table, 32-byte entries -- codon number (its first base's digit lowest) -> { (residue of the
+  // reverse complement) * c1, W == 9: seed ^ mix_k2(residue) ^ W, residue | residue of the reverse complement << 8 } --
+  // and seed ^ mix_k2(byte) ^ W of any byte (W == 9: the reverse strand's k2 is a residue met eight codons earlier)
+  __shared__ __attribute__((aligned(16))) uint32_t ctab[64 * 8];
   __shared__ uint64_t k2tab[W == 9 ? 256 : 1];
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* st_ctl = smem;
@@ -914,12 +954,19 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
   const uint64_t TILE = (uint64_t)THREADS << logR;
   const bool multi = b.starts != nullptr;
   if (tid < 64) {
-    const int d0 = (tid >> 4) & 3, d1 = (tid >> 2) & 3, d2 = tid & 3;
-    ctab[tid] = aa_of_digits(d0, d1, d2) | (aa_of_digits(3 - d2, 3 - d1, 3 - d0) << 8);
+    const int d0 = tid & 3, d1 = (tid >> 2) & 3, d2 = (tid >> 4) & 3;
+    const uint32_t af = aa_of_digits(d0, d1, d2), ar = aa_of_digits(3 - d2, 3 - d1, 3 - d0);
+    const uint64_t arc1 = (uint64_t)ar * kC1, h2f = hp.seed ^ mix_k2((uint64_t)af) ^ (uint64_t)W;
+    ctab[8 * tid] = (uint32_t)arc1; ctab[8 * tid + 1] = (uint32_t)(arc1 >> 32);
+    ctab[8 * tid + 2] = (uint32_t)h2f; ctab[8 * tid + 3] = (uint32_t)(h2f >> 32);
+    ctab[8 * tid + 4] = af | (ar << 8);
   }
   if (W == 9) for (int e = tid; e < 256; e += THREADS) k2tab[e] = hp.seed ^ mix_k2((uint64_t)e) ^ (uint64_t)W;
   if (tid == 0) st_ctl[0] = 0;
 
+  const uint32_t thr_hi1 = open_thr(hp.thr);
+  W2 seedw{(uint32_t)hp.seed ^ (uint32_t)W, (uint32_t)(hp.seed >> 32)};   // in vector registers: see k_dna_rolling
+  asm volatile("" : "+v"(seedw.lo), "+v"(seedw.hi));
   const uint64_t ntiles = (b.len + TILE - 1) / TILE;
   const uintptr_t gend = ((uintptr_t)(b.seq + b.len) + 15) & ~(uintptr_t)15;
   const uint32_t nsteps = ((R + (uint32_t)KB - 1 + 11) / 12) * 12;   // bases walked per lane: whole triples of dwords
@@ -973,22 +1020,40 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
     ta = ta + ((ta >> logR) << 2);
     const uint32_t sh = m & 3u;
     uint32_t cur = tile[ta >> 2];
-    uint32_t w4 = 0;                                      // last bases as 2-bit digits, newest lowest, times 4 (a ctab byte offset)
-    uint32_t Sf[3][ND], Sr[3][ND];                        // per reading frame (base index mod 3): forward / reverse-complement residue strings
+    ta += ((xu + 4u) & (R - 1)) == 0 ? 8u : 4u;
+    uint32_t nxt = tile[ta >> 2];                         // always one dword ahead: its latency hides behind the hashing
+    uint32_t pcode = 0;                                   // digits of the previous group, one per byte
+    // per reading frame (base index mod 3): the forward and the reverse-complement residue strings (for W == 9 the
+    // top dword of Sf is the last table entry as it came -- only its low byte is ever used -- and Sr keeps k1's 8 bytes)
+    uint32_t Sf[3][ND], Sr[3][ND];
+    uint64_t Mr[3];                                       // W >= 8: (first 8 residues of the reverse-complement string) * c1
 #pragma unroll
-    for (int t = 0; t < 3; t++)
+    for (int t = 0; t < 3; t++) {
+      Mr[t] = 0;
 #pragma unroll
       for (int d = 0; d < ND; d++) { Sf[t][d] = 0; Sr[t][d] = 0; }
+    }
 
     // four bases (one dword of the tile); PH = (base index / 4) mod 3 fixes which frame each base completes
     auto group = [&](uint32_t i0, auto phase, auto hashing) {
       constexpr int PH = decltype(phase)::value;
       constexpr bool kHash = decltype(hashing)::value;
-      const uint32_t xn = xu + i0 + 4;
-      ta += (xn & (R - 1)) == 0 ? 8u : 4u;
-      const uint32_t nxt = tile[ta >> 2];
+      // W == 9, reverse strand: k2 is the residue that leaves k1 -- byte 7 of the string as it stands before the base
+      // (for the group's fourth base, which shares its frame with the first: byte 6 of the string before the group).
+      // Nothing of this group is needed for it, so the four look-ups go first and overlap with everything below.
+      uint64_t h2r[4] = {0, 0, 0, 0};
+      if (kHash && W == 9) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t s1 = Sr[(4 * PH + q) % 3][1];
+          h2r[q] = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(k2tab) + (q < 3 ? byte_shl<3, 3>(s1) : byte_shl<3, 2>(s1)));
+        }
+      }
       const uint32_t d = __builtin_amdgcn_alignbyte(nxt, cur, sh);
       cur = nxt;
+      const uint32_t xn = xu + i0 + 8;
+      ta += (xn & (R - 1)) == 0 ? 8u : 4u;
+      nxt = tile[ta >> 2];                                 // for the next group
       const uint32_t u4 = d & 0xDFDFDFDFu;
       const uint32_t c2 = (u4 >> 1) & 0x03030303u;
       const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
@@ -1020,36 +1085,58 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
         }
         set_clean_window(!kHash);
       }
-      // the four codon look-ups of the group are issued together, ahead of the hashing they feed
-      uint32_t ent[4];
+      // Codon numbers of the codons that END at the group's four bases.  e4 = digits of bases i0-2 .. i0+1, one per
+      // byte; x | x >> 6 | x >> 12 gathers three consecutive bytes' digits into the first one's byte (oldest lowest).
+      const uint32_t e4 = __builtin_amdgcn_alignbyte(code4, pcode, 2);
+      pcode = code4;
+      const uint32_t ix01 = e4 | (e4 >> 6) | (e4 >> 12);              // bytes 0, 1: bases 0, 1
+      const uint32_t ix23 = code4 | (code4 >> 6) | (code4 >> 12);     // bytes 0, 1: bases 2, 3
+      // the four look-ups are issued together, ahead of the hashing they feed
+      uint32_t eaa[4];
+      uint64_t et1[4], h2f[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        w4 = ((w4 << 2) | (((code4 >> (8 * q)) & 3u) << 2)) & 0xfcu;
-        ent[q] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ctab) + w4);
+        const uint32_t off = (q & 1) ? byte_shl<5, 1>(q < 2 ? ix01 : ix23) : byte_shl<5, 0>(q < 2 ? ix01 : ix23);
+        const char* at = reinterpret_cast<const char*>(ctab) + off;
+        if (W >= 8) et1[q] = *reinterpret_cast<const uint64_t*>(at);
+        if (kHash && W == 9) h2f[q] = *reinterpret_cast<const uint64_t*>(at + 8);
+        eaa[q] = *reinterpret_cast<const uint32_t*>(at + 16);
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int t = (4 * PH + q) % 3;                    // reading frame completed by this base (lane-relative)
-        const uint32_t e = ent[q];
-        const uint32_t af = e & 0xffu, ar = (e >> 8) & 0xffu;
+        const uint32_t e = eaa[q];                         // residue | residue of the reverse complement << 8
         // forward string: drop the oldest residue (byte 0), the new one becomes byte W-1
 #pragma unroll
         for (int dd = 0; dd < ND - 1; dd++) Sf[t][dd] = __builtin_amdgcn_alignbyte(Sf[t][dd + 1], Sf[t][dd], 1);
-        Sf[t][ND - 1] = (Sf[t][ND - 1] >> 8) | (af << (8 * ((W - 1) & 3)));
-        // reverse-complement string: the new residue is its FIRST (byte 0), the oldest (byte W-1) falls off
+        if (W == 9) Sf[t][ND - 1] = e;
+        else Sf[t][ND - 1] = __builtin_amdgcn_perm(e, Sf[t][ND - 1], ((W - 1) & 3) == 0 ? 0x0c0c0c04u : ((W - 1) & 3) == 1 ? 0x0c0c0401u : ((W - 1) & 3) == 2 ? 0x0c040201u : 0x04030201u);
+        // reverse-complement string: the new residue is its FIRST (byte 0), the oldest (byte W-1) falls off.
+        // W >= 8: k1 * c1 rolls -- k1' = k1 << 8 | new (mod 2^64), and a left shift commutes with the multiplication:
+        // (k1 * c1)' = (k1 * c1) << 8 + new * c1 (table), two instructions instead of a 64 x 64 multiply.
 #pragma unroll
-        for (int dd = ND - 1; dd > 0; dd--) Sr[t][dd] = __builtin_amdgcn_alignbyte(Sr[t][dd], Sr[t][dd - 1], 3);
-        Sr[t][0] = (Sr[t][0] << 8) | ar;
-        if ((W & 3) != 0) Sr[t][ND - 1] &= (1u << (8 * (W & 3))) - 1u;
+        for (int dd = ND - 1; dd > 0; dd--) {
+          if (W == 9 && dd == 2) continue;
+          const bool last = dd == ND - 1 && (W & 3) != 0;   // partial top dword: keep the bytes past W zero
+          Sr[t][dd] = !last ? __builtin_amdgcn_alignbyte(Sr[t][dd], Sr[t][dd - 1], 3)
+                            : __builtin_amdgcn_perm(Sr[t][dd], Sr[t][dd - 1], (W & 3) == 1 ? 0x0c0c0c03u : (W & 3) == 2 ? 0x0c0c0403u : 0x0c050403u);
+        }
+        Sr[t][0] = __builtin_amdgcn_perm(e, Sr[t][0], 0x02010005u);
+        if (W >= 8) {
+          uint64_t m16;
+          asm("v_lshl_add_u64 %0, %1, 4, 0" : "=v"(m16) : "v"(Mr[t]));
+          asm("v_lshl_add_u64 %0, %1, 4, %2" : "=v"(Mr[t]) : "v"(m16), "v"(et1[q]));
+        }
         if (kHash && i0 + q + 1 >= (uint32_t)KB && i0 + q < R + (uint32_t)KB - 1) {   // uniform: a window of some lane's run can be complete here
-          uint32_t Df[4] = {0, 0, 0, 0}, Dr[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int dd = 0; dd < ND; dd++) { Df[dd] = Sf[t][dd]; Dr[dd] = Sr[t][dd]; }
-          const uint64_t hf = murmur_short<W>(Df, hp.seed, W == 9 ? k2tab[Df[2] & 0xffu] : 0ull);
-          const uint64_t hr = murmur_short<W>(Dr, hp.seed, W == 9 ? k2tab[Dr[2] & 0xffu] : 0ull);
-          if (hf <= hp.thr || hr <= hp.thr) {                // ~2 in `scaled` positions get here
+          W2 fa, fb, ra, rb;
+          const W2 k2f{ND > 2 ? Sf[t][ND > 2 ? 2 : 0] : 0u, ND > 3 ? Sf[t][ND > 3 ? 3 : 0] : 0u};
+          const W2 k2r{ND > 2 ? Sr[t][ND > 2 ? 2 : 0] : 0u, ND > 3 ? Sr[t][ND > 3 ? 3 : 0] : 0u};
+          murmur_short<W>(w2_mul(W2{Sf[t][0], Sf[t][1]}, kC1), k2f, seedw, h2f[q], fa, fb);
+          murmur_short<W>(W >= 8 ? w2_split(Mr[t]) : w2_mul(W2{Sr[t][0], Sr[t][1]}, kC1), k2r, seedw, h2r[q], ra, rb);
+          if (open_may_pass(fa, fb, thr_hi1) || open_may_pass(ra, rb, thr_hi1)) {   // ~2 in `scaled` positions get here
             uint32_t om = okmask;
             asm volatile("" : "+v"(om));
+            const uint64_t hf = open_finish(fa, fb), hr = open_finish(ra, rb);
             if ((om >> q) & 1u) {
               const uint64_t a = p0 + i0 + q + 1 - KB;      // first base of the span; see k_protein_positions
               if (hf <= hp.thr) stage_emit(stage, sink, hf, a << 1);

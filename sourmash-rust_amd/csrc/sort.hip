@@ -352,11 +352,14 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __res
                                                            const uint32_t* __restrict__ skip) {
   __shared__ uint32_t wsum[kRleThreads / 64];
   if (skip && *skip) return;   // a device-side plan decided that this result is not needed
-  size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
+  // items of a tile are dealt to the lanes round-robin: every load of a wave is one contiguous 512-byte piece
+  const size_t tile0 = (size_t)blockIdx.x * kRleTile;
   uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < kRleItems; i++)
-    if (base + i < n && is_head(keys, key2, sh2, base + i)) c++;
+  for (int i = 0; i < kRleItems; i++) {
+    const size_t idx = tile0 + (size_t)i * kRleThreads + threadIdx.x;
+    if (idx < n && is_head(keys, key2, sh2, idx)) c++;
+  }
   for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -367,8 +370,10 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_count(const uint64_t* __res
   }
 }
 
-// thread owns kRleItems consecutive keys; exclusive position of its first head inside the
-// workgroup comes from a wave scan + per-wave offsets.
+// Items dealt round-robin as in k_rle_count (row i of the tile = items i * kRleThreads ...): the number of heads
+// before an item is the heads of the rows above it, of the waves before its own in its row, and of the lanes before
+// it in its wave (a ballot).  Loads are contiguous per wave and so are the stores of the heads, apart from the gaps
+// the repeated keys leave.
 // With `origin` / `rank_out` it also scatters the run id of every element back to where the
 // element came from (rank_out[origin[i]] = run of sorted position i): the dictionary encoding of
 // the compare pre-pass, fused here instead of a second pass over the runs.
@@ -383,34 +388,52 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
                                                            uint32_t* __restrict__ rank_out,
                                                            const uint32_t* __restrict__ skip,
                                                            uint32_t* __restrict__ runid_out) {
-  __shared__ uint32_t wsum[kRleThreads / 64];
+  constexpr int NW = kRleThreads / 64;
+  static_assert(kRleItems * NW <= 64, "k_rle_write: one wave scans the per-row, per-wave head counts");
+  __shared__ uint32_t wcnt[kRleItems * NW];
   if (skip && *skip) return;
-  size_t base = (size_t)blockIdx.x * kRleTile + (size_t)threadIdx.x * kRleItems;
-  uint32_t flags = 0, c = 0;
-#pragma unroll
-  for (int i = 0; i < kRleItems; i++)
-    if (base + i < n && is_head(keys, key2, sh2, base + i)) { flags |= 1u << i; c++; }
-  uint32_t incl = c;
-  const int lane = threadIdx.x & 63;
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) wsum[threadIdx.x >> 6] = incl;
-  __syncthreads();
-  uint32_t woffs = 0;
-  for (int i = 0; i < (int)(threadIdx.x >> 6); i++) woffs += wsum[i];
-  uint32_t o = bscan[blockIdx.x] + woffs + incl - c;
+  const size_t tile0 = (size_t)blockIdx.x * kRleTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  uint64_t k[kRleItems];
+  uint32_t lp[kRleItems], flags = 0;
 #pragma unroll
   for (int i = 0; i < kRleItems; i++) {
-    if (flags & (1u << i)) {
-      uniq[o] = keys[base + i];
-      if (key2) uniq2[o] = key2[base + i] >> sh2;
-      starts[o] = (uint32_t)(base + i);
-      o++;
+    const size_t idx = tile0 + (size_t)i * kRleThreads + threadIdx.x;
+    const bool in = idx < n;
+    k[i] = in ? keys[idx] : 0;
+    const bool head = in && is_head(keys, key2, sh2, idx);
+    const uint64_t ball = __ballot(head);
+    lp[i] = (uint32_t)__popcll(ball & below);
+    if (head) flags |= 1u << i;
+    if (lane == 0) wcnt[i * NW + wave] = (uint32_t)__popcll(ball);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                                  // exclusive scan of the kRleItems * NW counts, row-major
+    const uint32_t v = threadIdx.x < kRleItems * NW ? wcnt[threadIdx.x] : 0;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off);
+      if (lane >= off) incl += u;
     }
-    if (rank_out && base + i < n) rank_out[origin[base + i]] = o - 1;
-    if (runid_out && base + i < n) runid_out[base + i] = o - 1;     // the same by sorted position
+    if (threadIdx.x < kRleItems * NW) wcnt[threadIdx.x] = incl - v;
+  }
+  __syncthreads();
+  const uint32_t o0 = bscan[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kRleItems; i++) {
+    const size_t idx = tile0 + (size_t)i * kRleThreads + threadIdx.x;
+    if (idx >= n) continue;
+    const bool head = (flags >> i) & 1u;
+    const uint32_t o = o0 + wcnt[i * NW + wave] + lp[i];   // heads before this item
+    if (head) {
+      uniq[o] = k[i];
+      if (key2) uniq2[o] = key2[idx] >> sh2;
+      starts[o] = (uint32_t)idx;
+    }
+    const uint32_t run = o + (head ? 1u : 0u) - 1u;        // the run this item belongs to
+    if (rank_out) rank_out[origin[idx]] = run;
+    if (runid_out) runid_out[idx] = run;                   // the same by sorted position
   }
 }
 

@@ -32,6 +32,16 @@ constexpr int ITERS = 2048;
 #define I_MAD_U32_U24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %8\n"
 #define I_LSHRREV(n) "v_lshrrev_b32 %" #n ", 3, %" #n "\n"
 #define I_AND_OR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %8\n"
+#define I_XOR_LIT(n) "v_xor_b32 %" #n ", 0x12345679, %" #n "\n"
+#define I_ADD_INL(n) "v_add_u32 %" #n ", 7, %" #n "\n"
+#define I_XOR_S(n) "v_xor_b32 %" #n ", %9, %" #n "\n"
+#define I_SDWA(n) "v_lshlrev_b32_sdwa %" #n ", 3, %" #n " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_ALIGNBYTE(n) "v_alignbyte_b32 %" #n ", %" #n ", %8, 1\n"
+#define I_CMP(n) "v_cmp_lt_u32 vcc, %" #n ", %8\n"
+#define I_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define I_ADDCO(n) "v_add_co_u32 %" #n ", vcc, %" #n ", %8\n"
+#define I_ADDC(n) "v_addc_co_u32 %" #n ", vcc, %" #n ", %8, vcc\n"
+#define I_AND_LIT(n) "v_and_b32 %" #n ", 0xDFDFDFDF, %" #n "\n"
 
 template <int OP>
 __global__ __launch_bounds__(256) void k32(uint32_t* out, uint32_t b, uint32_t c) {
@@ -54,6 +64,16 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, uint32_t b, uint32_t c
   if (OP == 16) BODY8(I_MAD_U32_U24)
   if (OP == 17) BODY8(I_LSHRREV)
   if (OP == 18) BODY8(I_AND_OR)
+  if (OP == 19) BODY8(I_XOR_LIT)
+  if (OP == 20) BODY8(I_ADD_INL)
+  if (OP == 21) BODY8(I_XOR_S)
+  if (OP == 22) BODY8(I_SDWA)
+  if (OP == 23) BODY8(I_ALIGNBYTE)
+  if (OP == 24) BODY8(I_CMP)
+  if (OP == 25) BODY8(I_MOV)
+  if (OP == 26) BODY8(I_ADDCO)
+  if (OP == 27) BODY8(I_ADDC)
+  if (OP == 28) BODY8(I_AND_LIT)
   uint32_t r = 0;
   for (int i = 0; i < 8; i++) r ^= a[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
@@ -69,6 +89,11 @@ __global__ __launch_bounds__(256) void k32(uint32_t* out, uint32_t b, uint32_t c
 #define J_LSHLADD64(n) "v_lshl_add_u64 %" #n ", %" #n ", 2, %6\n"
 #define J_SHL64(n) "v_lshlrev_b64 %" #n ", 3, %" #n "\n"
 #define J_SHR64(n) "v_lshrrev_b64 %" #n ", 3, %" #n "\n"
+#define J_MAD64_V(n) "v_mad_u64_u32 %" #n ", vcc, %4, %4, %" #n "\n"
+#define J_MAD64_0(n) "v_mad_u64_u32 %" #n ", vcc, %4, %5, 0\n"
+#define J_MAD64_V0(n) "v_mad_u64_u32 %" #n ", vcc, %4, %4, 0\n"
+#define J_MOV64(n) "v_mov_b64 %" #n ", %6\n"
+#define J_LSHLADD64_0(n) "v_lshl_add_u64 %" #n ", %" #n ", 0, %6\n"
 
 template <int OP>
 __global__ __launch_bounds__(256) void k64(uint64_t* out, uint32_t b, uint32_t c, uint64_t d) {
@@ -78,6 +103,11 @@ __global__ __launch_bounds__(256) void k64(uint64_t* out, uint32_t b, uint32_t c
   if (OP == 1) BODY4_64(J_LSHLADD64)
   if (OP == 2) BODY4_64(J_SHL64)
   if (OP == 3) BODY4_64(J_SHR64)
+  if (OP == 4) BODY4_64(J_MAD64_V)
+  if (OP == 5) BODY4_64(J_MAD64_0)
+  if (OP == 6) BODY4_64(J_MAD64_V0)
+  if (OP == 7) BODY4_64(J_MOV64)
+  if (OP == 8) BODY4_64(J_LSHLADD64_0)
   out[blockIdx.x * blockDim.x + threadIdx.x] = a[0] ^ a[1] ^ a[2] ^ a[3];
 }
 
@@ -107,6 +137,9 @@ int main() {
   RUN32(4, "v_alignbit_b32") RUN32(5, "v_add3_u32") RUN32(6, "v_lshl_add_u32") RUN32(7, "v_bfe_u32") RUN32(8, "v_perm_b32") RUN32(9, "v_cndmask_b32")
   RUN32(11, "mul_lo v,v,v") RUN32(12, "v_add_u32 sgpr") RUN32(15, "v_add_u32_e64")
   RUN32(16, "v_mad_u32_u24") RUN32(17, "v_lshrrev_b32") RUN32(18, "v_and_or_b32")
+  RUN32(19, "v_xor_b32 literal") RUN32(28, "v_and_b32 literal") RUN32(20, "v_add_u32 inline7") RUN32(21, "v_xor_b32 sgpr") RUN32(22, "v_lshlrev_sdwa")
+  RUN32(23, "v_alignbyte_b32") RUN32(24, "v_cmp_lt_u32 vcc") RUN32(25, "v_mov_b32") RUN32(26, "v_add_co_u32") RUN32(27, "v_addc_co_u32")
   RUN64(0, "v_mad_u64_u32") RUN64(1, "v_lshl_add_u64") RUN64(2, "v_lshlrev_b64") RUN64(3, "v_lshrrev_b64")
+  RUN64(4, "mad_u64 v,v,v64") RUN64(5, "mad_u64 v,s,0") RUN64(6, "mad_u64 v,v,0") RUN64(7, "v_mov_b64") RUN64(8, "lshl_add_u64 sh0")
   return 0;
 }

@@ -31,6 +31,9 @@ def main():
             continue
         op = l.split()[0]
         if op == "s_cbranch_execz":
+            if l.split()[1] == label:     # a skipped rare block that ends the iteration
+                cnt["salu"] += 1
+                break
             i = labels[l.split()[1]] + 1
             cnt["salu"] += 1
             continue
