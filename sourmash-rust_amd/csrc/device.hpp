@@ -80,6 +80,8 @@ class Device {
 
   // scratch shared by the fold / sort primitives (guarded by mutex())
   DeviceBuffer scratch;
+  // per-tile record numbers of the running sketch launch (guarded by mutex(); see k_tile_records)
+  DeviceBuffer tile_rec;
 
   // HIP-event timing of named kernels (enabled by smh_profile_enable)
   void profile_enable(bool on);

@@ -29,6 +29,9 @@ struct SeqBatch {
   const uint64_t* vends = nullptr;
   uint32_t nrec = 1;
   uint64_t vend0 = 0;
+  // set by the launchers of the tiled kernels: the record that holds the first position of every tile
+  // of the launch, plus one entry for the position past the last tile (see k_tile_records)
+  const uint32_t* tile_rec = nullptr;
 };
 
 struct HashParams {

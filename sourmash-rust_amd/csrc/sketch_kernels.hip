@@ -141,6 +141,26 @@ __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ sta
   return lo;
 }
 
+// The tiled kernels need, per lane, the record its run starts in.  A binary search over all record starts is ~log2(nrec)
+// DEPENDENT global loads that every lane of a workgroup waits for at the top of every tile (14 at 10 000 records:
+// a tenth of the tile's time).  One tiny launch looks up the record of every TILE's first position instead; a lane then
+// searches only between its tile's entry and the next one (no step at all while records are longer than tiles).
+__global__ __launch_bounds__(256) void k_tile_records(const uint64_t* __restrict__ starts, uint32_t nrec, uint64_t base,
+                                                      uint64_t tile, uint64_t ntiles, uint32_t* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= ntiles) out[t] = find_record(starts, nrec, base + t * tile);
+}
+// record of position p, known to lie in tile `tix` of the launch
+__device__ __forceinline__ uint32_t find_record_in_tile(const SeqBatch& b, uint64_t tix, uint64_t p) {
+  if (!b.tile_rec) return find_record(b.starts, b.nrec, p);
+  uint32_t lo = b.tile_rec[tix], hi = b.tile_rec[tix + 1] + 1;   // answer in [lo, hi)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (b.starts[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
 
 // ---------------------------------------------------------------------------------
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     uint32_t rec = 0;
     uint64_t cur_end = b.vend0;
     if (multi) {
-      rec = find_record(b.starts, b.nrec, p0);
+      rec = find_record_in_tile(b, tix, p0);
       cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
       if (PR) lthr = hp.thr_rec[rec];
     }
@@ -1004,10 +1024,11 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
 
     uint32_t rec = 0;
     uint64_t cur_end = b.vend0;
-    if (multi) { rec = find_record(b.starts, b.nrec, p0); cur_end = valid_end(rec); }
+    if (multi) { rec = find_record_in_tile(b, tix, p0); cur_end = valid_end(rec); }
     uint32_t lim = 0;
     if (cur_end > p0) lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
-    uint32_t vstart = 0;
+    uint32_t vstart = 0;                                  // first base index after the last record start / dropped base
+    uint32_t rstart = 0;                                  // first base index of the record the walk is in
     uint32_t g_lo = 0, g_span = 0;
     auto set_clean_window = [&](bool warm) {
       const uint32_t lim2 = warm ? lim : (lim < hi_ok ? lim : hi_ok);
@@ -1069,7 +1090,7 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
           if (i >= lim) {
             const uint64_t qpos = p0 + i;
             if (multi) {
-              while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vstart = i; }
+              while (rec + 1 < b.nrec && qpos >= b.starts[rec + 1]) { rec++; vstart = i; rstart = i; }
               cur_end = valid_end(rec);
             }
             if (qpos >= cur_end) { bad = 1; lim = i + 1; }
@@ -1080,7 +1101,11 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
             const bool inrun = i + 1 >= (uint32_t)KB && i < hi_ok;
             const bool simple = inrun && (i + 1 >= vstart + (uint32_t)KB);
             okmask |= simple ? (1u << q) : 0u;
-            slowmask |= (inrun && !simple) ? (1u << q) : 0u;
+            // A span that is not clean goes to the codon-by-codon walk -- unless it STARTS in an earlier record than
+            // this base: its record then ends before 3W bases are through, and no window starts there.  (Every record
+            // boundary makes 3W - 1 such spans; sending them through the walk cost a tenth of the kernel's time at
+            // one boundary per 1 MB.)
+            slowmask |= (inrun && !simple && i + 1 >= rstart + (uint32_t)KB) ? (1u << q) : 0u;
           }
         }
         set_clean_window(!kHash);
@@ -1405,11 +1430,21 @@ static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSin
 #undef SMH_LAUNCH
 }
 
-void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sink, Device& dev,
+// the batch with its per-tile record table (k_tile_records) for a launch of `ntiles` tiles from position `base`
+static SeqBatch with_tile_records(const SeqBatch& b, uint64_t base, uint64_t tile, uint64_t ntiles, Device& dev, hipStream_t s) {
+  SeqBatch r = b;
+  if (!b.starts || b.nrec < 2) return r;
+  dev.tile_rec.ensure((size_t)(ntiles + 1) * sizeof(uint32_t));
+  hipLaunchKernelGGL(k_tile_records, dim3((unsigned)((ntiles + 1 + 255) / 256)), dim3(256), 0, s, b.starts, b.nrec, base, tile,
+                     ntiles, dev.tile_rec.as<uint32_t>());
+  r.tile_rec = dev.tile_rec.as<uint32_t>();
+  return r;
+}
+
+void launch_dna_hash(const SeqBatch& b_in, const HashParams& p, const CandSink& sink, Device& dev,
                      hipStream_t s, bool force_generic) {
   if (p.range_hi <= p.range_lo) return;
   const uint64_t span = p.range_hi - p.range_lo;
-  dev.prof_begin(s);
   if (p.ksize >= 1 && p.ksize <= 128 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
@@ -1418,6 +1453,8 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * c.threads * 2) logR--;
     const uint64_t tile = (uint64_t)c.threads << logR;
     const uint64_t ntiles = (span + tile - 1) / tile;
+    const SeqBatch b = with_tile_records(b_in, p.range_lo, tile, ntiles, dev, s);
+    dev.prof_begin(s);
     int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
     const int limbs = p.ksize <= 32 ? 2 : (p.ksize <= 64 ? 4 : 8);
     const uint32_t x_bytes = (uint32_t)tile + 16 * limbs + 96;
@@ -1438,8 +1475,9 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
     HIP_CHECK(hipGetLastError());
     dev.prof_end("dna_rolling", s);
   } else {
+    dev.prof_begin(s);
     hipLaunchKernelGGL(k_dna_generic, dim3(grid_for(span, 256, dev.cu_count() * 16)), dim3(256), 0, s,
-                       b, p, sink);
+                       b_in, p, sink);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("dna_generic", s);
   }
@@ -1460,14 +1498,14 @@ void launch_translate(const SeqBatch& b, const uint64_t* seg_off, uint32_t nseg,
   HIP_CHECK(hipGetLastError());
 }
 
-bool launch_protein_fused(const SeqBatch& b, const uint64_t* seg_offsets, uint32_t win, const HashParams& p,
+bool launch_protein_fused(const SeqBatch& b_in, const uint64_t* seg_offsets, uint32_t win, const HashParams& p,
                           const CandSink& sink, uint32_t* high_flag, Device& dev, hipStream_t s) {
-  if (b.len == 0) return true;
+  if (b_in.len == 0) return true;
   if (!(win == 7 || win == 9 || win == 10)) return false;     // the usual protein k-mer sizes (ksize 21 / 27 / 30)
   int logR = SMH_PF_LOGR;
-  while (logR > 5 && (b.len >> logR) < (uint64_t)dev.cu_count() * 512 * 2) logR--;
+  while (logR > 5 && (b_in.len >> logR) < (uint64_t)dev.cu_count() * 512 * 2) logR--;
   const uint64_t tile = 512ull << logR;
-  const uint64_t ntiles = (b.len + tile - 1) / tile;
+  const uint64_t ntiles = (b_in.len + tile - 1) / tile;
   const int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
   const uint32_t x_bytes = (uint32_t)tile + 3 * win + 12 + 96;
   // two windows per position pass with probability (thr + 1) / 2^64 each
@@ -1475,6 +1513,7 @@ bool launch_protein_fused(const SeqBatch& b, const uint64_t* seg_offsets, uint32
   uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
   if (stage_cap < 128) stage_cap = 128;
   const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes + 4 * ((x_bytes >> logR) + 2);
+  const SeqBatch b = with_tile_records(b_in, 0, tile, ntiles, dev, s);
 #define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap, high_flag)
   if (win == 7) SMH_PF(7); else if (win == 9) SMH_PF(9); else SMH_PF(10);
 #undef SMH_PF
