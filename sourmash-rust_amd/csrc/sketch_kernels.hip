@@ -176,7 +176,7 @@ __device__ __forceinline__ uint32_t upper(uint32_t c) { return (c >= 'a' && c <=
 // and never paid (1, 2: 37.8 ms; 4, 8: 39.7; 16: 50.5 per 10 GB) -- with one copy the entry address
 // is (digits << 3) plus an immediate, two full-rate instructions per group.
 constexpr int kLutEntries = 256 + 256 + 64 + 1;              // P1, P2, partial group, one zero entry (groups past the k-mer)
-constexpr int kLutDwords = kLutEntries * 2;                  // u64 entries: 4.5 KiB
+constexpr int kLutDwords = kLutEntries * 3;                  // u64 entries (4.5 KiB), then their low dwords once more, packed
 
 // The hash runs on explicit 32-bit halves.  Issue rates on gfx950 (tools/instr_rate.hip,
 // profiles/r01_instr_rates.txt): two-operand VALU forms ~100 lanes/clk/CU, everything with three
@@ -293,7 +293,7 @@ __device__ __forceinline__ void murmur_kmer_pre(const W2 (&M)[2 * L], int K, uin
 template <int KT, int THREADS, int HB, int L, bool PR = false>
 __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
                                                          int logR, uint32_t stage_cap) {
-  // LDS: static: the product tables (4.5 KiB; a compile-time address, so a table read is one
+  // LDS: static: the product tables (6.8 KiB; a compile-time address, so a table read is one
   // ds_read with the table's base as its immediate offset); dynamic: [staged candidates: count,
   // hashes, positions][sequence tile]
   __shared__ __attribute__((aligned(16))) uint32_t lut[kLutDwords];
@@ -330,7 +330,11 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     const int nb = ent < 512 ? 4 : (ent < 576 ? nb_last : 0);
     uint32_t v = 0;
     for (int j = 0; j < nb; j++) v |= ((0x54474341u >> (8 * ((idx >> (2 * j)) & 3))) & 0xffu) << (8 * j);
-    ptab[e] = (uint64_t)v * (ent < 256 ? kC1 : (ent < 512 ? kC2 : c_last));
+    const uint64_t prod = (uint64_t)v * (ent < 256 ? kC1 : (ent < 512 ? kC2 : c_last));
+    ptab[e] = prod;
+    // The high half of a word needs only the product's low dword.  Read out of the 8-byte entries those look-ups
+    // touch the even banks only; the packed copy spreads them over all 64 (SQ_LDS_BANK_CONFLICT 43 -> ... per 64 k-mers).
+    lut[2 * kLutEntries + e] = (uint32_t)prod;
   }
   // table base (bytes) of every 4-letter group: a compile-time constant for a compile-time k, fixed for
   // the launch otherwise, so that the per-k-mer code is the same straight line either way
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     uint32_t ent0 = 576u;                                              // past the k-mer: the zero entry
     if (nb >= 4) ent0 = ((g >> 1) & 1) ? 256u : 0u;
     else if (nb > 0) ent0 = 512u;
-    gbase[g] = ent0 * 8u;
+    gbase[g] = (g & 1) ? 8u * kLutEntries + ent0 * 4u : ent0 * 8u;   // odd groups (high halves): the packed low dwords
   }
   if (tid == 0) st_ctl[0] = 0;
 
@@ -519,11 +523,11 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
                 // rate on gfx950: 32.0 -> 30.8 ms per 10 GB).  No mask is needed, for any k: both windows are
                 // zero above their 2k bits, so a partial group indexes inside its 4^nb-entry table and a
                 // group past the k-mer reads entry 0 of the zero table.
-                uint32_t off;
+                uint32_t off;                                        // digits << 3 (8-byte entries) or << 2 (packed low dwords)
                 if ((g & 3) == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off) : "v"(xw));
-                else if ((g & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(xw));
+                else if ((g & 3) == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off) : "v"(xw));
                 else if ((g & 3) == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(xw));
-                else asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(xw));
+                else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off) : "v"(xw));
                 const char* at = reinterpret_cast<const char*>(lut) + gbase[g] + off;
                 if ((g & 1) == 0) {                                  // low half of the word: full product
                   const uint2 e = *reinterpret_cast<const uint2*>(at);
@@ -937,11 +941,10 @@ __device__ __forceinline__ void murmur_short(W2 k1c1, W2 k2, W2 seedw /* seed ^ 
 // byte BYTE of x, shifted left by SH, in one sub-dword-addressed instruction (full rate; see k_dna_rolling)
 template <int SH, int BYTE>
 __device__ __forceinline__ uint32_t byte_shl(uint32_t x) {
-  static_assert((SH == 3 || SH == 5) && BYTE >= 0 && BYTE < 4, "byte_shl");
+  static_assert(SH == 3 && BYTE >= 0 && BYTE < 4, "byte_shl");
   uint32_t r;
 #define SMH_BSHL(SH_, B_) asm("v_lshlrev_b32_sdwa %0, " #SH_ ", %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B_ : "=v"(r) : "v"(x))
-  if (SH == 3) { if (BYTE == 0) SMH_BSHL(3, 0); else if (BYTE == 1) SMH_BSHL(3, 1); else if (BYTE == 2) SMH_BSHL(3, 2); else SMH_BSHL(3, 3); }
-  else         { if (BYTE == 0) SMH_BSHL(5, 0); else if (BYTE == 1) SMH_BSHL(5, 1); else if (BYTE == 2) SMH_BSHL(5, 2); else SMH_BSHL(5, 3); }
+  if (BYTE == 0) SMH_BSHL(3, 0); else if (BYTE == 1) SMH_BSHL(3, 1); else if (BYTE == 2) SMH_BSHL(3, 2); else SMH_BSHL(3, 3);
 #undef SMH_BSHL
   return r;
 }
@@ -957,10 +960,11 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
                                                                           uint32_t stage_cap, uint32_t* __restrict__ high_flag) {
   constexpr int KB = 3 * W;                          // bases per window
   constexpr int ND = (W + 3) / 4;                    // dwords of a residue string
-  // static LDS: codon table, 32-byte entries -- codon number (its first base's digit lowest) -> { (residue of the
-  // reverse complement) * c1, W == 9: seed ^ mix_k2(residue) ^ W, residue | residue of the reverse complement << 8 } --
-  // and seed ^ mix_k2(byte) ^ W of any byte (W == 9: the reverse strand's k2 is a residue met eight codons earlier)
-  __shared__ __attribute__((aligned(16))) uint32_t ctab[64 * 8];
+  // static LDS: codon tables -- codon number (its first base's digit lowest) -> (residue of the reverse complement) * c1 |
+  // W == 9: seed ^ mix_k2(residue) ^ W | residue + residue of the reverse complement << 8 -- as three arrays of 8-byte
+  // entries read with ONE offset register (32-byte records would put every look-up of a wave on eight banks), and
+  // seed ^ mix_k2(byte) ^ W of any byte (W == 9: the reverse strand's k2 is a residue met eight codons earlier)
+  __shared__ uint64_t ctab[3 * 64];
   __shared__ uint64_t k2tab[W == 9 ? 256 : 1];
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* st_ctl = smem;
@@ -977,9 +981,7 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
     const int d0 = tid & 3, d1 = (tid >> 2) & 3, d2 = (tid >> 4) & 3;
     const uint32_t af = aa_of_digits(d0, d1, d2), ar = aa_of_digits(3 - d2, 3 - d1, 3 - d0);
     const uint64_t arc1 = (uint64_t)ar * kC1, h2f = hp.seed ^ mix_k2((uint64_t)af) ^ (uint64_t)W;
-    ctab[8 * tid] = (uint32_t)arc1; ctab[8 * tid + 1] = (uint32_t)(arc1 >> 32);
-    ctab[8 * tid + 2] = (uint32_t)h2f; ctab[8 * tid + 3] = (uint32_t)(h2f >> 32);
-    ctab[8 * tid + 4] = af | (ar << 8);
+    ctab[tid] = arc1; ctab[64 + tid] = h2f; ctab[128 + tid] = af | (ar << 8);
   }
   if (W == 9) for (int e = tid; e < 256; e += THREADS) k2tab[e] = hp.seed ^ mix_k2((uint64_t)e) ^ (uint64_t)W;
   if (tid == 0) st_ctl[0] = 0;
@@ -1121,11 +1123,11 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
       uint64_t et1[4], h2f[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const uint32_t off = (q & 1) ? byte_shl<5, 1>(q < 2 ? ix01 : ix23) : byte_shl<5, 0>(q < 2 ? ix01 : ix23);
+        const uint32_t off = (q & 1) ? byte_shl<3, 1>(q < 2 ? ix01 : ix23) : byte_shl<3, 0>(q < 2 ? ix01 : ix23);
         const char* at = reinterpret_cast<const char*>(ctab) + off;
         if (W >= 8) et1[q] = *reinterpret_cast<const uint64_t*>(at);
-        if (kHash && W == 9) h2f[q] = *reinterpret_cast<const uint64_t*>(at + 8);
-        eaa[q] = *reinterpret_cast<const uint32_t*>(at + 16);
+        if (kHash && W == 9) h2f[q] = *reinterpret_cast<const uint64_t*>(at + 512);
+        eaa[q] = *reinterpret_cast<const uint32_t*>(at + 1024);
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {

@@ -38,3 +38,5 @@ run("protein k=21 scaled=1000, 1 MB records", True, 21, MAXH, off, b"protein_fus
 run("protein k=30 scaled=1000, 1 MB records", True, 30, MAXH, off, b"protein_fused")
 run("DNA k=31 scaled=1000, 1 MB records", False, 31, MAXH, off, b"dna_rolling")
 run("DNA k=31 max_hash=1", False, 31, 1, off, b"dna_rolling")
+run("DNA k=31 scaled=1000, ONE record", False, 31, MAXH, one, b"dna_rolling")
+run("DNA k=21 scaled=1000, 1 MB records", False, 21, MAXH, off, b"dna_rolling")
