@@ -29,9 +29,15 @@ struct SeqBatch {
   const uint64_t* vends = nullptr;
   uint32_t nrec = 1;
   uint64_t vend0 = 0;
-  // set by the launchers of the tiled kernels: the record that holds the first position of every tile
-  // of the launch, plus one entry for the position past the last tile (see k_tile_records)
-  const uint32_t* tile_rec = nullptr;
+  // set by the launchers of the tiled kernels: per tile of the launch, the record that holds its first
+  // position (see k_tile_records)
+  const struct TileRec* tile_rec = nullptr;
+};
+
+struct TileRec {
+  uint32_t rec;    // record of the tile's first position
+  uint32_t last;   // record of the first position of the NEXT tile (== rec: the tile lies inside one record)
+  uint64_t end;    // end of the valid part of `rec`
 };
 
 struct HashParams {

@@ -141,23 +141,42 @@ __device__ __forceinline__ uint32_t find_record(const uint64_t* __restrict__ sta
   return lo;
 }
 
-// The tiled kernels need, per lane, the record its run starts in.  A binary search over all record starts is ~log2(nrec)
-// DEPENDENT global loads that every lane of a workgroup waits for at the top of every tile (14 at 10 000 records:
-// a tenth of the tile's time).  One tiny launch looks up the record of every TILE's first position instead; a lane then
-// searches only between its tile's entry and the next one (no step at all while records are longer than tiles).
-__global__ __launch_bounds__(256) void k_tile_records(const uint64_t* __restrict__ starts, uint32_t nrec, uint64_t base,
-                                                      uint64_t tile, uint64_t ntiles, uint32_t* __restrict__ out) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t <= ntiles) out[t] = find_record(starts, nrec, base + t * tile);
+// The tiled kernels need, per lane, the record its run starts in and where that record's valid part ends.  A binary
+// search over all record starts is ~log2(nrec) DEPENDENT global loads that every lane of a workgroup waits for at the
+// top of every tile (14 at 10 000 records: a tenth of the tile's time), and their misses show up as memory requests.
+// One tiny launch looks up the record of every TILE's first position instead, with its end; a lane reads its tile's
+// entry (one 16-byte load, the same for the whole workgroup) and is done when the tile lies inside one record; otherwise
+// it searches between the entry's two record numbers.
+// end of the valid part of record r: vends[r] when given (DNA arm, force=false); a record shorter than min_len adds
+// nothing (protein arm, src/lib.rs:257)
+__device__ __forceinline__ uint64_t record_valid_end(const uint64_t* __restrict__ starts, const uint64_t* __restrict__ vends,
+                                                     uint32_t min_len, uint32_t r) {
+  if (vends) return vends[r];
+  const uint64_t s0 = starts[r], s1 = starts[r + 1];
+  return (min_len && s1 - s0 < min_len) ? s0 : s1;
 }
-// record of position p, known to lie in tile `tix` of the launch
-__device__ __forceinline__ uint32_t find_record_in_tile(const SeqBatch& b, uint64_t tix, uint64_t p) {
-  if (!b.tile_rec) return find_record(b.starts, b.nrec, p);
-  uint32_t lo = b.tile_rec[tix], hi = b.tile_rec[tix + 1] + 1;   // answer in [lo, hi)
+__global__ __launch_bounds__(256) void k_tile_records(const uint64_t* __restrict__ starts, const uint64_t* __restrict__ vends,
+                                                      uint32_t nrec, uint32_t min_len, uint64_t base, uint64_t tile,
+                                                      uint64_t ntiles, TileRec* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const uint32_t r = find_record(starts, nrec, base + t * tile);
+  out[t] = TileRec{r, find_record(starts, nrec, base + (t + 1) * tile), record_valid_end(starts, vends, min_len, r)};
+}
+// record of position p, known to lie in tile `tix` of the launch, and the end of its valid part
+__device__ __forceinline__ uint32_t find_record_in_tile(const SeqBatch& b, uint32_t min_len, uint64_t tix, uint64_t p,
+                                                        uint64_t* end) {
+  uint32_t lo = 0, hi = b.nrec;                            // answer in [lo, hi)
+  if (b.tile_rec) {
+    const TileRec t = b.tile_rec[tix];
+    if (t.last == t.rec) { *end = t.end; return t.rec; }
+    lo = t.rec; hi = t.last + 1;
+  }
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
     if (b.starts[mid] <= p) lo = mid; else hi = mid;
   }
+  *end = record_valid_end(b.starts, b.vends, min_len, lo);
   return lo;
 }
 
@@ -391,8 +410,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     uint32_t rec = 0;
     uint64_t cur_end = b.vend0;
     if (multi) {
-      rec = find_record_in_tile(b, tix, p0);
-      cur_end = b.vends ? b.vends[rec] : b.starts[rec + 1];
+      rec = find_record_in_tile(b, 0, tix, p0, &cur_end);
       if (PR) lthr = hp.thr_rec[rec];
     }
     uint32_t lim = 0;
@@ -973,18 +991,18 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
   uint32_t* tile = reinterpret_cast<uint32_t*>(st_pos + (sink.pos ? stage_cap : 0));
   const Stage stage{st_ctl, st_hash, st_pos, stage_cap};
 
-  const int tid = threadIdx.x;
+  const int tid0 = threadIdx.x;
   const uint32_t R = 1u << logR;
   const uint64_t TILE = (uint64_t)THREADS << logR;
   const bool multi = b.starts != nullptr;
-  if (tid < 64) {
-    const int d0 = tid & 3, d1 = (tid >> 2) & 3, d2 = (tid >> 4) & 3;
+  if (tid0 < 64) {
+    const int d0 = tid0 & 3, d1 = (tid0 >> 2) & 3, d2 = (tid0 >> 4) & 3;
     const uint32_t af = aa_of_digits(d0, d1, d2), ar = aa_of_digits(3 - d2, 3 - d1, 3 - d0);
     const uint64_t arc1 = (uint64_t)ar * kC1, h2f = hp.seed ^ mix_k2((uint64_t)af) ^ (uint64_t)W;
-    ctab[tid] = arc1; ctab[64 + tid] = h2f; ctab[128 + tid] = af | (ar << 8);
+    ctab[tid0] = arc1; ctab[64 + tid0] = h2f; ctab[128 + tid0] = af | (ar << 8);
   }
-  if (W == 9) for (int e = tid; e < 256; e += THREADS) k2tab[e] = hp.seed ^ mix_k2((uint64_t)e) ^ (uint64_t)W;
-  if (tid == 0) st_ctl[0] = 0;
+  if (W == 9) for (int e = tid0; e < 256; e += THREADS) k2tab[e] = hp.seed ^ mix_k2((uint64_t)e) ^ (uint64_t)W;
+  if (tid0 == 0) st_ctl[0] = 0;
 
   const uint32_t thr_hi1 = open_thr(hp.thr);
   W2 seedw{(uint32_t)hp.seed ^ (uint32_t)W, (uint32_t)(hp.seed >> 32)};   // in vector registers: see k_dna_rolling
@@ -1000,6 +1018,12 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
   };
 
   for (uint64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    // The lane number, re-read per tile behind an opaque asm: the compiler otherwise computes tid << logR and friends
+    // once, ahead of this loop, and -- the main loop holding every register -- spills them; their reload at every tile
+    // came from memory (the streamed input evicts the scratch lines from the L2 in between): 11 % more bytes fetched
+    // than the input holds, 26 % for W = 10 (TCC_EA0_RDREQ, profiles/r02_ea_read_requests.txt).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const uint64_t T0 = tix * TILE;
     const uintptr_t g0 = (uintptr_t)(b.seq + T0);
     const uintptr_t ga = g0 & ~(uintptr_t)15;
@@ -1026,7 +1050,7 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
 
     uint32_t rec = 0;
     uint64_t cur_end = b.vend0;
-    if (multi) { rec = find_record_in_tile(b, tix, p0); cur_end = valid_end(rec); }
+    if (multi) rec = find_record_in_tile(b, hp.ksize, tix, p0, &cur_end);
     uint32_t lim = 0;
     if (cur_end > p0) lim = (cur_end - p0) > 0xfffffffeull ? 0xffffffffu : (uint32_t)(cur_end - p0);
     uint32_t vstart = 0;                                  // first base index after the last record start / dropped base
@@ -1433,13 +1457,14 @@ static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSin
 }
 
 // the batch with its per-tile record table (k_tile_records) for a launch of `ntiles` tiles from position `base`
-static SeqBatch with_tile_records(const SeqBatch& b, uint64_t base, uint64_t tile, uint64_t ntiles, Device& dev, hipStream_t s) {
+static SeqBatch with_tile_records(const SeqBatch& b, uint32_t min_len, uint64_t base, uint64_t tile, uint64_t ntiles, Device& dev,
+                                  hipStream_t s) {
   SeqBatch r = b;
   if (!b.starts || b.nrec < 2) return r;
-  dev.tile_rec.ensure((size_t)(ntiles + 1) * sizeof(uint32_t));
-  hipLaunchKernelGGL(k_tile_records, dim3((unsigned)((ntiles + 1 + 255) / 256)), dim3(256), 0, s, b.starts, b.nrec, base, tile,
-                     ntiles, dev.tile_rec.as<uint32_t>());
-  r.tile_rec = dev.tile_rec.as<uint32_t>();
+  dev.tile_rec.ensure((size_t)ntiles * sizeof(TileRec));
+  hipLaunchKernelGGL(k_tile_records, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, b.starts, b.vends, b.nrec, min_len, base,
+                     tile, ntiles, dev.tile_rec.as<TileRec>());
+  r.tile_rec = dev.tile_rec.as<TileRec>();
   return r;
 }
 
@@ -1455,7 +1480,7 @@ void launch_dna_hash(const SeqBatch& b_in, const HashParams& p, const CandSink& 
     while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * c.threads * 2) logR--;
     const uint64_t tile = (uint64_t)c.threads << logR;
     const uint64_t ntiles = (span + tile - 1) / tile;
-    const SeqBatch b = with_tile_records(b_in, p.range_lo, tile, ntiles, dev, s);
+    const SeqBatch b = with_tile_records(b_in, 0, p.range_lo, tile, ntiles, dev, s);
     dev.prof_begin(s);
     int grid = (int)(ntiles < (uint64_t)dev.cu_count() * 8 ? ntiles : (uint64_t)dev.cu_count() * 8);
     const int limbs = p.ksize <= 32 ? 2 : (p.ksize <= 64 ? 4 : 8);
@@ -1515,7 +1540,7 @@ bool launch_protein_fused(const SeqBatch& b_in, const uint64_t* seg_offsets, uin
   uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
   if (stage_cap < 128) stage_cap = 128;
   const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes + 4 * ((x_bytes >> logR) + 2);
-  const SeqBatch b = with_tile_records(b_in, 0, tile, ntiles, dev, s);
+  const SeqBatch b = with_tile_records(b_in, p.ksize, 0, tile, ntiles, dev, s);
 #define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap, high_flag)
   if (win == 7) SMH_PF(7); else if (win == 9) SMH_PF(9); else SMH_PF(10);
 #undef SMH_PF

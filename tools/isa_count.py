@@ -3,7 +3,9 @@
 `s_cbranch_execz` is TAKEN (rare per-lane blocks are skipped) and every other conditional branch
 falls through, until the back-edge.  Classes follow the issue rates measured by tools/instr_rate.hip
 (profiles/r01_instr_rates.txt): full-rate VALU (VOP1/VOP2 2-operand forms), half-rate VALU
-(VOP3 3-operand forms, 32-bit multiplies, v_mad_u64_u32, 64-bit shifts), LDS, SALU, other.
+(VOP3 3-operand forms, 32-bit multiplies, v_mad_u64_u32, 64-bit forms, compares and carries through VCC,
+v_cndmask, SDWA forms, and any plain form with a scalar-register operand -- profiles/r02_instr_rates.txt), LDS,
+SALU, other.
 Usage: python tools/isa_count.py kernel.s LOOP_LABEL"""
 import re
 import sys
@@ -11,7 +13,13 @@ from collections import Counter
 
 HALF = re.compile(r"^v_(mul_lo_u32|mul_hi_u32|mad_u64_u32|mad_u32_u24|mul_u32_u24|alignbit_b32|alignbyte_b32|perm_b32|bfe_u32|"
                   r"and_or_b32|add3_u32|lshl_add_u32|lshl_or_b32|or3_b32|xad_u32|lshl_add_u64|lshlrev_b64|lshrrev_b64|"
-                  r"xor3_b32|bfi_b32|add_lshl_u32|cndmask_b32_e64|mad_i32_i24|mul_i32_i24|mul_hi_i32)")
+                  r"xor3_b32|bfi_b32|add_lshl_u32|cndmask_b32|mad_i32_i24|mul_i32_i24|mul_hi_i32|mov_b64|cmp_|add_co_|addc_co_|"
+                  r"sub_co_|subb_co_|subrev_co_|bitop3_b32)")
+SCALAR_OPERAND = re.compile(r"(^|[ ,\[])(s\d+|s\[\d+:\d+\]|vcc|exec)\b")
+
+
+def is_half(op, line):
+    return bool(HALF.match(op)) or "_sdwa" in op or bool(SCALAR_OPERAND.search(line[len(op):]))
 
 
 def main():
@@ -52,7 +60,7 @@ def main():
             continue
         ops[op] += 1
         if op.startswith("v_"):
-            cnt["valu_half" if HALF.match(op) else "valu_full"] += 1
+            cnt["valu_half" if is_half(op, l) else "valu_full"] += 1
         elif op.startswith("ds_"):
             cnt["lds"] += 1
         elif op.startswith("s_"):
