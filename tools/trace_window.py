@@ -13,7 +13,7 @@ prev_end = t0
 tot = 0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("smh::(anonymous namespace)::", "").replace("void ", "")[:60]
+    name = r["Kernel_Name"].replace("smh::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
     print("%10.1f us  %9.1f us  gap %8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name))
     prev_end = e
     tot += e - s
