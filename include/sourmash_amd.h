@@ -123,6 +123,12 @@ int smh_index_compare(SmhIndex *rows, SmhIndex *cols, double *jaccard, uint64_t 
 int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every,
                       void *stream);
 
+/* The fold's sort on its own (diagnostic entry point for the parity tests): sorts `n` keys in host memory in place,
+ * stably, carrying `payload` (n 32-bit values, or NULL) along -- on the device, through the same code as the sketch
+ * fold and the compare pre-pass.  hashed_keys != 0 selects the path for hash values (16 most significant bits by
+ * radix passes, the rest per bucket in LDS); the result is the same either way. */
+int smh_sort_u64(uint64_t *keys, uint32_t *payload, uintptr_t n, int hashed_keys);
+
 /* Which kernel serves an N x M compare block is chosen from the block's shape (a wavefront per
  * pair, a few-against-many stream, a per-component pair kernel, the tiled matrix kernel).  The
  * choice NEVER changes a result.  It can be pinned: the parity tests run every route over the same

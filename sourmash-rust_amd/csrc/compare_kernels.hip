@@ -1084,9 +1084,10 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
   }
   hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint32_t>(), n);
-  // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
+  // hashes are uniform 64-bit values: every byte differs (no histogram read-back), and the sort may finish the
+  // buckets of the 16 most significant bits in LDS instead of running all eight passes
   int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), n,
-                               dev.scratch, s, 0xffu);
+                               dev.scratch, s, 0xffu, true);
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
 

@@ -748,6 +748,27 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
   });
 }
 
+int smh_sort_u64(uint64_t* keys, uint32_t* payload, uintptr_t n, int hashed_keys) {
+  return pad_code([&] {
+    if (n == 0) return;
+    require(keys, "keys");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.stream();
+    smh::DeviceBuffer k[2], v[2];
+    for (int i = 0; i < 2; i++) { k[i].ensure(n * 8); if (payload) v[i].ensure(n * 4); }
+    HIP_CHECK(hipMemcpyAsync(k[0].ptr, keys, n * 8, hipMemcpyHostToDevice, s));
+    if (payload) HIP_CHECK(hipMemcpyAsync(v[0].ptr, payload, n * 4, hipMemcpyHostToDevice, s));
+    int cur;
+    if (payload) cur = smh::radix_sort_u64_v32(k[0].as<uint64_t>(), k[1].as<uint64_t>(), v[0].as<uint32_t>(), v[1].as<uint32_t>(), n,
+                                               dev.scratch, s, 0, hashed_keys != 0);
+    else cur = smh::radix_sort_u64(k[0].as<uint64_t>(), k[1].as<uint64_t>(), nullptr, nullptr, n, dev.scratch, s, 0, 8, hashed_keys != 0);
+    HIP_CHECK(hipMemcpyAsync(keys, k[cur].ptr, n * 8, hipMemcpyDeviceToHost, s));
+    if (payload) HIP_CHECK(hipMemcpyAsync(payload, v[cur].ptr, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
 void smh_compare_last_stats(SmhCompareStats* out) {
   if (!out) return;
   const smh::CompareStats st = smh::compare_last_stats();

@@ -1,0 +1,68 @@
+"""The fold's sort on its own (smh_sort_u64): radix passes and the hashed-key path (two passes over the most
+significant bits, buckets finished in LDS, oversized buckets set aside) against numpy's stable sort.  Covers the
+inputs that make buckets large: repeated keys, keys that share their high bits, constant high bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(pkg, keys, payload, hashed):
+    k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    p = None if payload is None else np.ascontiguousarray(payload, dtype=np.uint32).copy()
+    rc = pkg.lib().smh_sort_u64(k.ctypes.data_as(C.c_void_p), None if p is None else p.ctypes.data_as(C.c_void_p), k.size, int(hashed))
+    assert rc == 0
+    return k, p
+
+
+def _check(pkg, keys):
+    keys = np.asarray(keys, dtype=np.uint64)
+    order = np.argsort(keys, kind="stable")
+    want = keys[order]
+    for hashed in (1, 0):
+        k, _ = _sort(pkg, keys, None, hashed)
+        assert np.array_equal(k, want), "keys only, hashed=%d" % hashed
+        k, p = _sort(pkg, keys, np.arange(keys.size, dtype=np.uint32), hashed)
+        assert np.array_equal(k, want), "keys with payload, hashed=%d" % hashed
+        assert np.array_equal(p, order.astype(np.uint32)), "payload order (stability), hashed=%d" % hashed
+
+
+@pytest.mark.parametrize("n", [2, 4096, 4097, 65535, 65536, 300_000, 3_000_000])
+def test_uniform_keys(pkg, n):
+    rng = np.random.default_rng(n)
+    _check(pkg, rng.integers(0, 2**64, size=n, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("n", [70_000, 1_000_000])
+def test_keys_under_a_scaled_threshold(pkg, n):
+    rng = np.random.default_rng(n + 1)
+    _check(pkg, rng.integers(0, 18446744073709552, size=n, dtype=np.uint64))   # max_hash of scaled=1000: 55 bits
+
+
+def test_repeated_keys_make_big_equal_buckets(pkg):
+    rng = np.random.default_rng(7)
+    distinct = rng.integers(0, 2**64, size=300, dtype=np.uint64)
+    _check(pkg, distinct[rng.integers(0, distinct.size, size=400_000)])          # ~1300 copies of each key
+    _check(pkg, np.full(10_000, 0x123456789ABCDEF0, dtype=np.uint64))            # one key: nothing to sort
+
+
+def test_keys_that_share_their_high_bits(pkg):
+    rng = np.random.default_rng(8)
+    low = rng.integers(0, 2**48, size=100_000, dtype=np.uint64)
+    _check(pkg, (np.uint64(0x5A5A) << np.uint64(48)) | low)                      # ONE bucket of 100 000 different keys
+    # a uniform background, one bucket of 5 000 different keys, one run of 2 000 equal keys
+    bg = rng.integers(0, 2**64, size=200_000, dtype=np.uint64)
+    heavy = (np.uint64(0x0123) << np.uint64(48)) | rng.integers(0, 2**48, size=5_000, dtype=np.uint64)
+    run = np.full(2_000, 0xFEDC_0000_0000_0001, dtype=np.uint64)
+    mix = np.concatenate([bg, heavy, run])
+    rng.shuffle(mix)
+    _check(pkg, mix)
+
+
+def test_constant_high_byte_and_short_keys(pkg):
+    rng = np.random.default_rng(9)
+    _check(pkg, (np.uint64(0xAB) << np.uint64(56)) | rng.integers(0, 2**40, size=150_000, dtype=np.uint64))
+    _check(pkg, rng.integers(0, 2**20, size=150_000, dtype=np.uint64))           # 20-bit keys, many repeats
+    _check(pkg, rng.integers(0, 2**33, size=150_000, dtype=np.uint64))
