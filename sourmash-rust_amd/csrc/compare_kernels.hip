@@ -1087,7 +1087,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // hashes are uniform 64-bit values: every byte differs (no histogram read-back), and the sort may finish the
   // buckets of the 16 most significant bits in LDS instead of running all eight passes
   int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), n,
-                               dev.scratch, s, 0xffu, true);
+                               dev.scratch, s, 0xffu, kHashedPooled);
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
 

@@ -21,7 +21,7 @@ def _check(pkg, keys):
     keys = np.asarray(keys, dtype=np.uint64)
     order = np.argsort(keys, kind="stable")
     want = keys[order]
-    for hashed in (1, 0):
+    for hashed in (1, 2, 0):
         k, _ = _sort(pkg, keys, None, hashed)
         assert np.array_equal(k, want), "keys only, hashed=%d" % hashed
         k, p = _sort(pkg, keys, np.arange(keys.size, dtype=np.uint32), hashed)
