@@ -491,15 +491,28 @@ __global__ __launch_bounds__(64) void k_long_runs(uint64_t* __restrict__ keys, v
   for (uint32_t e = blockIdx.x; e < nlong; e += gridDim.x) {
     const uint32_t s = long_list[e];
     const uint64_t f = keys[s] >> sh;
-    // the run's length and whether it is in order already, 64 keys at a time
+    // the run's length and whether it is in order already, 256 keys at a time (a k-mer repeated a million times is
+    // a run of a million equal keys: the loads of a step are independent, so that they overlap)
     uint32_t len = 0;
-    bool bad = false;
-    for (uint32_t base = s;; base += 64) {
-      const uint32_t j = base + lane;
-      const bool in = j < n && (keys[j] >> sh) == f;
-      bad = bad || (in && j > s && keys[j - 1] > keys[j]);
-      const uint64_t m_in = __ballot(in);
-      if (m_in != ~0ull) { len = base - s + (uint32_t)__popcll(m_in); break; }   // (the fields are sorted: `in` is a prefix)
+    bool bad = false, done = false;
+    for (uint32_t base = s; !done; base += 256) {
+      uint64_t kc[4], kp[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t j = base + 64u * r + lane;
+        kc[r] = j < n ? keys[j] : 0;
+        kp[r] = (j < n && j > s) ? keys[j - 1] : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t j = base + 64u * r + lane;
+        const bool in = j < n && (kc[r] >> sh) == f;
+        const uint64_t m_in = __ballot(in);                   // (the fields are sorted: `in` is a prefix of the run's tail)
+        if (!done) {
+          bad = bad || (in && j > s && kp[r] > kc[r]);
+          if (m_in != ~0ull) { len = base - s + 64u * r + (uint32_t)__popcll(m_in); done = true; }
+        }
+      }
     }
     if (!__any(bad)) continue;
     if (len > (uint32_t)kBucketCap) {

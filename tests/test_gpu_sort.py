@@ -66,3 +66,11 @@ def test_constant_high_byte_and_short_keys(pkg):
     _check(pkg, (np.uint64(0xAB) << np.uint64(56)) | rng.integers(0, 2**40, size=150_000, dtype=np.uint64))
     _check(pkg, rng.integers(0, 2**20, size=150_000, dtype=np.uint64))           # 20-bit keys, many repeats
     _check(pkg, rng.integers(0, 2**33, size=150_000, dtype=np.uint64))
+
+
+def test_one_key_repeated_a_million_times_among_distinct_ones(pkg):
+    rng = np.random.default_rng(10)
+    keys = np.concatenate([rng.integers(0, 2**55, size=500_000, dtype=np.uint64), np.full(1_000_000, 0x0012_3456_789A_BCDE, dtype=np.uint64),
+                           np.full(70, 0x0000_0000_0000_0007, dtype=np.uint64)])
+    rng.shuffle(keys)
+    _check(pkg, keys)
