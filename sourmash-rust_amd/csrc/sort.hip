@@ -563,7 +563,6 @@ __global__ __launch_bounds__(256) void k_big_buckets(uint64_t* __restrict__ b0, 
       __syncthreads();
       // exclusive offsets in (digit, thread) order
       uint32_t off[16];
-      uint32_t tot[16];
       for (int d = 0; d < 16; d++) {
         const uint32_t v = cnt[d][t];
         uint32_t incl = v;
@@ -580,10 +579,8 @@ __global__ __launch_bounds__(256) void k_big_buckets(uint64_t* __restrict__ b0, 
         uint32_t before = 0, all = 0;
         for (int ww = 0; ww < 4; ww++) { if (ww < w) before += wtot[d][ww]; all += wtot[d][ww]; }
         off[d] += base + before;
-        tot[d] = all;
         base += all;
       }
-      (void)tot;
       for (uint32_t i = lo; i < hi; i++) {
         const uint64_t k = ka[i];
         const uint32_t pos = off[(k >> sh) & 15u]++;
