@@ -349,7 +349,7 @@ void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_mi
   if (n == 0) return;
   int cur = radix_sort_u64(cand_hash[0].as<uint64_t>(), cand_hash[1].as<uint64_t>(),
                            have_pos ? cand_pos[0].as<uint64_t>() : nullptr,
-                           have_pos ? cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s, 0, 8, kHashedDistinct);
+                           have_pos ? cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s);
   out->sorted_buf = cur;
   uniq.ensure(n * 8);
   starts.ensure((n + 1) * 4);
@@ -621,7 +621,7 @@ bool KmerMinHash::merge_on_device(const KmerMinHash& other) {
   }
   int cur = radix_sort_u64(E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(),
                            both_tracked ? E.cand_pos[0].as<uint64_t>() : nullptr,
-                           both_tracked ? E.cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s, 0, 8, kHashedDistinct);
+                           both_tracked ? E.cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s);
   E.uniq.ensure(n * 8);
   E.starts.ensure((n + 1) * 4);
   const uint32_t nruns = run_length_encode_u64(E.cand_hash[cur].as<uint64_t>(), n, E.uniq.as<uint64_t>(),
@@ -1009,7 +1009,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
     // (hash, position) -> (hash, group); sort by hash, then stably by group: (group, hash) order
     launch_pos_to_group(E.cand_pos[0].as<uint64_t>(), n, pos_table, pos_entries, pos_groups, s, keep_pos ? kPosBits : 0);
     const int c1 = radix_sort_u64(E.cand_hash[0].as<uint64_t>(), E.cand_hash[1].as<uint64_t>(), E.cand_pos[0].as<uint64_t>(),
-                                  E.cand_pos[1].as<uint64_t>(), n, dev.scratch, s, 0, 8, kHashedDistinct);
+                                  E.cand_pos[1].as<uint64_t>(), n, dev.scratch, s);
     const int c2 = radix_sort_u64(E.cand_pos[c1].as<uint64_t>(), E.cand_pos[c1 ^ 1].as<uint64_t>(),
                                   E.cand_hash[c1].as<uint64_t>(), E.cand_hash[c1 ^ 1].as<uint64_t>(), n, dev.scratch, s,
                                   keep_pos ? kPosBits / 8 : 0, 8);

@@ -336,21 +336,22 @@ __global__ __launch_bounds__(1024) void k_small_sort(const uint64_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
-// Hashed keys: most significant bits first, the rest in place.
-// Eight LSD passes move every key eight times.  When the keys are hash values -- uniform -- a few passes over the most
-// significant bits that can differ leave every key within a handful of places of its final one:
-//   * distinct hashes, more than 32 768 keys: THREE passes over the top 24 bits; runs of keys with equal top bits are
-//     then one to three keys long and k_fix_runs puts each in order where it lies (one more read of the keys, hardly
-//     any writes) -- four trips through memory instead of eight;
-//   * pooled hashes (many copies of each), up to 8 M keys: TWO passes over the top 16 bits, each of the 65 536 buckets
-//     finished by a wavefront in LDS (k_bucket_sort);
-//   * up to 32 768 keys: ONE pass over the top 8 bits and 256 buckets -- six launches instead of twenty-four.
-// Correct for any input, and stable like the passes it replaces: a run longer than 8 keys (a k-mer repeated a
-// million times, a hash every signature of a collection holds) is checked by a whole wavefront and is almost always in
-// order already -- equal keys -- otherwise sorted in LDS (up to kBucketCap keys) or by ONE workgroup with 4-bit passes
-// (k_big_buckets: slow, and never needed for hashes).
+// Hashed keys: most significant bits first, the rest per bucket.
+// Eight LSD passes move every key eight times.  When the keys are hash values -- uniform -- passes over the most
+// significant bits that can differ leave small buckets in their final places, and a bucket is finished by one wavefront
+// with a bitonic network in LDS (k_bucket_sort):
+//   * up to 32 768 keys: ONE pass over the top 8 bits and 256 buckets -- six launches instead of twenty-four;
+//   * up to 8 M keys: TWO passes over the top 16 bits and 65 536 buckets -- three trips through memory instead of eight.
+//     The network is m log^2 m, so this pays up to ~128 keys per bucket; above 8 M keys the plain passes are as fast.
+// Correct for any input, and stable like the passes it replaces: a bucket of more than kBucketCap keys is passed through
+// when its keys are all equal and otherwise sorted by ONE workgroup with 4-bit passes (k_big_buckets: ~10 us per
+// thousand keys).  That path is the reason the callers ask for this sort only where one key cannot come in too many
+// copies -- the compare pre-pass of up to 8192 sketches; a sketch fold (a k-mer repeated a million times makes a
+// bucket of a million keys: 57 ms instead of 3) stays on the plain passes.
+// (Tried and dropped: three passes over the top 24 bits and an in-place insertion fix-up of the short runs that remain --
+// 0.3 ms faster on 10 M distinct hashes, slower on everything with repeats: reads at 30-fold coverage, a compare pool,
+// one k-mer a million times.  profiles/r02_sort_paths.txt.)
 constexpr int kBucketCap = 1024;
-constexpr uint32_t kFixScan = 8;      // k_fix_runs: a lane follows its run this far before handing it over
 
 // bitonic network over (key, place) pairs in LDS, one wavefront (= the workgroup); m a power of two
 __device__ __forceinline__ void wave_bitonic(uint64_t* sk, uint16_t* si, uint32_t m, uint32_t lane) {
@@ -425,114 +426,6 @@ __global__ __launch_bounds__(64) void k_bucket_sort(const uint64_t* __restrict__
       kout[s + i] = sk[i];
       if (VB == 8) static_cast<uint64_t*>(vout_)[s + i] = static_cast<const uint64_t*>(vin_)[s + si[i]];
       if (VB == 4) static_cast<uint32_t*>(vout_)[s + i] = static_cast<const uint32_t*>(vin_)[s + si[i]];
-    }
-    __syncthreads();
-  }
-}
-
-// After the passes over the top bits (field = key >> sh): every run of equal fields put in order where it lies.
-// One lane per key; the lane of a run's first key follows the run -- a few keys -- and sorts it by insertion; a run
-// longer than kFixScan goes on the list of k_long_runs.
-template <int VB>
-__global__ __launch_bounds__(256) void k_fix_runs(uint64_t* __restrict__ keys, void* __restrict__ vals_, uint32_t n, int sh,
-                                                  uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_list) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t k0 = keys[i];
-  const uint64_t f = k0 >> sh;
-  if (i > 0 && (keys[i - 1] >> sh) == f) return;          // not the first of its run
-  uint32_t len = 1;
-  bool sorted = true;
-  uint64_t prev = k0;
-  while (len <= kFixScan && i + len < n) {
-    const uint64_t k = keys[i + len];
-    if ((k >> sh) != f) break;
-    sorted = sorted && k >= prev;
-    prev = k;
-    len++;
-  }
-  if (len > kFixScan) {                                    // k_long_runs finds the end, 64 keys at a time
-    long_list[atomicAdd(long_count, 1u)] = i;
-    return;
-  }
-  if (sorted) return;
-  for (uint32_t a = 1; a < len; a++) {                     // stable: strict comparisons
-    const uint64_t kx = keys[i + a];
-    uint64_t v8 = 0; uint32_t v4 = 0;
-    if (VB == 8) v8 = static_cast<uint64_t*>(vals_)[i + a];
-    if (VB == 4) v4 = static_cast<uint32_t*>(vals_)[i + a];
-    uint32_t b = a;
-    while (b > 0 && keys[i + b - 1] > kx) {
-      keys[i + b] = keys[i + b - 1];
-      if (VB == 8) static_cast<uint64_t*>(vals_)[i + b] = static_cast<uint64_t*>(vals_)[i + b - 1];
-      if (VB == 4) static_cast<uint32_t*>(vals_)[i + b] = static_cast<uint32_t*>(vals_)[i + b - 1];
-      b--;
-    }
-    if (b != a) {
-      keys[i + b] = kx;
-      if (VB == 8) static_cast<uint64_t*>(vals_)[i + b] = v8;
-      if (VB == 4) static_cast<uint32_t*>(vals_)[i + b] = v4;
-    }
-  }
-}
-
-// The long runs: one wavefront each.  In order already (equal keys, nearly always): nothing to do.  Otherwise sorted in
-// LDS, or -- more than kBucketCap keys -- handed on to k_big_buckets.
-template <int VB>
-__global__ __launch_bounds__(64) void k_long_runs(uint64_t* __restrict__ keys, void* __restrict__ vals_, uint32_t n, int sh,
-                                                  const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list,
-                                                  uint32_t* __restrict__ big_count, uint2* __restrict__ big_list) {
-  __shared__ uint64_t sk[kBucketCap];
-  __shared__ uint64_t sv[VB == 8 ? kBucketCap : 1];
-  __shared__ uint32_t sw[VB == 4 ? kBucketCap : 1];
-  __shared__ uint16_t si[kBucketCap];
-  const uint32_t lane = threadIdx.x;
-  const uint32_t nlong = *long_count;
-  for (uint32_t e = blockIdx.x; e < nlong; e += gridDim.x) {
-    const uint32_t s = long_list[e];
-    const uint64_t f = keys[s] >> sh;
-    // the run's length and whether it is in order already, 256 keys at a time (a k-mer repeated a million times is
-    // a run of a million equal keys: the loads of a step are independent, so that they overlap)
-    uint32_t len = 0;
-    bool bad = false, done = false;
-    for (uint32_t base = s; !done; base += 256) {
-      uint64_t kc[4], kp[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t j = base + 64u * r + lane;
-        kc[r] = j < n ? keys[j] : 0;
-        kp[r] = (j < n && j > s) ? keys[j - 1] : 0;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t j = base + 64u * r + lane;
-        const bool in = j < n && (kc[r] >> sh) == f;
-        const uint64_t m_in = __ballot(in);                   // (the fields are sorted: `in` is a prefix of the run's tail)
-        if (!done) {
-          bad = bad || (in && j > s && kp[r] > kc[r]);
-          if (m_in != ~0ull) { len = base - s + 64u * r + (uint32_t)__popcll(m_in); done = true; }
-        }
-      }
-    }
-    if (!__any(bad)) continue;
-    if (len > (uint32_t)kBucketCap) {
-      if (lane == 0) big_list[atomicAdd(big_count, 1u)] = make_uint2(s, len);
-      continue;
-    }
-    uint32_t m = 1;
-    while (m < len) m <<= 1;
-    for (uint32_t i = lane; i < m; i += 64) {
-      sk[i] = i < len ? keys[s + i] : ~0ull;
-      si[i] = i < len ? (uint16_t)i : (uint16_t)0xffffu;
-      if (VB == 8 && i < len) sv[i] = static_cast<const uint64_t*>(vals_)[s + i];
-      if (VB == 4 && i < len) sw[i] = static_cast<const uint32_t*>(vals_)[s + i];
-    }
-    __syncthreads();
-    wave_bitonic(sk, si, m, lane);
-    for (uint32_t i = lane; i < len; i += 64) {
-      keys[s + i] = sk[i];
-      if (VB == 8) static_cast<uint64_t*>(vals_)[s + i] = sv[si[i]];
-      if (VB == 4) static_cast<uint32_t*>(vals_)[s + i] = sw[si[i]];
     }
     __syncthreads();
   }
@@ -778,7 +671,7 @@ static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanCh
 // keys can differ) -- no digit-histogram read-back, so no host synchronisation inside the sort.
 static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
                            DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0,
-                           int hashed_keys = kNotHashed) {
+                           bool hashed_keys = false) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
   if (n <= (size_t)kSmallSortMax && first_pass == 0 && last_pass == 8) {
@@ -794,13 +687,13 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   const size_t tmp_bytes = (std::max<size_t>(scan_tmp_entries((size_t)256 * nblocks), 256) * sizeof(uint32_t) + 15) & ~(size_t)15;   // (>= the 256 digit totals)
   // hybrid finish (hashed keys): bucket bounds, the count and the list of the buckets set aside
   const size_t bounds_bytes = (65536 + 16) * sizeof(uint32_t);
-  const size_t big_bytes = (n / kBucketCap + 2) * sizeof(uint2) + (n / kFixScan + 2) * sizeof(uint32_t);   // buckets set aside; long runs
+  const size_t big_bytes = (n / kBucketCap + 2) * sizeof(uint2);
   scratch.ensure(hist_bytes + bh_bytes + tmp_bytes + bounds_bytes + big_bytes);
   auto* ghist = (unsigned long long*)scratch.ptr;
   auto* blockhist = (uint32_t*)((char*)scratch.ptr + hist_bytes);
   auto* scan_tmp = (uint32_t*)((char*)scratch.ptr + hist_bytes + bh_bytes);
   auto* bounds = (uint32_t*)((char*)scratch.ptr + hist_bytes + bh_bytes + tmp_bytes);
-  auto* big_count = bounds + 65536 + 8;                    // [0] buckets set aside, [1] long runs
+  auto* big_count = bounds + 65536 + 8;
   auto* big_list = (uint2*)((char*)scratch.ptr + hist_bytes + bh_bytes + tmp_bytes + bounds_bytes);
 
   unsigned long long hh[8 * 256];
@@ -841,17 +734,11 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
       }
     }
   }
-  // Hashed keys: F field bits by F/8 passes, the rest in place (k_fix_runs) or per bucket (k_bucket_sort) -- when that
-  // saves passes.  Distinct hashes (sketch candidates): 24 bits + fix-up above 32 768 keys.  Pooled hashes (the compare
-  // pre-pass: every hash of a family comes in tens to hundreds of copies, and runs of equal keys are what the fix-up
-  // is slow on): 16 bits + buckets in LDS up to 128 keys per bucket on average, the plain passes above that (measured,
-  // profiles/r02_sort_paths.txt).  Up to 32 768 keys either way: 8 bits + buckets.
+  // Hashed keys: F field bits by F/8 passes, the rest per bucket (k_bucket_sort) -- when that saves passes.
   // (B as computed is exact only when every byte above the top differing one is zero; with a nonzero constant byte up
   // there the field would not index the keys from zero, so that case stays on the plain passes.)
-  int F = 8;
-  if (n > 32768) F = hashed_keys == kHashedPooled ? 16 : 24;
-  bool hybrid = hashed_keys != kNotHashed && first_pass == 0 && last_pass == 8 && npasses >= F / 8 + 2 && B > F;
-  if (F == 16 && n > ((size_t)128 << 16)) hybrid = false;
+  const int F = n > 32768 ? 16 : 8;
+  bool hybrid = hashed_keys && first_pass == 0 && last_pass == 8 && npasses >= F / 8 + 2 && B > F && n <= ((size_t)128 << 16);
   if (hybrid && !pass_mask)
     for (int p = (B + 7) / 8; p < 8; p++)
       if (hh[p * 256] != n) hybrid = false;
@@ -887,22 +774,7 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
     HIP_CHECK(hipGetLastError());
     cur ^= 1;
   }
-  if (hybrid && F == 24) {
-    uint32_t* long_count = big_count + 1;
-    uint32_t* long_list = reinterpret_cast<uint32_t*>(big_list + (n / kBucketCap + 2));
-    HIP_CHECK(hipMemsetAsync(big_count, 0, 2 * sizeof(uint32_t), s));
-    const int vb = v0 ? vbytes : 0;
-#define SMH_FIX(VB_)                                                                                                              \
-  hipLaunchKernelGGL(k_fix_runs<VB_>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kk[cur], vv[cur], (uint32_t)n, field_sh, \
-                     long_count, long_list);                                                                                      \
-  hipLaunchKernelGGL(k_long_runs<VB_>, dim3(4096), dim3(64), 0, s, kk[cur], vv[cur], (uint32_t)n, field_sh, long_count, long_list, \
-                     big_count, big_list);                                                                                        \
-  hipLaunchKernelGGL(k_big_buckets<VB_>, dim3(64), dim3(256), 0, s, kk[cur], kk[cur ^ 1], vv[cur], vv[cur ^ 1], big_count,        \
-                     big_list, field_sh)
-    if (vb == 8) { SMH_FIX(8); } else if (vb == 4) { SMH_FIX(4); } else { SMH_FIX(0); }
-#undef SMH_FIX
-    HIP_CHECK(hipGetLastError());
-  } else if (hybrid) {
+  if (hybrid) {
     const uint32_t nbuckets = 1u << F;
     hipLaunchKernelGGL(k_bucket_bounds, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, s, kk[cur], (uint32_t)n, field_sh, nbuckets,
                        bounds, big_count);
@@ -922,11 +794,11 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
 }
 
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, int hashed_keys) {
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, bool hashed_keys) {
   return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass, 0, hashed_keys);
 }
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                       hipStream_t s, uint32_t pass_mask, int hashed_keys) {
+                       hipStream_t s, uint32_t pass_mask, bool hashed_keys) {
   return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask, hashed_keys);
 }
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask) {

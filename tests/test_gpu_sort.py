@@ -21,7 +21,7 @@ def _check(pkg, keys):
     keys = np.asarray(keys, dtype=np.uint64)
     order = np.argsort(keys, kind="stable")
     want = keys[order]
-    for hashed in (1, 2, 0):
+    for hashed in (1, 0):
         k, _ = _sort(pkg, keys, None, hashed)
         assert np.array_equal(k, want), "keys only, hashed=%d" % hashed
         k, p = _sort(pkg, keys, np.arange(keys.size, dtype=np.uint32), hashed)
@@ -72,5 +72,14 @@ def test_one_key_repeated_a_million_times_among_distinct_ones(pkg):
     rng = np.random.default_rng(10)
     keys = np.concatenate([rng.integers(0, 2**55, size=500_000, dtype=np.uint64), np.full(1_000_000, 0x0012_3456_789A_BCDE, dtype=np.uint64),
                            np.full(70, 0x0000_0000_0000_0007, dtype=np.uint64)])
+    rng.shuffle(keys)
+    _check(pkg, keys)
+
+
+def test_every_key_thirty_times(pkg):
+    """reads at 30-fold coverage: every retained hash is a long run of equal keys"""
+    rng = np.random.default_rng(11)
+    distinct = rng.integers(0, 18446744073709552, size=100_000, dtype=np.uint64)
+    keys = np.repeat(distinct, 30)
     rng.shuffle(keys)
     _check(pkg, keys)
