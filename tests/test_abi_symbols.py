@@ -72,6 +72,12 @@ def test_compute_fails_loudly_without_gpu(pkg):
             call()
         assert ei.value.code == 2
     assert a.mins == [7, 11, 13] and b.mins == [8, 12, 14]
+    # the diagnostic sort: code 2, the array untouched
+    import ctypes as C
+    import numpy as np
+    keys = np.array([5, 3, 9], dtype=np.uint64)
+    assert pkg.lib().smh_sort_u64(keys.ctypes.data_as(C.c_void_p), None, keys.size, 1) == 2
+    assert keys.tolist() == [5, 3, 9]
 
 
 def test_product_does_not_reference_the_oracle():
