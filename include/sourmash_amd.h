@@ -125,9 +125,8 @@ int smh_synth_dna_dev(void *out_dev, uint64_t start, uint64_t len, uint64_t seed
 
 /* The fold's sort on its own (diagnostic entry point for the parity tests): sorts `n` keys in host memory in place,
  * stably, carrying `payload` (n 32-bit values, or NULL) along -- on the device, through the same code as the sketch
- * fold and the compare pre-pass.  hashed_keys != 0 selects the path for hash values (up to 8 M keys: the most
- * significant 8 or 16 bits by radix passes, the buckets finished in LDS); the result is the same either way. */
-int smh_sort_u64(uint64_t *keys, uint32_t *payload, uintptr_t n, int hashed_keys);
+ * fold and the compare pre-pass. */
+int smh_sort_u64(uint64_t *keys, uint32_t *payload, uintptr_t n);
 
 /* Which kernel serves an N x M compare block is chosen from the block's shape (a wavefront per
  * pair, a few-against-many stream, a per-component pair kernel, the tiled matrix kernel).  The

@@ -116,7 +116,7 @@ _SIGS = {
     "smh_compare_get_tuning": (None, [C.POINTER(SmhCompareTuning)]),
     "smh_compare_set_tuning": (C.c_int, [C.POINTER(SmhCompareTuning)]),
     "smh_synth_dna_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
-    "smh_sort_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "smh_sort_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "smh_profile_enable": (None, [C.c_int]),
     "smh_profile_reset": (None, []),
     "smh_profile_get": (C.c_int, [C.c_char_p, f64p, u64p]),

@@ -1084,13 +1084,9 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
   }
   hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint32_t>(), n);
-  // hashes are uniform 64-bit values: every byte differs (no histogram read-back), and the sort may finish the
-  // buckets of the 16 most significant bits in LDS instead of running all eight passes.  A hash comes at most once per
-  // sketch, so a bucket holds at most rows + cols copies of one key beside its ~n / 65 536 others: with few enough
-  // sketches even a hash they all share keeps its bucket small enough for the one-workgroup path (sort.hip).
-  const bool hashed = (uint64_t)rows.n + cols.n <= 8192;
+  // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
   int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), n,
-                               dev.scratch, s, 0xffu, hashed);
+                               dev.scratch, s, 0xffu);
   uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
   uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
 

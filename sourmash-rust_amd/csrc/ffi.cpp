@@ -748,7 +748,7 @@ int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed
   });
 }
 
-int smh_sort_u64(uint64_t* keys, uint32_t* payload, uintptr_t n, int hashed_keys) {
+int smh_sort_u64(uint64_t* keys, uint32_t* payload, uintptr_t n) {
   return pad_code([&] {
     if (n == 0) return;
     require(keys, "keys");
@@ -761,8 +761,8 @@ int smh_sort_u64(uint64_t* keys, uint32_t* payload, uintptr_t n, int hashed_keys
     if (payload) HIP_CHECK(hipMemcpyAsync(v[0].ptr, payload, n * 4, hipMemcpyHostToDevice, s));
     int cur;
     if (payload) cur = smh::radix_sort_u64_v32(k[0].as<uint64_t>(), k[1].as<uint64_t>(), v[0].as<uint32_t>(), v[1].as<uint32_t>(), n,
-                                               dev.scratch, s, 0, hashed_keys != 0);
-    else cur = smh::radix_sort_u64(k[0].as<uint64_t>(), k[1].as<uint64_t>(), nullptr, nullptr, n, dev.scratch, s, 0, 8, hashed_keys != 0);
+                                               dev.scratch, s);
+    else cur = smh::radix_sort_u64(k[0].as<uint64_t>(), k[1].as<uint64_t>(), nullptr, nullptr, n, dev.scratch, s);
     HIP_CHECK(hipMemcpyAsync(keys, k[cur].ptr, n * 8, hipMemcpyDeviceToHost, s));
     if (payload) HIP_CHECK(hipMemcpyAsync(payload, v[cur].ptr, n * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));

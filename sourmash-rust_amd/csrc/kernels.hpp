@@ -97,16 +97,13 @@ void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed,
 // LSD radix sort, ping-pong between (k0,v0) and (k1,v1); returns which pair holds the result.
 // Only the byte passes [first_pass, last_pass) are run (default: all eight): a stable sort by a bit
 // field of the key.
-// hashed_keys: the keys are hash values (uniform) and no key comes in more than a few thousand copies.  A full sort of up
-// to 8 M of them runs one or two passes over the most significant bits that differ and finishes every bucket in LDS
-// (sort.hip, "Hashed keys"); any input is still sorted correctly, and stably -- only slowly when one key dominates.
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8, bool hashed_keys = false);
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8);
 // the same with a 32-bit payload (indices): a quarter less traffic per pass
 // pass_mask != 0: run exactly the byte passes whose bit is set instead of reading the digit histograms
 // back to skip constant bytes -- no host synchronisation inside the sort
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                       hipStream_t s, uint32_t pass_mask = 0, bool hashed_keys = false);
+                       hipStream_t s, uint32_t pass_mask = 0);
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask);
 // run_length_encode_u64 without its read-back: *nruns_dev (device) receives the number of runs;
 // skip (device, nullable): non-zero = the launches do nothing

@@ -336,167 +336,6 @@ __global__ __launch_bounds__(1024) void k_small_sort(const uint64_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
-// Hashed keys: most significant bits first, the rest per bucket.
-// Eight LSD passes move every key eight times.  When the keys are hash values -- uniform -- passes over the most
-// significant bits that can differ leave small buckets in their final places, and a bucket is finished by one wavefront
-// with a bitonic network in LDS (k_bucket_sort):
-//   * up to 32 768 keys: ONE pass over the top 8 bits and 256 buckets -- six launches instead of twenty-four;
-//   * up to 8 M keys: TWO passes over the top 16 bits and 65 536 buckets -- three trips through memory instead of eight.
-//     The network is m log^2 m, so this pays up to ~128 keys per bucket; above 8 M keys the plain passes are as fast.
-// Correct for any input, and stable like the passes it replaces: a bucket of more than kBucketCap keys is passed through
-// when its keys are all equal and otherwise sorted by ONE workgroup with 4-bit passes (k_big_buckets: ~10 us per
-// thousand keys).  That path is the reason the callers ask for this sort only where one key cannot come in too many
-// copies -- the compare pre-pass of up to 8192 sketches; a sketch fold (a k-mer repeated a million times makes a
-// bucket of a million keys: 57 ms instead of 3) stays on the plain passes.
-// (Tried and dropped: three passes over the top 24 bits and an in-place insertion fix-up of the short runs that remain --
-// 0.3 ms faster on 10 M distinct hashes, slower on everything with repeats: reads at 30-fold coverage, a compare pool,
-// one k-mer a million times.  profiles/r02_sort_paths.txt.)
-constexpr int kBucketCap = 1024;
-
-// bitonic network over (key, place) pairs in LDS, one wavefront (= the workgroup); m a power of two
-__device__ __forceinline__ void wave_bitonic(uint64_t* sk, uint16_t* si, uint32_t m, uint32_t lane) {
-  for (uint32_t k = 2; k <= m; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = lane; t < m; t += 64) {
-        const uint32_t p = t ^ j;
-        if (p > t) {
-          const uint64_t a = sk[t], c = sk[p];
-          const uint16_t ia = si[t], ic = si[p];
-          const bool gt = a > c || (a == c && ia > ic);
-          const bool up = (t & k) == 0;
-          if (gt == up) { sk[t] = c; sk[p] = a; si[t] = ic; si[p] = ia; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// bounds[b] = first index whose field (key >> sh) is >= b, b = 0 .. nbuckets (keys sorted by field)
-__global__ __launch_bounds__(256) void k_bucket_bounds(const uint64_t* __restrict__ keys, uint32_t n, int sh, uint32_t nbuckets,
-                                                       uint32_t* __restrict__ bounds, uint32_t* __restrict__ big_count) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) *big_count = 0;
-  if (b > nbuckets) return;
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
-    if ((keys[mid] >> sh) < (uint64_t)b) lo = mid + 1; else hi = mid;
-  }
-  bounds[b] = lo;
-}
-
-// one wavefront (= one workgroup) per bucket: bitonic network over (key, place in the bucket) in LDS
-template <int VB>
-__global__ __launch_bounds__(64) void k_bucket_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
-                                                    const void* __restrict__ vin_, void* __restrict__ vout_,
-                                                    const uint32_t* __restrict__ bounds, uint32_t nbuckets,
-                                                    uint32_t* __restrict__ big_count, uint2* __restrict__ big_list) {
-  __shared__ uint64_t sk[kBucketCap];
-  __shared__ uint16_t si[kBucketCap];
-  const uint32_t lane = threadIdx.x;
-  for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-    const uint32_t s = bounds[b], len = bounds[b + 1] - s;
-    if (len == 0) continue;
-    if (len > (uint32_t)kBucketCap) {
-      uint64_t mn = ~0ull, mx = 0;
-      for (uint32_t i = lane; i < len; i += 64) {
-        const uint64_t k = kin[s + i];
-        mn = k < mn ? k : mn; mx = k > mx ? k : mx;
-        kout[s + i] = k;
-        if (VB == 8) static_cast<uint64_t*>(vout_)[s + i] = static_cast<const uint64_t*>(vin_)[s + i];
-        if (VB == 4) static_cast<uint32_t*>(vout_)[s + i] = static_cast<const uint32_t*>(vin_)[s + i];
-      }
-      for (int off = 32; off; off >>= 1) {
-        const uint64_t a = __shfl_xor(mn, off), c = __shfl_xor(mx, off);
-        mn = a < mn ? a : mn; mx = c > mx ? c : mx;
-      }
-      if (mn != mx && lane == 0) big_list[atomicAdd(big_count, 1u)] = make_uint2(s, len);
-      continue;
-    }
-    uint32_t m = 1;
-    while (m < len) m <<= 1;
-    for (uint32_t i = lane; i < m; i += 64) {
-      sk[i] = i < len ? kin[s + i] : ~0ull;
-      si[i] = i < len ? (uint16_t)i : (uint16_t)0xffffu;   // pads sort after a real ~0 key
-    }
-    __syncthreads();
-    wave_bitonic(sk, si, m, lane);
-    for (uint32_t i = lane; i < len; i += 64) {
-      kout[s + i] = sk[i];
-      if (VB == 8) static_cast<uint64_t*>(vout_)[s + i] = static_cast<const uint64_t*>(vin_)[s + si[i]];
-      if (VB == 4) static_cast<uint32_t*>(vout_)[s + i] = static_cast<const uint32_t*>(vin_)[s + si[i]];
-    }
-    __syncthreads();
-  }
-}
-
-// The buckets k_bucket_sort set aside (more than kBucketCap keys, not all equal): one workgroup each, stable 4-bit
-// passes over the `lowbits` bits below the field, thread t owning the t-th stretch of the bucket.  The bucket is in
-// (b0, w0) on entry (k_bucket_sort copied it there) and on exit; (b1, w1) is the other half of the ping-pong.
-template <int VB>
-__global__ __launch_bounds__(256) void k_big_buckets(uint64_t* __restrict__ b0, uint64_t* __restrict__ b1, void* __restrict__ w0_,
-                                                     void* __restrict__ w1_, const uint32_t* __restrict__ big_count,
-                                                     const uint2* __restrict__ big_list, int lowbits) {
-  __shared__ uint32_t cnt[16][256];
-  __shared__ uint32_t wtot[16][4];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const uint32_t nbig = *big_count;
-  for (uint32_t e = blockIdx.x; e < nbig; e += gridDim.x) {
-    const uint32_t s = big_list[e].x, len = big_list[e].y;
-    const uint32_t chunk = (len + 255) / 256;
-    const uint32_t lo = min(len, (uint32_t)t * chunk), hi = min(len, lo + chunk);
-    uint64_t* ka = b0 + s; uint64_t* kb = b1 + s;
-    char* va = VB ? static_cast<char*>(w0_) + (size_t)s * VB : nullptr;
-    char* vb = VB ? static_cast<char*>(w1_) + (size_t)s * VB : nullptr;
-    int npass = 0;
-    for (int sh = 0; sh < lowbits; sh += 4, npass++) {
-      for (int d = 0; d < 16; d++) cnt[d][t] = 0;
-      for (uint32_t i = lo; i < hi; i++) cnt[(ka[i] >> sh) & 15u][t]++;
-      __syncthreads();
-      // exclusive offsets in (digit, thread) order
-      uint32_t off[16];
-      for (int d = 0; d < 16; d++) {
-        const uint32_t v = cnt[d][t];
-        uint32_t incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint32_t u = __shfl_up(incl, o);
-          if (lane >= o) incl += u;
-        }
-        if (lane == 63) wtot[d][w] = incl;
-        off[d] = incl - v;
-      }
-      __syncthreads();
-      uint32_t base = 0;
-      for (int d = 0; d < 16; d++) {
-        uint32_t before = 0, all = 0;
-        for (int ww = 0; ww < 4; ww++) { if (ww < w) before += wtot[d][ww]; all += wtot[d][ww]; }
-        off[d] += base + before;
-        base += all;
-      }
-      for (uint32_t i = lo; i < hi; i++) {
-        const uint64_t k = ka[i];
-        const uint32_t pos = off[(k >> sh) & 15u]++;
-        kb[pos] = k;
-        if (VB == 8) reinterpret_cast<uint64_t*>(vb)[pos] = reinterpret_cast<const uint64_t*>(va)[i];
-        if (VB == 4) reinterpret_cast<uint32_t*>(vb)[pos] = reinterpret_cast<const uint32_t*>(va)[i];
-      }
-      __syncthreads();
-      uint64_t* tk = ka; ka = kb; kb = tk;
-      char* tv = va; va = vb; vb = tv;
-    }
-    if (npass & 1) {   // the result sits in the other half: bring it back
-      for (uint32_t i = t; i < len; i += 256) {
-        kb[i] = ka[i];
-        if (VB == 8) reinterpret_cast<uint64_t*>(vb)[i] = reinterpret_cast<const uint64_t*>(va)[i];
-        if (VB == 4) reinterpret_cast<uint32_t*>(vb)[i] = reinterpret_cast<const uint32_t*>(va)[i];
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // run-length encoding of sorted keys
 constexpr int kRleThreads = 256;
 constexpr int kRleItems = 8;
@@ -670,8 +509,7 @@ static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanCh
 // pass_mask != 0: run exactly the byte passes whose bit is set (the caller knows which bytes of the
 // keys can differ) -- no digit-histogram read-back, so no host synchronisation inside the sort.
 static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
-                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0,
-                           bool hashed_keys = false) {
+                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
   if (n <= (size_t)kSmallSortMax && first_pass == 0 && last_pass == 8) {
@@ -684,17 +522,11 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   const uint32_t nblocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
   const size_t hist_bytes = 8 * 256 * sizeof(unsigned long long);
   const size_t bh_bytes = (size_t)256 * nblocks * sizeof(uint32_t);
-  const size_t tmp_bytes = (std::max<size_t>(scan_tmp_entries((size_t)256 * nblocks), 256) * sizeof(uint32_t) + 15) & ~(size_t)15;   // (>= the 256 digit totals)
-  // hybrid finish (hashed keys): bucket bounds, the count and the list of the buckets set aside
-  const size_t bounds_bytes = (65536 + 16) * sizeof(uint32_t);
-  const size_t big_bytes = (n / kBucketCap + 2) * sizeof(uint2);
-  scratch.ensure(hist_bytes + bh_bytes + tmp_bytes + bounds_bytes + big_bytes);
+  const size_t tmp_bytes = std::max<size_t>(scan_tmp_entries((size_t)256 * nblocks), 256) * sizeof(uint32_t);   // (>= the 256 digit totals)
+  scratch.ensure(hist_bytes + bh_bytes + tmp_bytes);
   auto* ghist = (unsigned long long*)scratch.ptr;
   auto* blockhist = (uint32_t*)((char*)scratch.ptr + hist_bytes);
   auto* scan_tmp = (uint32_t*)((char*)scratch.ptr + hist_bytes + bh_bytes);
-  auto* bounds = (uint32_t*)((char*)scratch.ptr + hist_bytes + bh_bytes + tmp_bytes);
-  auto* big_count = bounds + 65536 + 8;
-  auto* big_list = (uint2*)((char*)scratch.ptr + hist_bytes + bh_bytes + tmp_bytes + bounds_bytes);
 
   unsigned long long hh[8 * 256];
   if (!pass_mask) {
@@ -710,50 +542,14 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   int cur = 0;
   uint64_t* kk[2] = {k0, k1};
   void* vv[2] = {v0, v1};
-  // which byte passes differ, and B = the number of low bits that can differ at all
-  bool trivial_pass[8];
-  int npasses = 0, B = 0;
-  for (int p = 0; p < 8; p++) {
-    bool trivial = p < first_pass || p >= last_pass;
-    if (!trivial) {
-      if (pass_mask) trivial = !((pass_mask >> p) & 1u);
-      else
-        for (int d = 0; d < 256; d++)
-          if (hh[p * 256 + d] == n) { trivial = true; break; }   // every key has the same digit: the pass is the identity
-    }
-    trivial_pass[p] = trivial;
-    if (!trivial) {
-      npasses++;
-      B = 8 * p + 8;
-      if (!pass_mask) {   // the top digit's largest value present bounds the keys
-        int dmax = 255;
-        while (dmax > 0 && hh[p * 256 + dmax] == 0) dmax--;
-        int bl = 0;
-        while ((1 << bl) <= dmax) bl++;
-        B = 8 * p + bl;
-      }
-    }
-  }
-  // Hashed keys: F field bits by F/8 passes, the rest per bucket (k_bucket_sort) -- when that saves passes.
-  // (B as computed is exact only when every byte above the top differing one is zero; with a nonzero constant byte up
-  // there the field would not index the keys from zero, so that case stays on the plain passes.)
-  const int F = n > 32768 ? 16 : 8;
-  bool hybrid = hashed_keys && first_pass == 0 && last_pass == 8 && npasses >= F / 8 + 2 && B > F && n <= ((size_t)128 << 16);
-  if (hybrid && !pass_mask)
-    for (int p = (B + 7) / 8; p < 8; p++)
-      if (hh[p * 256] != n) hybrid = false;
-  if (hybrid && pass_mask && B != 64)
-    hybrid = false;   // (constant high bytes of unknown value)
-  const int field_sh = B - F;
-  for (int step = 0; step < 8; step++) {
-    int shift = 8 * step;
-    if (hybrid) {
-      if (step >= F / 8) break;
-      shift = field_sh + 8 * step;
-    } else if (trivial_pass[step]) {
-      continue;
-    }
-    hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, shift,
+  for (int p = first_pass; p < last_pass; p++) {
+    bool trivial = false;
+    if (pass_mask) trivial = !((pass_mask >> p) & 1u);
+    else
+      for (int d = 0; d < 256; d++)
+        if (hh[p * 256 + d] == n) { trivial = true; break; }
+    if (trivial) continue;  // every key has the same digit: the pass is the identity
+    hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
                        blockhist, nblocks);
     const uint32_t* dtot = nullptr;
     if (nblocks <= kRowScanMax) {
@@ -764,29 +560,13 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
     }
     if (v0 && vbytes == 8)
       hipLaunchKernelGGL(k_radix_scatter<8>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, shift, blockhist, nblocks, dtot);
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot);
     else if (v0 && vbytes == 4)
       hipLaunchKernelGGL(k_radix_scatter<4>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, shift, blockhist, nblocks, dtot);
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot);
     else
       hipLaunchKernelGGL(k_radix_scatter<0>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], nullptr, nullptr, n, shift, blockhist, nblocks, dtot);
-    HIP_CHECK(hipGetLastError());
-    cur ^= 1;
-  }
-  if (hybrid) {
-    const uint32_t nbuckets = 1u << F;
-    hipLaunchKernelGGL(k_bucket_bounds, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, s, kk[cur], (uint32_t)n, field_sh, nbuckets,
-                       bounds, big_count);
-    const dim3 bgrid(nbuckets < 8192u ? nbuckets : 8192u);
-    const int vb = v0 ? vbytes : 0;
-#define SMH_BUCKETS(VB_)                                                                                                          \
-  hipLaunchKernelGGL(k_bucket_sort<VB_>, bgrid, dim3(64), 0, s, kk[cur], kk[cur ^ 1], vv[cur], vv[cur ^ 1], bounds, nbuckets,     \
-                     big_count, big_list);                                                                                        \
-  hipLaunchKernelGGL(k_big_buckets<VB_>, dim3(64), dim3(256), 0, s, kk[cur ^ 1], kk[cur], vv[cur ^ 1], vv[cur], big_count,       \
-                     big_list, field_sh)
-    if (vb == 8) { SMH_BUCKETS(8); } else if (vb == 4) { SMH_BUCKETS(4); } else { SMH_BUCKETS(0); }
-#undef SMH_BUCKETS
+                         kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks, dtot);
     HIP_CHECK(hipGetLastError());
     cur ^= 1;
   }
@@ -794,12 +574,12 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
 }
 
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, bool hashed_keys) {
-  return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass, 0, hashed_keys);
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
+  return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass);
 }
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                       hipStream_t s, uint32_t pass_mask, bool hashed_keys) {
-  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask, hashed_keys);
+                       hipStream_t s, uint32_t pass_mask) {
+  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask);
 }
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask) {
   return radix_sort_impl(k0, k1, nullptr, nullptr, 0, n, scratch, s, 0, 8, pass_mask);

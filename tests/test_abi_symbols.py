@@ -76,7 +76,7 @@ def test_compute_fails_loudly_without_gpu(pkg):
     import ctypes as C
     import numpy as np
     keys = np.array([5, 3, 9], dtype=np.uint64)
-    assert pkg.lib().smh_sort_u64(keys.ctypes.data_as(C.c_void_p), None, keys.size, 1) == 2
+    assert pkg.lib().smh_sort_u64(keys.ctypes.data_as(C.c_void_p), None, keys.size) == 2
     assert keys.tolist() == [5, 3, 9]
 
 

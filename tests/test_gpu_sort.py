@@ -1,6 +1,6 @@
-"""The fold's sort on its own (smh_sort_u64): radix passes and the hashed-key path (two passes over the most
-significant bits, buckets finished in LDS, oversized buckets set aside) against numpy's stable sort.  Covers the
-inputs that make buckets large: repeated keys, keys that share their high bits, constant high bytes."""
+"""The fold's sort on its own (smh_sort_u64) against numpy's stable sort: uniform hashes, scaled hashes, repeated keys
+(a k-mer a million times, every key thirty times, the pool of one family), keys that share their high bits, constant
+high bytes, short keys (passes skipped), the sizes around the one-workgroup sort."""
 import ctypes as C
 
 import numpy as np
@@ -9,10 +9,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _sort(pkg, keys, payload, hashed):
+def _sort(pkg, keys, payload):
     k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
     p = None if payload is None else np.ascontiguousarray(payload, dtype=np.uint32).copy()
-    rc = pkg.lib().smh_sort_u64(k.ctypes.data_as(C.c_void_p), None if p is None else p.ctypes.data_as(C.c_void_p), k.size, int(hashed))
+    rc = pkg.lib().smh_sort_u64(k.ctypes.data_as(C.c_void_p), None if p is None else p.ctypes.data_as(C.c_void_p), k.size)
     assert rc == 0
     return k, p
 
@@ -21,12 +21,11 @@ def _check(pkg, keys):
     keys = np.asarray(keys, dtype=np.uint64)
     order = np.argsort(keys, kind="stable")
     want = keys[order]
-    for hashed in (1, 0):
-        k, _ = _sort(pkg, keys, None, hashed)
-        assert np.array_equal(k, want), "keys only, hashed=%d" % hashed
-        k, p = _sort(pkg, keys, np.arange(keys.size, dtype=np.uint32), hashed)
-        assert np.array_equal(k, want), "keys with payload, hashed=%d" % hashed
-        assert np.array_equal(p, order.astype(np.uint32)), "payload order (stability), hashed=%d" % hashed
+    k, _ = _sort(pkg, keys, None)
+    assert np.array_equal(k, want), "keys only"
+    k, p = _sort(pkg, keys, np.arange(keys.size, dtype=np.uint32))
+    assert np.array_equal(k, want), "keys with payload"
+    assert np.array_equal(p, order.astype(np.uint32)), "payload order (stability)"
 
 
 @pytest.mark.parametrize("n", [2, 4096, 4097, 65535, 65536, 300_000, 3_000_000])
@@ -83,3 +82,13 @@ def test_every_key_thirty_times(pkg):
     keys = np.repeat(distinct, 30)
     rng.shuffle(keys)
     _check(pkg, keys)
+
+
+def test_pool_of_one_family(pkg):
+    """every pool hash in most signatures of the block: 4 000 keys x 800-2 300 copies beside a million single ones"""
+    rng = np.random.default_rng(12)
+    for copies in (800, 2300):
+        heavy = np.repeat(rng.integers(0, 2**64, size=1500, dtype=np.uint64), copies)
+        keys = np.concatenate([heavy, rng.integers(0, 2**64, size=1_000_000, dtype=np.uint64)])
+        rng.shuffle(keys)
+        _check(pkg, keys)

@@ -7,8 +7,8 @@ from __graft_entry__ import load_package
 pkg = load_package()
 from sourmash_rust_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-mode = sys.argv[2] if len(sys.argv) > 2 else "families"      # families | one_component | all_tiles | nosym
-sigs = synth.family_signatures(0, n, num=2000, seed=3)
+mode = sys.argv[2] if len(sys.argv) > 2 else "families"      # families | one_component | one_family | all_tiles | nosym
+sigs = synth.family_signatures(0, n, num=2000, seed=3, n_families=1 if mode == "one_family" else 50)
 if mode == "one_component":
     sigs[:, 0] = 1                                            # a contaminant hash shared by every signature
 tune = {"all_tiles": dict(route="tiled", visit_all_tiles=True), "nosym": dict(route="tiled", visit_all_tiles=True, use_symmetry=False)}.get(mode, {})
