@@ -251,9 +251,13 @@ struct DnaSource : HashSource {
 // instantiation for.
 struct ProteinSource : HashSource {
   SeqBatch b;
-  std::vector<uint64_t> seg;           // host copy of the segment table (6 frames per record)
-  const uint64_t* seg_off = nullptr;   // device copy
+  // The segment table (6 frames per record) of the six-frame layout: only the two-pass path and callers that want
+  // positions need it, and for a batch of reads it is six entries per read -- built and uploaded on demand.
+  std::vector<uint64_t> seg;           // host copy
+  const uint64_t* seg_off = nullptr;   // device copy (null until ensure_segments)
+  const uint64_t* h_offsets = nullptr; // the caller's record offsets (valid for the duration of the call)
   uint32_t nseg = 0;
+  void ensure_segments(hipStream_t s);
   uint64_t total = 0;
   uint32_t win = 0, ksize = 0;
   uint64_t seed = 0;
@@ -272,6 +276,7 @@ struct ProteinSource : HashSource {
       eng->badbuf.ensure(8);
       uint32_t* flag = eng->badbuf.as<uint32_t>();
       HIP_CHECK(hipMemsetAsync(flag, 0, 4, s));
+      if (sink.pos) ensure_segments(s);                     // positions are residue indices of the six-frame layout
       dev->prof_begin(s);
       const bool ran = launch_protein_fused(b, seg_off, win, p, sink, flag, *dev, s);
       if (ran) {
@@ -285,6 +290,7 @@ struct ProteinSource : HashSource {
         dev->prof_end("protein_fused_unsupported", s);
       }
     }
+    ensure_segments(s);
     if (!translated) translate(s);
     p.range_lo = lo; p.range_hi = hi;
     dev->prof_begin(s);
@@ -706,30 +712,45 @@ void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, 
 // six-frame layout that defines the arm's position space.  Returns false when there is nothing to hash.
 bool prepare_protein(const SeqBatch& b, const uint64_t* h_offsets, uint32_t nrec, uint32_t ksize, uint64_t seed, Engine& E,
                      Device& dev, hipStream_t s, ProteinSource* src, bool* have_error, Error* err) {
+  (void)s;
   const uint32_t aa_k = ksize / 3;
-  const uint32_t nseg = 6 * nrec;
-  std::vector<uint64_t>& seg = src->seg;
-  seg.assign(nseg + 1, 0);
+  // residues over the six frames of every record: frame f of a record of `len` bases holds (len - f) / 3, twice
+  // (forward and reverse complement); a record shorter than ksize adds nothing
+  // (len / 3 + (len - 1) / 3 + (len - 2) / 3 == len - 2 for len >= 2)
+  uint64_t total = 0;
   for (uint32_t r = 0; r < nrec; r++) {
     const uint64_t len = h_offsets[r + 1] - h_offsets[r];
-    for (uint32_t f = 0; f < 6; f++) {
-      const uint32_t frame = f >> 1;
-      uint64_t nres = (len >= ksize && len >= frame) ? (len - frame) / 3 : 0;
-      seg[6 * r + f + 1] = seg[6 * r + f] + nres;
-    }
+    if (len < ksize) continue;
+    if (len >= 2) total += 2 * (len - 2);
+    else for (uint32_t frame = 0; frame < 3; frame++) total += len >= frame ? 2 * ((len - frame) / 3) : 0;
   }
-  const uint64_t total = seg[nseg];
   if (aa_k == 0) throw_panic("window size must be non-zero");  // aa.windows(0), quirk Q8
   if (total == 0) return false;
-  E.segbuf.ensure((size_t)(nseg + 1) * 8);
-  HIP_CHECK(hipMemcpyAsync(E.segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
   src->b = b;
   if (nrec == 1) src->b.vend0 = (h_offsets[1] - h_offsets[0]) >= ksize ? b.len : 0;
-  src->seg_off = E.segbuf.as<uint64_t>(); src->nseg = nseg;
+  src->seg.clear(); src->seg_off = nullptr; src->h_offsets = h_offsets; src->nseg = 6 * nrec;
   src->total = total; src->win = aa_k; src->ksize = ksize; src->seed = seed; src->dev = &dev; src->eng = &E;
   src->have_error = have_error; src->err = err; src->translated = false;
   return true;
 }
+
+void ProteinSource::ensure_segments(hipStream_t s) {
+  if (seg_off) return;
+  const uint32_t nrec = nseg / 6;
+  seg.assign((size_t)nseg + 1, 0);
+  for (uint32_t r = 0; r < nrec; r++) {
+    const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+    for (uint32_t f = 0; f < 6; f++) {
+      const uint32_t frame = f >> 1;
+      const uint64_t nres = (len >= ksize && len >= frame) ? (len - frame) / 3 : 0;
+      seg[6 * (size_t)r + f + 1] = seg[6 * (size_t)r + f] + nres;
+    }
+  }
+  eng->segbuf.ensure((size_t)(nseg + 1) * 8);
+  HIP_CHECK(hipMemcpyAsync(eng->segbuf.ptr, seg.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
+  seg_off = eng->segbuf.as<uint64_t>();
+}
+
 }  // namespace
 
 // Six-frame translation into E.resbuf, and the reference's UTF-8 panic: a codon chunk that is not
@@ -989,6 +1010,7 @@ void add_sequences_grouped(KmerMinHash* const* mhs, uint32_t n_mh, const uint8_t
     E.grpbuf.ensure(g6.size() * 4);
     HIP_CHECK(hipMemcpyAsync(E.grpbuf.ptr, g6.data(), g6.size() * 4, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));   // g6 is a stack-lifetime staging vector
+    prot.ensure_segments(s);              // the grouped fold maps positions to groups through the segment table
     pos_table = E.segbuf.as<uint64_t>(); pos_entries = 6 * nrec; pos_groups = E.grpbuf.as<uint32_t>();
   }
   HashSource& src = *srcp;
