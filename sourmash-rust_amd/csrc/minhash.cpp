@@ -711,19 +711,22 @@ void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, 
 // Protein arm set-up (reference src/lib.rs:277-301): the segment table (6 frames per record) of the
 // six-frame layout that defines the arm's position space.  Returns false when there is nothing to hash.
 bool prepare_protein(const SeqBatch& b, const uint64_t* h_offsets, uint32_t nrec, uint32_t ksize, uint64_t seed, Engine& E,
-                     Device& dev, hipStream_t s, ProteinSource* src, bool* have_error, Error* err) {
+                     Device& dev, hipStream_t s, ProteinSource* src, bool* have_error, Error* err,
+                     const uint64_t* known_total = nullptr) {
   (void)s;
   const uint32_t aa_k = ksize / 3;
   // residues over the six frames of every record: frame f of a record of `len` bases holds (len - f) / 3, twice
   // (forward and reverse complement); a record shorter than ksize adds nothing
   // (len / 3 + (len - 1) / 3 + (len - 2) / 3 == len - 2 for len >= 2)
   uint64_t total = 0;
-  for (uint32_t r = 0; r < nrec; r++) {
-    const uint64_t len = h_offsets[r + 1] - h_offsets[r];
-    if (len < ksize) continue;
-    if (len >= 2) total += 2 * (len - 2);
-    else for (uint32_t frame = 0; frame < 3; frame++) total += len >= frame ? 2 * ((len - frame) / 3) : 0;
-  }
+  if (known_total) total = *known_total;
+  else
+    for (uint32_t r = 0; r < nrec; r++) {
+      const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+      if (len < ksize) continue;
+      if (len >= 2) total += 2 * (len - 2);
+      else for (uint32_t frame = 0; frame < 3; frame++) total += len >= frame ? 2 * ((len - frame) / 3) : 0;
+    }
   if (aa_k == 0) throw_panic("window size must be non-zero");  // aa.windows(0), quirk Q8
   if (total == 0) return false;
   src->b = b;
@@ -797,17 +800,32 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
   hipStream_t s = stream ? stream : dev.stream();
   materialize();   // drains queued small sequences first: stream order is part of the semantics
 
-  // records shorter than ksize add nothing (reference src/lib.rs:257)
-  bool any_long = false;
-  for (uint32_t r = 0; r < nrec; r++) any_long |= (h_offsets[r + 1] - h_offsets[r]) >= ksize;
-  if (!any_long) return;
-
   const uint64_t* d_starts = nullptr;
   if (nrec > 1) {
     E.offbuf.ensure((size_t)(nrec + 1) * 8);
     HIP_CHECK(hipMemcpyAsync(E.offbuf.ptr, h_offsets, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, s));
     d_starts = E.offbuf.as<uint64_t>();
   }
+  // records shorter than ksize add nothing (reference src/lib.rs:257); the protein arm also needs its position count.
+  // A batch of reads is tens of millions of records: the device counts them from the offsets it has just received.
+  uint64_t n_long = 0, protein_total = 0;
+  if (nrec >= 65536) {
+    E.misc.ensure(16);
+    launch_record_stats(d_starts, nrec, ksize, E.misc.as<uint64_t>(), s);
+    uint64_t st[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(st, E.misc.ptr, 16, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    n_long = st[0]; protein_total = st[1];
+  } else {
+    for (uint32_t r = 0; r < nrec; r++) {
+      const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+      if (len < ksize) continue;
+      n_long++;
+      if (len >= 2) protein_total += 2 * (len - 2);    // len / 3 + (len - 1) / 3 + (len - 2) / 3 == len - 2
+      else for (uint32_t frame = 0; frame < 3; frame++) protein_total += len >= frame ? 2 * ((len - frame) / 3) : 0;
+    }
+  }
+  if (n_long == 0) return;
   SeqBatch b;
   b.seq = d_seq; b.len = total_len; b.starts = d_starts; b.nrec = nrec; b.vend0 = total_len;
 
@@ -822,7 +840,7 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
     ingest(*this, src, s);
   } else {
     ProteinSource src;
-    if (!prepare_protein(b, h_offsets, nrec, ksize, seed, E, dev, s, &src, &have_error, &err)) return;
+    if (!prepare_protein(b, h_offsets, nrec, ksize, seed, E, dev, s, &src, &have_error, &err, &protein_total)) return;
     ingest(*this, src, s);
   }
 

@@ -1510,6 +1510,30 @@ void launch_dna_hash(const SeqBatch& b_in, const HashParams& p, const CandSink& 
   }
 }
 
+// out[0] = records of at least ksize bases, out[1] = positions of the protein arm's six-frame layout (2 (len - 2) per such
+// record: len / 3 + (len - 1) / 3 + (len - 2) / 3 == len - 2).  A batch of reads has tens of millions of records; a
+// host pass over their offsets costs more than hashing them.
+__global__ __launch_bounds__(256) void k_record_stats(const uint64_t* __restrict__ starts, uint32_t nrec, uint32_t ksize,
+                                                      unsigned long long* __restrict__ out) {
+  unsigned long long nlong = 0, total = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t len = starts[r + 1] - starts[r];
+    if (len >= ksize) {
+      nlong++;
+      if (len >= 2) total += 2 * (len - 2);
+      else for (uint32_t f = 0; f < 3; f++) total += len >= f ? 2 * ((len - f) / 3) : 0;
+    }
+  }
+  for (int off = 32; off; off >>= 1) { nlong += __shfl_down(nlong, off); total += __shfl_down(total, off); }
+  if ((threadIdx.x & 63) == 0 && (nlong | total)) { atomicAdd(&out[0], nlong); atomicAdd(&out[1], total); }
+}
+void launch_record_stats(const uint64_t* starts, uint32_t nrec, uint32_t ksize, uint64_t* out2, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(out2, 0, 16, s));
+  hipLaunchKernelGGL(k_record_stats, dim3(grid_for(nrec, 256, 2048)), dim3(256), 0, s, starts, nrec, ksize,
+                     reinterpret_cast<unsigned long long*>(out2));
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s) {
   if (b.len == 0) return;
   hipLaunchKernelGGL(k_first_invalid, dim3(grid_for(b.len, 256 * 16, 4096)), dim3(256), 0, s, b,

@@ -771,3 +771,29 @@ def test_release_workspace_then_continue(pkg, coracle):
         out = pkg.matrix.compare_block([g] * 20, [g] * 70, want=("jaccard",))
         assert (out["jaccard"] == 1.0).all()
         assert L.smh_release_workspace() == 0
+
+
+@pytest.mark.parametrize("prot", [False, True])
+def test_a_batch_of_many_short_records(prot, pkg, coracle):
+    """100 000 records of 0..70 bases in one device batch (a batch of reads; above 65 536 records the device counts
+    the records of at least ksize bases and the protein arm's positions itself) against the C oracle fed record by
+    record: scaled sketch with abundance, and a bottom-num one."""
+    import torch
+    rng = np.random.default_rng(77)
+    nrec = 100_000
+    lens = rng.integers(0, 71, size=nrec)
+    off = np.zeros(nrec + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    total = int(off[-1])
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=total)
+    seq[rng.integers(0, total, size=total // 400)] = ord("N")
+    buf = torch.from_numpy(seq).cuda()
+    for num, mx in ((0, (1 << 64) // 50), (300, 0)):
+        ks = 27 if prot else 21
+        g = pkg.KmerMinHash(num, ks, prot, 42, mx, True)
+        g.add_sequences_dev(buf.data_ptr(), total, off, True)
+        o = coracle.MinHash(num, ks, prot, 42, mx, True)
+        raw = seq.tobytes()
+        for r in range(nrec):
+            o.add_sequence(raw[int(off[r]):int(off[r + 1])], True)
+        same_state(g, o)
