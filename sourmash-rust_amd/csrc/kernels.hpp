@@ -57,6 +57,8 @@ void launch_dna_hash(const SeqBatch& b, const HashParams& p, const CandSink& sin
 // smallest position of a byte outside [ACGTacgt] per record -> vends (atomicMin); vends must be
 // pre-filled with the record ends.  (reference src/lib.rs:795-804 _checkdna, applied per byte)
 void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s);
+// *out (device) = the first record that is at least ksize long and whose vends entry lies before its end, else UINT64_MAX
+void launch_first_bad_record(const uint64_t* starts, const uint64_t* vends, uint32_t nrec, uint32_t ksize, uint64_t* out, hipStream_t s);
 // out2 (device): [0] records of at least ksize bases, [1] positions of the protein arm's six-frame layout
 void launch_record_stats(const uint64_t* starts, uint32_t nrec, uint32_t ksize, uint64_t* out2, hipStream_t s);
 

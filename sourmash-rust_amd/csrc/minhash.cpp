@@ -684,15 +684,31 @@ namespace {
 // the first such record in order is reported.  Leaves the cut points in b.vends / b.vend0.
 void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, uint32_t nrec, uint32_t ksize, Engine& E,
                   hipStream_t s, bool* have_error, Error* err) {
-  std::vector<uint64_t> vends(h_offsets + 1, h_offsets + nrec + 1);
+  // vends = the record ends (a device copy of starts + 1: no host vector, a batch of reads has tens of millions of
+  // records), lowered by k_first_invalid; the first offending record is found on the device too
   E.vendbuf.ensure((size_t)nrec * 8);
-  HIP_CHECK(hipMemcpyAsync(E.vendbuf.ptr, vends.data(), (size_t)nrec * 8, hipMemcpyHostToDevice, s));
+  if (nrec > 1) HIP_CHECK(hipMemcpyAsync(E.vendbuf.ptr, b.starts + 1, (size_t)nrec * 8, hipMemcpyDeviceToDevice, s));
+  else HIP_CHECK(hipMemcpyAsync(E.vendbuf.ptr, h_offsets + 1, 8, hipMemcpyHostToDevice, s));
   launch_first_invalid(b, E.vendbuf.as<uint64_t>(), s);
-  HIP_CHECK(hipMemcpyAsync(vends.data(), E.vendbuf.ptr, (size_t)nrec * 8, hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipStreamSynchronize(s));
-  for (uint32_t r = 0; r < nrec && !*have_error; r++) {
-    const uint64_t st = h_offsets[r], en = h_offsets[r + 1], bad = vends[r];
-    if (bad >= en || en - st < ksize) continue;
+  uint64_t first = ~0ull, vend0 = 0;
+  if (nrec > 1) {
+    E.misc.ensure(16);
+    launch_first_bad_record(b.starts, E.vendbuf.as<uint64_t>(), nrec, ksize, E.misc.as<uint64_t>(), s);
+    HIP_CHECK(hipMemcpyAsync(&first, E.misc.ptr, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(&vend0, E.vendbuf.ptr, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (vend0 < h_offsets[1] && h_offsets[1] - h_offsets[0] >= ksize) first = 0;
+  }
+  if (first != ~0ull && !*have_error) {
+    const uint32_t r = (uint32_t)first;
+    const uint64_t st = h_offsets[r];
+    uint64_t bad = vend0;
+    if (nrec > 1) {
+      HIP_CHECK(hipMemcpyAsync(&bad, E.vendbuf.as<uint64_t>() + r, 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+    }
     const uint64_t ws = bad + 1 >= st + ksize ? bad + 1 - ksize : st;  // first window holding `bad`
     std::vector<uint8_t> kmer(ksize);
     HIP_CHECK(hipMemcpyAsync(kmer.data(), d_seq + ws, ksize, hipMemcpyDeviceToHost, s));
@@ -706,7 +722,7 @@ void dna_validate(SeqBatch& b, const uint8_t* d_seq, const uint64_t* h_offsets, 
   }
   // records shorter than ksize must not lose anything: they add nothing either way
   if (nrec > 1) b.vends = E.vendbuf.as<uint64_t>();
-  else b.vend0 = vends[0];
+  else b.vend0 = vend0;
 }
 // Protein arm set-up (reference src/lib.rs:277-301): the segment table (6 frames per record) of the
 // six-frame layout that defines the arm's position space.  Returns false when there is nothing to hash.

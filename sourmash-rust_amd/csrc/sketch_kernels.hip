@@ -624,19 +624,48 @@ __global__ __launch_bounds__(256) void k_dna_generic(SeqBatch b, HashParams hp, 
 }
 
 // ---------------------------------------------------------------------------------
+// force == false: the smallest position of a byte outside [ACGTacgt] per record (atomicMin into vends, pre-filled with
+// the record ends).  16 bytes per lane per step, aligned, validity four bytes at a time as in k_dna_rolling (10 GB in
+// ~3 ms; the byte-at-a-time version took 11).
 __global__ __launch_bounds__(256) void k_first_invalid(SeqBatch b, uint64_t* __restrict__ vends) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
-  for (uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; base < b.len;
-       base += stride) {
-    uint64_t hi = base + 16 < b.len ? base + 16 : b.len;
-    for (uint64_t q = base; q < hi; q++) {
-      uint32_t u = b.seq[q] & 0xDFu;
-      if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) {
-        uint32_t r = b.starts ? find_record(b.starts, b.nrec, q) : 0;
+  const uintptr_t p0 = (uintptr_t)b.seq, pa = p0 & ~(uintptr_t)15;
+  const uint64_t head = p0 - pa;
+  const uint64_t nch = (head + b.len + 15) >> 4;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += stride) {
+    const uint4 v = *reinterpret_cast<const uint4*>(pa + (c << 4));
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t u4 = w[k] & 0xDFDFDFDFu;
+      const uint32_t c2 = (u4 >> 1) & 0x03030303u;
+      const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
+      const uint32_t diff4 = u4 ^ __builtin_amdgcn_perm(0u, 0x54474341u, code4);
+      if (diff4 == 0) continue;
+      for (int j = 0; j < 4; j++) {
+        if (((diff4 >> (8 * j)) & 0xffu) == 0) continue;
+        const uint64_t at = (c << 4) + 4 * k + j;            // offset from pa
+        if (at < head || at - head >= b.len) continue;       // a byte of the 16-byte granule outside the batch
+        const uint64_t q = at - head;
+        const uint32_t r = b.starts ? find_record(b.starts, b.nrec, q) : 0;
         atomicMin((unsigned long long*)&vends[r], (unsigned long long)q);
       }
     }
   }
+}
+// the first record, in order, that is at least ksize long and whose valid part ends before its end (UINT64_MAX: none)
+__global__ __launch_bounds__(256) void k_first_bad_record(const uint64_t* __restrict__ starts, const uint64_t* __restrict__ vends,
+                                                          uint32_t nrec, uint32_t ksize, unsigned long long* __restrict__ out) {
+  unsigned long long best = ~0ull;
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t st = starts[r], en = starts[r + 1];
+    if (vends[r] < en && en - st >= ksize && r < best) best = r;
+  }
+  for (int off = 32; off; off >>= 1) {
+    const unsigned long long o = __shfl_down(best, off);
+    best = o < best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(out, best);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1534,9 +1563,16 @@ void launch_record_stats(const uint64_t* starts, uint32_t nrec, uint32_t ksize, 
   HIP_CHECK(hipGetLastError());
 }
 
+void launch_first_bad_record(const uint64_t* starts, const uint64_t* vends, uint32_t nrec, uint32_t ksize, uint64_t* out, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(out, 0xff, 8, s));
+  hipLaunchKernelGGL(k_first_bad_record, dim3(grid_for(nrec, 256, 2048)), dim3(256), 0, s, starts, vends, nrec, ksize,
+                     reinterpret_cast<unsigned long long*>(out));
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_first_invalid(const SeqBatch& b, uint64_t* vends_out, hipStream_t s) {
   if (b.len == 0) return;
-  hipLaunchKernelGGL(k_first_invalid, dim3(grid_for(b.len, 256 * 16, 4096)), dim3(256), 0, s, b,
+  hipLaunchKernelGGL(k_first_invalid, dim3(grid_for(b.len + 32, 256 * 16, 8192)), dim3(256), 0, s, b,
                      vends_out);
   HIP_CHECK(hipGetLastError());
 }

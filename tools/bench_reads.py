@@ -19,14 +19,16 @@ buf = torch.empty(n, dtype=torch.uint8, device="cuda")
 L.smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, n, 2, 0, C.c_void_p(0))
 torch.cuda.synchronize()
 off = np.arange(nrec + 1, dtype=np.uint64) * np.uint64(rl)
-for params, name in [((0, 31, False, 42, 18446744073709552, True), "scaled=1000 abund"), ((1000, 21, False, 42, 0, False), "num=1000 k=21"),
-                     ((0, 27, True, 42, 18446744073709552, True), "protein ksize=27 scaled=1000 abund")]:
+for params, name, force in [((0, 31, False, 42, 18446744073709552, True), "scaled=1000 abund", True),
+                            ((0, 31, False, 42, 18446744073709552, True), "scaled=1000 abund, force=false", False),
+                            ((1000, 21, False, 42, 0, False), "num=1000 k=21", True),
+                            ((0, 27, True, 42, 18446744073709552, True), "protein ksize=27 scaled=1000 abund", True)]:
     L.smh_profile_reset(); L.smh_profile_enable(1)
     ts = []
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         mh = pkg.KmerMinHash(*params)
-        mh.add_sequences_dev(buf.data_ptr(), n, off, True)
+        mh.add_sequences_dev(buf.data_ptr(), n, off, force)
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     ms, cnt = C.c_double(), C.c_uint64()
     L.smh_profile_get(b"protein_fused" if params[2] else b"dna_rolling", C.byref(ms), C.byref(cnt))
