@@ -297,38 +297,90 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
 }
 
 // ---------------------------------------------------------------------------------
-// Up to 4096 keys: one workgroup, bitonic network in LDS.  The eight-pass radix sort is ~40 tiny
-// launches, which is most of the latency of a small sketch (1 MB of DNA leaves ~1000 candidates).
-// Sorting (key, original index) pairs makes it stable, like the LSD sort it stands in for.
-constexpr int kSmallSortMax = 4096;
+// Up to 8192 keys: the radix passes inside ONE workgroup, keys and their places in LDS, one launch instead of twenty-one.
+// Same ranking as k_radix_scatter (lanes holding the same digit found with eight ballots, per-wave digit counters); a
+// pass reads every key into registers and -- after the barriers -- writes it back to the same array at its new place.
+// One bacterial genome per call (5 Mbp -> 5 059 candidates at scaled=1000) spent 150 of its 245 us in those launches.
+constexpr int kBlockSortMax = 8192;
+constexpr int kBsThreads = 512, kBsWaves = kBsThreads / 64, kBsItems = kBlockSortMax / kBsThreads;
 template <int VB>
-__global__ __launch_bounds__(1024) void k_small_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
-                                                     const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
-  __shared__ uint64_t sk[kSmallSortMax];
-  __shared__ uint32_t si[kSmallSortMax];
-  uint32_t m = 1;
-  while (m < n) m <<= 1;   // padded size
-  for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-    sk[i] = i < n ? kin[i] : ~0ull;
-    si[i] = i < n ? i : 0xffffffffu;   // pads sort after a real ~0 key
+__global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
+                                                           const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
+  __shared__ uint64_t sk[kBlockSortMax];
+  __shared__ uint16_t si[kBlockSortMax];
+  __shared__ uint32_t wcount[kBsWaves][256];
+  __shared__ uint32_t lbase[kBsWaves][256];
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t skip;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const uint32_t items = (n + kBsThreads - 1) / kBsThreads;          // per lane; the workgroup covers items * 512 slots
+  const uint32_t covered = items * kBsThreads;
+  for (uint32_t i = t; i < covered; i += kBsThreads) {
+    sk[i] = i < n ? kin[i] : ~0ull;                                  // pads sort last (after a real ~0 key: they come later)
+    si[i] = (uint16_t)i;
   }
-  __syncthreads();
-  for (uint32_t k = 2; k <= m; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < m; t += 1024) {
-        const uint32_t p = t ^ j;
-        if (p > t) {
-          const uint64_t a = sk[t], b = sk[p];
-          const uint32_t ia = si[t], ib = si[p];
-          const bool gt = a > b || (a == b && ia > ib);
-          const bool up = (t & k) == 0;
-          if (gt == up) { sk[t] = b; sk[p] = a; si[t] = ib; si[p] = ia; }
+  const uint64_t lt = lanemask_lt();
+  const uint32_t wbase = (uint32_t)w * items * 64;
+  for (int shift = 0; shift < 64; shift += 8) {
+    for (int i = t; i < kBsWaves * 256; i += kBsThreads) (&wcount[0][0])[i] = 0;
+    if (t == 0) skip = 0;
+    __syncthreads();
+    uint64_t key[kBsItems];
+    uint32_t meta[kBsItems];   // digit << 16 | rank among the wave's keys with that digit
+    uint16_t idx[kBsItems];
+#pragma unroll
+    for (int i = 0; i < kBsItems; i++) {
+      key[i] = 0; meta[i] = 0; idx[i] = 0;
+      if ((uint32_t)i < items) {
+        const uint32_t pos = wbase + (uint32_t)i * 64 + lane;
+        const uint64_t k = sk[pos];
+        const uint32_t d = (uint32_t)(k >> shift) & 255u;
+        key[i] = k; idx[i] = si[pos];
+        uint64_t m = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const uint64_t bal = __ballot((d >> b) & 1);
+          m &= ((d >> b) & 1) ? bal : ~bal;
         }
+        const uint32_t prior = wcount[w][d];
+        const uint32_t below = (uint32_t)__popcll(m & lt);
+        meta[i] = (d << 16) | (prior + below);
+        if (below == 0) wcount[w][d] = prior + (uint32_t)__popcll(m);
       }
-      __syncthreads();
     }
+    __syncthreads();
+    uint32_t tot = 0, incl = 0;
+    if (t < 256) {   // thread d: the keys with digit d
+#pragma unroll
+      for (int ww = 0; ww < kBsWaves; ww++) tot += wcount[ww][t];
+      // every real key has this digit (the pads -- all ones, always at the end -- count under digit 255): identity
+      if (tot - (t == 255 ? covered - n : 0u) == n) skip = 1;
+      incl = tot;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wtot[w] = incl;
+    }
+    __syncthreads();
+    if (t < 256) {   // where digit d starts, and inside it where each wave's keys go
+      uint32_t run = incl - tot;
+      for (int ww = 0; ww < w; ww++) run += wtot[ww];
+#pragma unroll
+      for (int ww = 0; ww < kBsWaves; ww++) { lbase[ww][t] = run; run += wcount[ww][t]; }
+    }
+    __syncthreads();
+    if (!skip) {
+#pragma unroll
+      for (int i = 0; i < kBsItems; i++)
+        if ((uint32_t)i < items) {
+          const uint32_t np = lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu);
+          sk[np] = key[i]; si[np] = idx[i];
+        }
+    }
+    __syncthreads();
   }
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+  for (uint32_t i = t; i < n; i += kBsThreads) {
     kout[i] = sk[i];
     if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[si[i]];
     if (VB == 4) static_cast<uint32_t*>(vout_)[i] = static_cast<const uint32_t*>(vin_)[si[i]];
@@ -512,10 +564,10 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
                            DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0) {
   if (n < 2) return 0;
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
-  if (n <= (size_t)kSmallSortMax && first_pass == 0 && last_pass == 8) {
-    if (v0 && vbytes == 8) hipLaunchKernelGGL(k_small_sort<8>, dim3(1), dim3(1024), 0, s, k0, k1, v0, v1, (uint32_t)n);
-    else if (v0 && vbytes == 4) hipLaunchKernelGGL(k_small_sort<4>, dim3(1), dim3(1024), 0, s, k0, k1, v0, v1, (uint32_t)n);
-    else hipLaunchKernelGGL(k_small_sort<0>, dim3(1), dim3(1024), 0, s, k0, k1, nullptr, nullptr, (uint32_t)n);
+  if (n <= (size_t)kBlockSortMax && first_pass == 0 && last_pass == 8) {
+    if (v0 && vbytes == 8) hipLaunchKernelGGL(k_block_sort<8>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, v0, v1, (uint32_t)n);
+    else if (v0 && vbytes == 4) hipLaunchKernelGGL(k_block_sort<4>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, v0, v1, (uint32_t)n);
+    else hipLaunchKernelGGL(k_block_sort<0>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, nullptr, nullptr, (uint32_t)n);
     HIP_CHECK(hipGetLastError());
     return 1;
   }

@@ -28,7 +28,7 @@ def _check(pkg, keys):
     assert np.array_equal(p, order.astype(np.uint32)), "payload order (stability)"
 
 
-@pytest.mark.parametrize("n", [2, 4096, 4097, 65535, 65536, 300_000, 3_000_000])
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 511, 512, 513, 4096, 4097, 8191, 8192, 8193, 65535, 65536, 300_000, 3_000_000])
 def test_uniform_keys(pkg, n):
     rng = np.random.default_rng(n)
     _check(pkg, rng.integers(0, 2**64, size=n, dtype=np.uint64))
@@ -92,3 +92,13 @@ def test_pool_of_one_family(pkg):
         keys = np.concatenate([heavy, rng.integers(0, 2**64, size=1_000_000, dtype=np.uint64)])
         rng.shuffle(keys)
         _check(pkg, keys)
+
+
+def test_small_arrays_with_repeats(pkg):
+    """the one-workgroup sort of up to 8192 keys: ties keep their order, constant digits are skipped"""
+    rng = np.random.default_rng(13)
+    for n in (5, 100, 2000, 5000, 8192):
+        _check(pkg, rng.integers(0, 50, size=n, dtype=np.uint64))
+        _check(pkg, np.full(n, 7, dtype=np.uint64))
+        _check(pkg, np.full(n, 2**64 - 1, dtype=np.uint64))
+        _check(pkg, rng.integers(2**63, 2**64, size=n, dtype=np.uint64))
