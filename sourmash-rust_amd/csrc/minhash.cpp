@@ -347,6 +347,41 @@ uint64_t Engine::run_chunk(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_
   throw_internal("candidate buffer overflow after re-run");
 }
 
+bool Engine::run_chunk_small(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_t thr, hipStream_t s, DeviceSketch* out,
+                             uint64_t* n_out, uint64_t* cap_out) {
+  HashSource& src = *static_cast<HashSource*>(src_);
+  uint64_t cap = estimate_capacity(hi - lo, thr);
+  if (cap == 0) cap = 1;
+  cand_hash[0].ensure(cap * 8);
+  cand_hash[1].ensure(cap * 8);
+  counter.ensure(8);
+  misc.ensure(16);
+  uniq.ensure((size_t)kSmallFoldMax * 8);
+  starts.ensure(((size_t)kSmallFoldMax + 1) * 4);
+  HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, s));
+  CandSink sink;
+  sink.hash = cand_hash[0].as<uint64_t>();
+  sink.pos = nullptr;
+  sink.count = counter.as<unsigned long long>();
+  sink.capacity = cap;
+  src.launch(lo, hi, thr, sink, s);
+  small_fold_async(cand_hash[0].as<uint64_t>(), counter.as<unsigned long long>(), cap, uniq.as<uint64_t>(), starts.as<uint32_t>(),
+                   misc.as<unsigned long long>(), s);
+  unsigned long long res[2] = {0, 0};
+  HIP_CHECK(hipMemcpyAsync(res, misc.ptr, 16, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  *n_out = res[0]; *cap_out = cap;
+  if (res[1] == ~0ull) return false;
+  std::swap(out->uniq.ptr, uniq.ptr);
+  std::swap(out->uniq.bytes, uniq.bytes);
+  std::swap(out->starts.ptr, starts.ptr);
+  std::swap(out->starts.bytes, starts.bytes);
+  out->n = res[1];
+  out->total = res[0];
+  out->has_runs = true;
+  return true;
+}
+
 void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s,
                           Delta* out, DeviceSketch* keep_on_device) {
   Device& dev = Device::get();
@@ -511,9 +546,22 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
     const uint64_t CH = span_ld > 4.0e12L ? (uint64_t)4e12 : (span_ld < 16777216.0L ? (1ull << 24) : (uint64_t)span_ld);
     for (uint64_t lo = 0; lo < P; lo += CH) {
       const uint64_t hi = std::min(P, lo + CH);
-      const uint64_t n = E.run_chunk(&src, lo, hi, mh.max_hash, false, s);
+      const bool whole_into_empty = mh.mins.empty() && !mh.dev && lo == 0 && hi == P;
+      uint64_t n = 0;
+      bool hashed = false;
+      if (whole_into_empty && (long double)P * frac < 0.7L * kSmallFoldMax) {
+        // one genome per call: a few thousand candidates -- hash, sort, collapse and count with ONE synchronisation
+        auto ds = std::make_shared<DeviceSketch>();
+        uint64_t cap = 0;
+        if (E.run_chunk_small(&src, lo, hi, mh.max_hash, s, ds.get(), &n, &cap)) {
+          if (n > 0) mh.dev = ds;
+          return;
+        }
+        hashed = n <= cap;   // more than the small fold takes (repeats): the candidates are there for the general path
+      }
+      if (!hashed) n = E.run_chunk(&src, lo, hi, mh.max_hash, false, s);
       Delta d;
-      if (mh.mins.empty() && !mh.dev && lo == 0 && hi == P && n > 0) {
+      if (whole_into_empty && n > 0) {
         // empty sketch, whole batch in one chunk: the sorted distinct hashes ARE the new state
         auto ds = std::make_shared<DeviceSketch>();
         E.reduce_chunk(n, 0, false, false, s, &d, ds.get());

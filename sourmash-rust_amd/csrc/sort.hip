@@ -302,28 +302,26 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
 // pass reads every key into registers and -- after the barriers -- writes it back to the same array at its new place.
 // One bacterial genome per call (5 Mbp -> 5 059 candidates at scaled=1000) spent 150 of its 245 us in those launches.
 constexpr int kBlockSortMax = 8192;
+static_assert(kBlockSortMax == (int)kSmallFoldMax, "kernels.hpp promises the small fold's limit");
 constexpr int kBsThreads = 512, kBsWaves = kBsThreads / 64, kBsItems = kBlockSortMax / kBsThreads;
-template <int VB>
-__global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
-                                                           const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
-  __shared__ uint64_t sk[kBlockSortMax];
-  __shared__ uint16_t si[kBlockSortMax];
-  __shared__ uint32_t wcount[kBsWaves][256];
-  __shared__ uint32_t lbase[kBsWaves][256];
-  __shared__ uint32_t wtot[4];
-  __shared__ uint32_t skip;
+struct BlockSortLds {
+  uint64_t sk[kBlockSortMax];
+  uint16_t si[kBlockSortMax];
+  uint32_t wcount[kBsWaves][256];
+  uint32_t lbase[kBsWaves][256];
+  uint32_t wtot[kBsWaves];
+  uint32_t skip;
+};
+// the eight passes over L.sk[0 .. items * 512) (and L.si, the keys' original places, when WithIdx); ends on a barrier
+template <bool WithIdx>
+__device__ __forceinline__ void block_sort_passes(BlockSortLds& L, uint32_t n, uint32_t items) {
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const uint32_t items = (n + kBsThreads - 1) / kBsThreads;          // per lane; the workgroup covers items * 512 slots
   const uint32_t covered = items * kBsThreads;
-  for (uint32_t i = t; i < covered; i += kBsThreads) {
-    sk[i] = i < n ? kin[i] : ~0ull;                                  // pads sort last (after a real ~0 key: they come later)
-    si[i] = (uint16_t)i;
-  }
   const uint64_t lt = lanemask_lt();
   const uint32_t wbase = (uint32_t)w * items * 64;
   for (int shift = 0; shift < 64; shift += 8) {
-    for (int i = t; i < kBsWaves * 256; i += kBsThreads) (&wcount[0][0])[i] = 0;
-    if (t == 0) skip = 0;
+    for (int i = t; i < kBsWaves * 256; i += kBsThreads) (&L.wcount[0][0])[i] = 0;
+    if (t == 0) L.skip = 0;
     __syncthreads();
     uint64_t key[kBsItems];
     uint32_t meta[kBsItems];   // digit << 16 | rank among the wave's keys with that digit
@@ -333,58 +331,109 @@ __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __res
       key[i] = 0; meta[i] = 0; idx[i] = 0;
       if ((uint32_t)i < items) {
         const uint32_t pos = wbase + (uint32_t)i * 64 + lane;
-        const uint64_t k = sk[pos];
+        const uint64_t k = L.sk[pos];
         const uint32_t d = (uint32_t)(k >> shift) & 255u;
-        key[i] = k; idx[i] = si[pos];
+        key[i] = k;
+        if (WithIdx) idx[i] = L.si[pos];
         uint64_t m = ~0ull;
 #pragma unroll
         for (int b = 0; b < 8; b++) {
           const uint64_t bal = __ballot((d >> b) & 1);
           m &= ((d >> b) & 1) ? bal : ~bal;
         }
-        const uint32_t prior = wcount[w][d];
+        const uint32_t prior = L.wcount[w][d];
         const uint32_t below = (uint32_t)__popcll(m & lt);
         meta[i] = (d << 16) | (prior + below);
-        if (below == 0) wcount[w][d] = prior + (uint32_t)__popcll(m);
+        if (below == 0) L.wcount[w][d] = prior + (uint32_t)__popcll(m);
       }
     }
     __syncthreads();
     uint32_t tot = 0, incl = 0;
     if (t < 256) {   // thread d: the keys with digit d
 #pragma unroll
-      for (int ww = 0; ww < kBsWaves; ww++) tot += wcount[ww][t];
+      for (int ww = 0; ww < kBsWaves; ww++) tot += L.wcount[ww][t];
       // every real key has this digit (the pads -- all ones, always at the end -- count under digit 255): identity
-      if (tot - (t == 255 ? covered - n : 0u) == n) skip = 1;
+      if (tot - (t == 255 ? covered - n : 0u) == n) L.skip = 1;
       incl = tot;
       for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(incl, off);
         if (lane >= off) incl += o;
       }
-      if (lane == 63) wtot[w] = incl;
+      if (lane == 63) L.wtot[w] = incl;
     }
     __syncthreads();
     if (t < 256) {   // where digit d starts, and inside it where each wave's keys go
       uint32_t run = incl - tot;
-      for (int ww = 0; ww < w; ww++) run += wtot[ww];
+      for (int ww = 0; ww < w; ww++) run += L.wtot[ww];
 #pragma unroll
-      for (int ww = 0; ww < kBsWaves; ww++) { lbase[ww][t] = run; run += wcount[ww][t]; }
+      for (int ww = 0; ww < kBsWaves; ww++) { L.lbase[ww][t] = run; run += L.wcount[ww][t]; }
     }
     __syncthreads();
-    if (!skip) {
+    if (!L.skip) {
 #pragma unroll
       for (int i = 0; i < kBsItems; i++)
         if ((uint32_t)i < items) {
-          const uint32_t np = lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu);
-          sk[np] = key[i]; si[np] = idx[i];
+          const uint32_t np = L.lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu);
+          L.sk[np] = key[i];
+          if (WithIdx) L.si[np] = idx[i];
         }
     }
     __syncthreads();
   }
-  for (uint32_t i = t; i < n; i += kBsThreads) {
-    kout[i] = sk[i];
-    if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[si[i]];
-    if (VB == 4) static_cast<uint32_t*>(vout_)[i] = static_cast<const uint32_t*>(vin_)[si[i]];
+}
+template <int VB>
+__global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
+                                                           const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
+  __shared__ BlockSortLds L;
+  const uint32_t t = threadIdx.x;
+  const uint32_t items = (n + kBsThreads - 1) / kBsThreads;          // per lane; the workgroup covers items * 512 slots
+  for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) {
+    L.sk[i] = i < n ? kin[i] : ~0ull;                                // pads sort last (after a real ~0 key: they come later)
+    L.si[i] = (uint16_t)i;
   }
+  block_sort_passes<VB != 0>(L, n, items);
+  for (uint32_t i = t; i < n; i += kBsThreads) {
+    kout[i] = L.sk[i];
+    if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[L.si[i]];
+    if (VB == 4) static_cast<uint32_t*>(vout_)[i] = static_cast<const uint32_t*>(vin_)[L.si[i]];
+  }
+}
+
+// The whole fold of a small batch in one launch, without waiting for the candidate count: *count candidates (device) ->
+// distinct keys ascending + run starts + {candidates, runs} in result[0..1].  More than kBlockSortMax candidates (or more
+// than the buffer holds): result[1] = ~0, nothing else touched -- the caller takes the general path.  This is the call
+// shape of one genome per sketch: 5 Mbp leave 5 000 candidates at scaled=1000.
+__global__ __launch_bounds__(kBsThreads) void k_small_fold(const uint64_t* __restrict__ kin, const unsigned long long* __restrict__ count,
+                                                           uint64_t capacity, uint64_t* __restrict__ uniq, uint32_t* __restrict__ starts,
+                                                           unsigned long long* __restrict__ result) {
+  __shared__ BlockSortLds L;
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const unsigned long long n64 = *count;
+  if (n64 > (unsigned long long)kBlockSortMax || n64 > capacity) {
+    if (t == 0) { result[0] = n64; result[1] = ~0ull; }
+    return;
+  }
+  const uint32_t n = (uint32_t)n64;
+  const uint32_t items = (n + kBsThreads - 1) / kBsThreads;
+  for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) L.sk[i] = i < n ? kin[i] : ~0ull;
+  if (n) block_sort_passes<false>(L, n, items);
+  __syncthreads();
+  // run heads: thread t owns slots [t * items, (t + 1) * items)
+  const uint32_t lo = t * items;
+  uint32_t c = 0;
+  for (uint32_t i = lo; i < lo + items && i < n; i++) c += (i == 0 || L.sk[i] != L.sk[i - 1]) ? 1u : 0u;
+  uint32_t incl = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) L.wtot[w] = incl;
+  __syncthreads();
+  uint32_t o = incl - c, total = 0;
+  for (uint32_t ww = 0; ww < (uint32_t)kBsWaves; ww++) { if (ww < w) o += L.wtot[ww]; total += L.wtot[ww]; }
+  for (uint32_t i = lo; i < lo + items && i < n; i++)
+    if (i == 0 || L.sk[i] != L.sk[i - 1]) { uniq[o] = L.sk[i]; starts[o] = i; o++; }
+  if (t == 0) { result[0] = n64; result[1] = total; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -623,6 +672,12 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
     cur ^= 1;
   }
   return cur;
+}
+
+void small_fold_async(const uint64_t* keys, const unsigned long long* count_dev, uint64_t capacity, uint64_t* uniq, uint32_t* starts,
+                      unsigned long long* result_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_small_fold, dim3(1), dim3(kBsThreads), 0, s, keys, count_dev, capacity, uniq, starts, result_dev);
+  HIP_CHECK(hipGetLastError());
 }
 
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
