@@ -593,12 +593,32 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
         if (est < thr) thr = est;
       }
       if (P < (1ull << 40)) {
-        const uint64_t n = E.run_chunk(&src, 0, P, thr, track, s);
+        uint64_t n = 0;
+        bool hashed = false;
+        if (!track && mh.mins.empty() && !mh.dev && want < 0.7L * kSmallFoldMax) {
+          // one genome per call, no abundances: hash, sort, collapse and count with ONE synchronisation; the sketch is
+          // the first `num` of the distinct candidates and stays in HBM until somebody looks at it
+          auto ds = std::make_shared<DeviceSketch>();
+          uint64_t cap = 0;
+          if (E.run_chunk_small(&src, 0, P, thr, s, ds.get(), &n, &cap)) {
+            if (thr == natural || ds->n >= (uint64_t)mh.num) {
+              if (ds->n > (uint64_t)mh.num) ds->n = mh.num;
+              if (ds->n > 0) mh.dev = ds;
+              return;
+            }
+            n = ~0ull;          // fewer than num distinct hashes: nothing applied, the growing-chunk loop takes over
+          } else {
+            hashed = n <= cap;  // too many candidates for the small fold (repeats): they wait in cand_hash[0]
+          }
+        }
+        if (n != ~0ull) {
+        if (!hashed) n = E.run_chunk(&src, 0, P, thr, track, s);
         Delta d;
         E.reduce_chunk(n, mh.num, track, track, s, &d);
         if (thr == natural || d.uniq.size() >= (size_t)mh.num) {
           apply_num(mh, d, E, s);
           return;
+        }
         }
       }
     }
