@@ -13,7 +13,8 @@ assert L.smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, n, 9, 0, None) == 0
 torch.cuda.synchronize()
 off = np.array([0, n], dtype=np.uint64)
 for params, name in (((0, 31, False, 42, 18446744073709552, False), "scaled=1000"), ((0, 31, False, 42, 18446744073709552, True), "scaled=1000 abund"),
-                     ((1000, 31, False, 42, 0, False), "num=1000")):
+                     ((1000, 31, False, 42, 0, False), "num=1000"), ((1000, 31, False, 42, 0, True), "num=1000 abund"),
+                     ((0, 30, True, 42, 18446744073709552, False), "protein ksize=30 scaled=1000")):
     ts = []
     for it in range(50):
         torch.cuda.synchronize(); t0 = time.perf_counter()
