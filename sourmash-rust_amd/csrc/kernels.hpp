@@ -105,11 +105,12 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
                    DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8);
 // The whole fold of a small batch in ONE launch that reads the candidate count from device memory (no host round trip in
 // front of it): up to kSmallFoldMax candidates -> distinct keys ascending in uniq, their run starts in starts (both with room
-// for kSmallFoldMax entries), result_dev[0] = candidates, result_dev[1] = runs.  More candidates than that, or than
-// `capacity`: result_dev[1] = ~0 and nothing else is written.
-constexpr uint32_t kSmallFoldMax = 8192;
+// for kSmallFoldMax entries), result_dev[0] = candidates, result_dev[1] = runs.  More candidates than it takes (kSmallFoldMax,
+// or half of that when `expected` is small enough for the half-size instance), or than `capacity`: result_dev[1] = ~0 and
+// nothing else is written.
+constexpr uint32_t kSmallFoldMax = 16384;
 void small_fold_async(const uint64_t* keys, const unsigned long long* count_dev, uint64_t capacity, uint64_t* uniq, uint32_t* starts,
-                      unsigned long long* result_dev, hipStream_t s);
+                      unsigned long long* result_dev, uint32_t expected, hipStream_t s);
 // the same with a 32-bit payload (indices): a quarter less traffic per pass
 // pass_mask != 0: run exactly the byte passes whose bit is set instead of reading the digit histograms
 // back to skip constant bytes -- no host synchronisation inside the sort

@@ -347,8 +347,8 @@ uint64_t Engine::run_chunk(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_
   throw_internal("candidate buffer overflow after re-run");
 }
 
-bool Engine::run_chunk_small(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_t thr, hipStream_t s, DeviceSketch* out,
-                             uint64_t* n_out, uint64_t* cap_out) {
+bool Engine::run_chunk_small(HashSourceRef src_, uint64_t lo, uint64_t hi, uint64_t thr, uint32_t expected, hipStream_t s,
+                             DeviceSketch* out, uint64_t* n_out, uint64_t* cap_out) {
   HashSource& src = *static_cast<HashSource*>(src_);
   uint64_t cap = estimate_capacity(hi - lo, thr);
   if (cap == 0) cap = 1;
@@ -366,7 +366,7 @@ bool Engine::run_chunk_small(HashSourceRef src_, uint64_t lo, uint64_t hi, uint6
   sink.capacity = cap;
   src.launch(lo, hi, thr, sink, s);
   small_fold_async(cand_hash[0].as<uint64_t>(), counter.as<unsigned long long>(), cap, uniq.as<uint64_t>(), starts.as<uint32_t>(),
-                   misc.as<unsigned long long>(), s);
+                   misc.as<unsigned long long>(), expected, s);
   unsigned long long res[2] = {0, 0};
   HIP_CHECK(hipMemcpyAsync(res, misc.ptr, 16, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
@@ -553,7 +553,7 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
         // one genome per call: a few thousand candidates -- hash, sort, collapse and count with ONE synchronisation
         auto ds = std::make_shared<DeviceSketch>();
         uint64_t cap = 0;
-        if (E.run_chunk_small(&src, lo, hi, mh.max_hash, s, ds.get(), &n, &cap)) {
+        if (E.run_chunk_small(&src, lo, hi, mh.max_hash, (uint32_t)((long double)P * frac), s, ds.get(), &n, &cap)) {
           if (n > 0) mh.dev = ds;
           return;
         }
@@ -600,7 +600,7 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
           // the first `num` of the distinct candidates and stays in HBM until somebody looks at it
           auto ds = std::make_shared<DeviceSketch>();
           uint64_t cap = 0;
-          if (E.run_chunk_small(&src, 0, P, thr, s, ds.get(), &n, &cap)) {
+          if (E.run_chunk_small(&src, 0, P, thr, (uint32_t)want, s, ds.get(), &n, &cap)) {
             if (thr == natural || ds->n >= (uint64_t)mh.num) {
               if (ds->n > (uint64_t)mh.num) ds->n = mh.num;
               if (ds->n > 0) mh.dev = ds;

@@ -126,8 +126,8 @@ class Engine {
   // A chunk expected to leave a few thousand candidates: hash AND fold with one synchronisation (k_small_fold reads the
   // candidate count on the device).  True: `out` holds the sorted distinct hashes and their run starts.  False: *n_out
   // candidates were produced and wait in cand_hash[0] (if they fit *cap_out) for the general path.
-  bool run_chunk_small(HashSourceRef src, uint64_t lo, uint64_t hi, uint64_t thr, hipStream_t s, DeviceSketch* out,
-                       uint64_t* n_out, uint64_t* cap_out);
+  bool run_chunk_small(HashSourceRef src, uint64_t lo, uint64_t hi, uint64_t thr, uint32_t expected, hipStream_t s,
+                       DeviceSketch* out, uint64_t* n_out, uint64_t* cap_out);
   // sort the chunk by hash, collapse runs, keep the first `keep` runs (0 = all), fetch them
   void reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s, Delta* out,
                     DeviceSketch* keep_on_device = nullptr);

@@ -301,20 +301,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
 // Same ranking as k_radix_scatter (lanes holding the same digit found with eight ballots, per-wave digit counters); a
 // pass reads every key into registers and -- after the barriers -- writes it back to the same array at its new place.
 // One bacterial genome per call (5 Mbp -> 5 059 candidates at scaled=1000) spent 150 of its 245 us in those launches.
-constexpr int kBlockSortMax = 8192;
-static_assert(kBlockSortMax == (int)kSmallFoldMax, "kernels.hpp promises the small fold's limit");
-constexpr int kBsThreads = 512, kBsWaves = kBsThreads / 64, kBsItems = kBlockSortMax / kBsThreads;
+constexpr int kBlockSortMax = 8192;                // with the keys' places (payload): 64 + 16 KB of LDS
+constexpr int kBsThreads = 512, kBsWaves = kBsThreads / 64;
+template <int CAP, bool WithIdx>
 struct BlockSortLds {
-  uint64_t sk[kBlockSortMax];
-  uint16_t si[kBlockSortMax];
+  uint64_t sk[CAP];
+  uint16_t si[WithIdx ? CAP : 1];
   uint32_t wcount[kBsWaves][256];
   uint32_t lbase[kBsWaves][256];
   uint32_t wtot[kBsWaves];
   uint32_t skip;
 };
 // the eight passes over L.sk[0 .. items * 512) (and L.si, the keys' original places, when WithIdx); ends on a barrier
-template <bool WithIdx>
-__device__ __forceinline__ void block_sort_passes(BlockSortLds& L, uint32_t n, uint32_t items) {
+template <int CAP, bool WithIdx>
+__device__ __forceinline__ void block_sort_passes(BlockSortLds<CAP, WithIdx>& L, uint32_t n, uint32_t items) {
+  constexpr int kBsItems = CAP / kBsThreads;
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const uint32_t covered = items * kBsThreads;
   const uint64_t lt = lanemask_lt();
@@ -384,14 +385,14 @@ __device__ __forceinline__ void block_sort_passes(BlockSortLds& L, uint32_t n, u
 template <int VB>
 __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
                                                            const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
-  __shared__ BlockSortLds L;
+  __shared__ BlockSortLds<kBlockSortMax, true> L;
   const uint32_t t = threadIdx.x;
   const uint32_t items = (n + kBsThreads - 1) / kBsThreads;          // per lane; the workgroup covers items * 512 slots
   for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) {
     L.sk[i] = i < n ? kin[i] : ~0ull;                                // pads sort last (after a real ~0 key: they come later)
     L.si[i] = (uint16_t)i;
   }
-  block_sort_passes<VB != 0>(L, n, items);
+  block_sort_passes<kBlockSortMax, true>(L, n, items);
   for (uint32_t i = t; i < n; i += kBsThreads) {
     kout[i] = L.sk[i];
     if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[L.si[i]];
@@ -402,21 +403,22 @@ __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __res
 // The whole fold of a small batch in one launch, without waiting for the candidate count: *count candidates (device) ->
 // distinct keys ascending + run starts + {candidates, runs} in result[0..1].  More than kBlockSortMax candidates (or more
 // than the buffer holds): result[1] = ~0, nothing else touched -- the caller takes the general path.  This is the call
-// shape of one genome per sketch: 5 Mbp leave 5 000 candidates at scaled=1000.
+// shape of one genome per sketch: 5 Mbp leave 5 000 candidates at scaled=1000 (10 000 through the protein arm).
+template <int CAP>
 __global__ __launch_bounds__(kBsThreads) void k_small_fold(const uint64_t* __restrict__ kin, const unsigned long long* __restrict__ count,
                                                            uint64_t capacity, uint64_t* __restrict__ uniq, uint32_t* __restrict__ starts,
                                                            unsigned long long* __restrict__ result) {
-  __shared__ BlockSortLds L;
+  __shared__ BlockSortLds<CAP, false> L;                         // keys only: 64 or 128 KB + the counters
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
   const unsigned long long n64 = *count;
-  if (n64 > (unsigned long long)kBlockSortMax || n64 > capacity) {
+  if (n64 > (unsigned long long)CAP || n64 > capacity) {
     if (t == 0) { result[0] = n64; result[1] = ~0ull; }
     return;
   }
   const uint32_t n = (uint32_t)n64;
   const uint32_t items = (n + kBsThreads - 1) / kBsThreads;
   for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) L.sk[i] = i < n ? kin[i] : ~0ull;
-  if (n) block_sort_passes<false>(L, n, items);
+  if (n) block_sort_passes<CAP, false>(L, n, items);
   __syncthreads();
   // run heads: thread t owns slots [t * items, (t + 1) * items)
   const uint32_t lo = t * items;
@@ -675,8 +677,12 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
 }
 
 void small_fold_async(const uint64_t* keys, const unsigned long long* count_dev, uint64_t capacity, uint64_t* uniq, uint32_t* starts,
-                      unsigned long long* result_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_small_fold, dim3(1), dim3(kBsThreads), 0, s, keys, count_dev, capacity, uniq, starts, result_dev);
+                      unsigned long long* result_dev, uint32_t expected, hipStream_t s) {
+  // the half-size instance keeps 16 keys per lane in registers instead of 32: ~10 us less for the usual few thousand keys
+  if (expected * 10 <= (kSmallFoldMax / 2) * 7)
+    hipLaunchKernelGGL(k_small_fold<(int)kSmallFoldMax / 2>, dim3(1), dim3(kBsThreads), 0, s, keys, count_dev, capacity, uniq, starts, result_dev);
+  else
+    hipLaunchKernelGGL(k_small_fold<(int)kSmallFoldMax>, dim3(1), dim3(kBsThreads), 0, s, keys, count_dev, capacity, uniq, starts, result_dev);
   HIP_CHECK(hipGetLastError());
 }
 
