@@ -12,7 +12,11 @@
 //                      replaces: src/lib.rs:260-267 (+ revcomp 677-689, _checkdna 795-804,
 //                      _hash_murmur 33-35) and the `hash <= max_hash` filter of add_hash 198.
 //   k_dna_generic      same contract for any ksize, one lane per k-mer, byte-wise.
-//   k_first_invalid    first byte outside [ACGTacgt] per record (force=false, lib.rs:268-273).
+//   k_first_invalid    first byte outside [ACGTacgt] per record (force=false, lib.rs:268-273); k_first_bad_record
+//                      finds the first offending record on the device.
+//   k_tile_records     record (and the end of its valid part) of every launch tile's first position, so that no lane
+//                      searches all record starts; k_record_stats counts the records of at least ksize bases and the
+//                      protein arm's positions for batches of many records (lib.rs:257).
 //   k_protein_fused<W> protein arm in one pass: translation + hashing of both strands' windows, no residue
 //                      buffer (lib.rs:275-302, 691-793); k_protein_positions rewrites candidate positions.
 //   k_translate        six-frame translation into a residue buffer, unknown codons marked (lib.rs:277-301,
