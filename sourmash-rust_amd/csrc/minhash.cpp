@@ -227,6 +227,12 @@ struct HashSource {
   virtual ~HashSource() = default;
   virtual uint64_t positions() const = 0;
   virtual void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) = 0;
+  // The same without any host round trip inside.  Returns null, or a device word the caller reads back together with
+  // its own results: non-zero means this launch's candidates must be discarded and launch() used instead.
+  virtual const uint32_t* launch_optimistic(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) {
+    launch(lo, hi, thr, sink, s);
+    return nullptr;
+  }
 };
 
 struct DnaSource : HashSource {
@@ -268,6 +274,24 @@ struct ProteinSource : HashSource {
   bool translated = false;
   uint64_t positions() const override { return total; }
   void translate(hipStream_t s);
+  // the fused kernel alone; the non-ASCII flag it raises is left for the caller to read (launch() decides then)
+  const uint32_t* launch_optimistic(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
+    if (translated || lo != 0 || hi != total || sink.pos) { launch(lo, hi, thr, sink, s); return nullptr; }
+    HashParams p;
+    p.seed = seed; p.thr = thr; p.ksize = ksize;
+    p.range_lo = 0; p.range_hi = ~0ull;
+    eng->badbuf.ensure(8);
+    uint32_t* flag = eng->badbuf.as<uint32_t>();
+    HIP_CHECK(hipMemsetAsync(flag, 0, 4, s));
+    dev->prof_begin(s);
+    if (!launch_protein_fused(b, seg_off, win, p, sink, flag, *dev, s)) {
+      dev->prof_end("protein_fused_unsupported", s);
+      launch(lo, hi, thr, sink, s);                         // other window lengths: the two-pass path
+      return nullptr;
+    }
+    dev->prof_end("protein_fused", s);
+    return flag;
+  }
   void launch(uint64_t lo, uint64_t hi, uint64_t thr, const CandSink& sink, hipStream_t s) override {
     HashParams p;
     p.seed = seed; p.thr = thr; p.ksize = ksize;
@@ -364,12 +388,23 @@ bool Engine::run_chunk_small(HashSourceRef src_, uint64_t lo, uint64_t hi, uint6
   sink.pos = nullptr;
   sink.count = counter.as<unsigned long long>();
   sink.capacity = cap;
-  src.launch(lo, hi, thr, sink, s);
+  const uint32_t* redo_flag = src.launch_optimistic(lo, hi, thr, sink, s);
   small_fold_async(cand_hash[0].as<uint64_t>(), counter.as<unsigned long long>(), cap, uniq.as<uint64_t>(), starts.as<uint32_t>(),
                    misc.as<unsigned long long>(), expected, s);
   unsigned long long res[2] = {0, 0};
+  uint32_t redo = 0;
   HIP_CHECK(hipMemcpyAsync(res, misc.ptr, 16, hipMemcpyDeviceToHost, s));
+  if (redo_flag) HIP_CHECK(hipMemcpyAsync(&redo, redo_flag, 4, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  if (redo) {   // (a byte >= 0x80 in a protein batch: rare) the checked launch, then the general path
+    HIP_CHECK(hipMemsetAsync(counter.ptr, 0, 8, s));
+    src.launch(lo, hi, thr, sink, s);
+    unsigned long long n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, counter.ptr, 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    *n_out = n; *cap_out = cap;
+    return false;
+  }
   *n_out = res[0]; *cap_out = cap;
   if (res[1] == ~0ull) return false;
   std::swap(out->uniq.ptr, uniq.ptr);
