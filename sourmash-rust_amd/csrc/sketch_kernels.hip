@@ -869,10 +869,13 @@ __global__ __launch_bounds__(kTrThreads) void k_translate(SeqBatch b, const uint
 // That covers every window whose 3W bases are all ACGT inside one record.  Windows that SKIP dropped
 // codons (to_aa drops a codon holding anything else and splices its neighbours together, quirk Q8)
 // are rare: the lane notices that a span is not clean with the same group test as the DNA kernel
-// and hands its start position to hash_spliced_windows(), which walks the bytes in global memory
-// exactly like the reference.  A byte >= 0x80 anywhere in the batch (where str::from_utf8 could
-// panic, src/lib.rs:787) raises `high_flag`: the host then discards this launch and takes the
-// two-pass path (k_translate + k_hash_windows), which reproduces the panic semantics.
+// and puts its start position on a list; k_spliced_windows, a second tiny launch, walks the bytes
+// of those spans in global memory exactly like the reference.  (A routine called from inside the
+// hashing kernel needs a stack, and a kernel with a stack costs ~110 us more PER LAUNCH on this
+// stack -- more than hashing a 5 Mbp genome.)  A byte >= 0x80 anywhere in the batch (where
+// str::from_utf8 could panic, src/lib.rs:787) or a full list raises `high_flag`: the host then
+// discards this launch and takes the two-pass path (k_translate + k_hash_windows), which
+// reproduces the panic semantics and has no limits.
 //
 // Candidate positions are residue indices of the six-frame layout (segment 6r + 2*frame + strand),
 // the order the reference walks them; seg_off is that layout's segment table.
@@ -920,17 +923,9 @@ __device__ __forceinline__ uint32_t aa_of_digits(int d0, int d1, int d2) {
 // that hold anything but ACGT, like to_aa + windows() of the reference (src/lib.rs:779-793, 289-300).
 // (everything by value: a reference parameter of a non-inlined function would force the caller's
 // kernel arguments into scratch memory)
-struct SplicedArgs {
-  const uint8_t* seq; uint64_t len; const uint64_t* starts; uint32_t nrec;
-  uint32_t ksize; uint64_t seed, thr;
-  uint64_t* sink_hash; uint64_t* sink_pos; unsigned long long* sink_count; uint64_t sink_capacity;
-  uint32_t* st_ctl; uint64_t* st_hash; uint64_t* st_pos; uint32_t st_cap;
-};
-__device__ __noinline__ void hash_spliced_windows(SplicedArgs A, uint32_t win, uint64_t a) {
-  SeqBatch b; b.seq = A.seq; b.len = A.len; b.starts = A.starts; b.nrec = A.nrec;
-  HashParams hp; hp.ksize = A.ksize; hp.seed = A.seed; hp.thr = A.thr;
-  CandSink sink; sink.hash = A.sink_hash; sink.pos = A.sink_pos; sink.count = A.sink_count; sink.capacity = A.sink_capacity;
-  const Stage stage{A.st_ctl, A.st_hash, A.st_pos, A.st_cap};
+// the windows that START at base `a` with dropped codons spliced out (one forward, one reverse complement), straight
+// to the global sink
+__device__ __forceinline__ void spliced_windows(const SeqBatch& b, const HashParams& hp, const CandSink& sink, uint32_t win, uint64_t a) {
   const uint32_t kb = 3 * win;
   uint32_t rec = 0;
   uint64_t rs = 0, re = b.len;
@@ -951,7 +946,7 @@ __device__ __noinline__ void hash_spliced_windows(SplicedArgs A, uint32_t win, u
     }
     if (got == win) {
       const uint64_t h = st.finish();
-      if (h <= hp.thr) stage_emit(stage, sink, h, a << 1);
+      if (h <= hp.thr) emit(sink, h, a << 1);
     }
   }
   // reverse complement: first residue = the codon read backward from base a + 3W - 1
@@ -968,9 +963,16 @@ __device__ __noinline__ void hash_spliced_windows(SplicedArgs A, uint32_t win, u
     }
     if (got == win) {
       const uint64_t h = st.finish();
-      if (h <= hp.thr) stage_emit(stage, sink, h, (a << 1) | 1u);
+      if (h <= hp.thr) emit(sink, h, (a << 1) | 1u);
     }
   }
+}
+
+constexpr uint32_t kSplicedCap = 1u << 20;   // spans a launch may set aside (more: the two-pass path)
+__global__ __launch_bounds__(256) void k_spliced_windows(SeqBatch b, HashParams hp, CandSink sink, uint32_t win,
+                                                         const uint64_t* __restrict__ list, const uint32_t* __restrict__ count) {
+  const uint32_t n = *count < kSplicedCap ? *count : kSplicedCap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) spliced_windows(b, hp, sink, win, list[i]);
 }
 
 // murmur64 of a W-byte string, 1 <= W <= 16: no full block, k1 = bytes 0..7, k2 = bytes 8..W-1 (reference
@@ -1008,7 +1010,8 @@ __device__ __forceinline__ uint32_t byte_shl(uint32_t x) {
 #endif
 template <int W, int THREADS>
 __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch b, HashParams hp, CandSink sink, int logR,
-                                                                          uint32_t stage_cap, uint32_t* __restrict__ high_flag) {
+                                                                          uint32_t stage_cap, uint32_t* __restrict__ high_flag,
+                                                                          uint64_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count) {
   constexpr int KB = 3 * W;                          // bases per window
   constexpr int ND = (W + 3) / 4;                    // dwords of a residue string
   // static LDS: codon tables -- codon number (its first base's digit lowest) -> (residue of the reverse complement) * c1 |
@@ -1232,10 +1235,10 @@ __global__ __launch_bounds__(THREADS, SMH_PF_MINW) void k_protein_fused(SeqBatch
       if (kHash && slowmask) {
 #pragma unroll 1
         for (int q = 0; q < 4; q++)
-          if ((slowmask >> q) & 1u) {
-            const SplicedArgs sa{b.seq, b.len, b.starts, b.nrec, hp.ksize, hp.seed, hp.thr,
-                                 sink.hash, sink.pos, sink.count, sink.capacity, st_ctl, st_hash, st_pos, stage_cap};
-            hash_spliced_windows(sa, (uint32_t)W, p0 + i0 + q + 1 - KB);
+          if ((slowmask >> q) & 1u) {                     // for k_spliced_windows
+            const uint32_t at = atomicAdd(slow_count, 1u);
+            if (at < kSplicedCap) slow_list[at] = p0 + i0 + q + 1 - KB;
+            else atomicOr(high_flag, 2u);
           }
       }
     };
@@ -1605,9 +1608,17 @@ bool launch_protein_fused(const SeqBatch& b_in, const uint64_t* seg_offsets, uin
   if (stage_cap < 128) stage_cap = 128;
   const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes + 4 * ((x_bytes >> logR) + 2);
   const SeqBatch b = with_tile_records(b_in, p.ksize, 0, tile, ntiles, dev, s);
-#define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap, high_flag)
+  // the list of span starts for k_spliced_windows: [count][starts], in the shared scratch (used up before this returns'
+  // successors on the stream -- the fold's sort -- claim it)
+  dev.scratch.ensure(16 + (size_t)kSplicedCap * 8);
+  uint32_t* slow_count = dev.scratch.as<uint32_t>();
+  uint64_t* slow_list = reinterpret_cast<uint64_t*>(dev.scratch.as<char>() + 16);
+  HIP_CHECK(hipMemsetAsync(slow_count, 0, 4, s));
+#define SMH_PF(W_) hipLaunchKernelGGL((k_protein_fused<W_, 512>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap, high_flag, \
+                                      slow_list, slow_count)
   if (win == 7) SMH_PF(7); else if (win == 9) SMH_PF(9); else SMH_PF(10);
 #undef SMH_PF
+  hipLaunchKernelGGL(k_spliced_windows, dim3(64), dim3(256), 0, s, b, p, sink, win, slow_list, slow_count);
   if (sink.pos)   // (a << 1 | strand) -> residue index of the six-frame layout
     hipLaunchKernelGGL(k_protein_positions, dim3(dev.cu_count() * 4), dim3(256), 0, s, sink.pos, sink.count, sink.capacity, b.starts,
                        b.nrec, b.len, seg_offsets, 3 * win, p.pos_base);
