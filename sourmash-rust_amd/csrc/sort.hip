@@ -302,13 +302,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
 // pass reads every key into registers and -- after the barriers -- writes it back to the same array at its new place.
 // One bacterial genome per call (5 Mbp -> 5 059 candidates at scaled=1000) spent 150 of its 245 us in those launches.
 constexpr int kBlockSortMax = 8192;                // with the keys' places (payload): 64 + 16 KB of LDS
-constexpr int kBsThreads = 512, kBsWaves = kBsThreads / 64;
+constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / 64;   // (16 waves hide the LDS latency of a pass better than 8: -4..8 %)
 template <int CAP, bool WithIdx>
 struct BlockSortLds {
   uint64_t sk[CAP];
   uint16_t si[WithIdx ? CAP : 1];
-  uint32_t wcount[kBsWaves][256];
-  uint32_t lbase[kBsWaves][256];
+  uint16_t wcount[kBsWaves][256];   // (16 bits are enough: at most CAP keys)
+  uint16_t lbase[kBsWaves][256];
   uint32_t wtot[kBsWaves];
   uint32_t skip;
 };
@@ -322,6 +322,7 @@ __device__ __forceinline__ void block_sort_passes(BlockSortLds<CAP, WithIdx>& L,
   const uint32_t wbase = (uint32_t)w * items * 64;
   for (int shift = 0; shift < 64; shift += 8) {
     for (int i = t; i < kBsWaves * 256; i += kBsThreads) (&L.wcount[0][0])[i] = 0;
+    static_assert(CAP <= 65535 + 1, "16-bit counters");
     if (t == 0) L.skip = 0;
     __syncthreads();
     uint64_t key[kBsItems];
@@ -345,7 +346,7 @@ __device__ __forceinline__ void block_sort_passes(BlockSortLds<CAP, WithIdx>& L,
         const uint32_t prior = L.wcount[w][d];
         const uint32_t below = (uint32_t)__popcll(m & lt);
         meta[i] = (d << 16) | (prior + below);
-        if (below == 0) L.wcount[w][d] = prior + (uint32_t)__popcll(m);
+        if (below == 0) L.wcount[w][d] = (uint16_t)(prior + (uint32_t)__popcll(m));
       }
     }
     __syncthreads();
@@ -367,7 +368,7 @@ __device__ __forceinline__ void block_sort_passes(BlockSortLds<CAP, WithIdx>& L,
       uint32_t run = incl - tot;
       for (int ww = 0; ww < w; ww++) run += L.wtot[ww];
 #pragma unroll
-      for (int ww = 0; ww < kBsWaves; ww++) { L.lbase[ww][t] = run; run += L.wcount[ww][t]; }
+      for (int ww = 0; ww < kBsWaves; ww++) { L.lbase[ww][t] = (uint16_t)run; run += L.wcount[ww][t]; }
     }
     __syncthreads();
     if (!L.skip) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __res
                                                            const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
   __shared__ BlockSortLds<kBlockSortMax, true> L;
   const uint32_t t = threadIdx.x;
-  const uint32_t items = (n + kBsThreads - 1) / kBsThreads;          // per lane; the workgroup covers items * 512 slots
+  const uint32_t items = (n + kBsThreads - 1) / kBsThreads;          // per lane; the workgroup covers items * 1024 slots
   for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) {
     L.sk[i] = i < n ? kin[i] : ~0ull;                                // pads sort last (after a real ~0 key: they come later)
     L.si[i] = (uint16_t)i;
