@@ -102,7 +102,7 @@ void launch_synth_dna(uint8_t* out, uint64_t start, uint64_t len, uint64_t seed,
 // Only the byte passes [first_pass, last_pass) are run (default: all eight): a stable sort by a bit
 // field of the key.
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8);
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass = 0, int last_pass = 8, uint32_t pass_mask = 0);
 // The whole fold of a small batch in ONE launch that reads the candidate count from device memory (no host round trip in
 // front of it): up to kSmallFoldMax candidates -> distinct keys ascending in uniq, their run starts in starts (both with room
 // for kSmallFoldMax entries), result_dev[0] = candidates, result_dev[1] = runs.  More candidates than it takes (kSmallFoldMax,

@@ -418,14 +418,16 @@ bool Engine::run_chunk_small(HashSourceRef src_, uint64_t lo, uint64_t hi, uint6
 }
 
 void Engine::reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s,
-                          Delta* out, DeviceSketch* keep_on_device) {
+                          Delta* out, DeviceSketch* keep_on_device, uint64_t key_bound) {
   Device& dev = Device::get();
   out->uniq.clear(); out->run_start.clear(); out->minpos.clear();
   out->sorted_buf = 0; out->n = n;
   if (n == 0) return;
+  uint32_t pass_mask = 0;   // the bytes up to the bound's highest non-zero one can differ; the ones above are zero
+  if (key_bound) for (int p = 0; p < 8; p++) if ((key_bound >> (8 * p)) != 0) pass_mask |= 1u << p;
   int cur = radix_sort_u64(cand_hash[0].as<uint64_t>(), cand_hash[1].as<uint64_t>(),
                            have_pos ? cand_pos[0].as<uint64_t>() : nullptr,
-                           have_pos ? cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s);
+                           have_pos ? cand_pos[1].as<uint64_t>() : nullptr, n, dev.scratch, s, 0, 8, pass_mask);
   out->sorted_buf = cur;
   uniq.ensure(n * 8);
   starts.ensure((n + 1) * 4);
@@ -599,11 +601,11 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
       if (whole_into_empty && n > 0) {
         // empty sketch, whole batch in one chunk: the sorted distinct hashes ARE the new state
         auto ds = std::make_shared<DeviceSketch>();
-        E.reduce_chunk(n, 0, false, false, s, &d, ds.get());
+        E.reduce_chunk(n, 0, false, false, s, &d, ds.get(), mh.max_hash);
         mh.dev = ds;
         return;
       }
-      E.reduce_chunk(n, 0, false, false, s, &d);
+      E.reduce_chunk(n, 0, false, false, s, &d, nullptr, mh.max_hash);
       apply_scaled(mh, d);
     }
     return;
@@ -649,7 +651,7 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
         if (n != ~0ull) {
         if (!hashed) n = E.run_chunk(&src, 0, P, thr, track, s);
         Delta d;
-        E.reduce_chunk(n, mh.num, track, track, s, &d);
+        E.reduce_chunk(n, mh.num, track, track, s, &d, nullptr, thr == UINT64_MAX ? 0 : thr);
         if (thr == natural || d.uniq.size() >= (size_t)mh.num) {
           apply_num(mh, d, E, s);
           return;
@@ -664,7 +666,7 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
       const uint64_t thr = full ? mh.mins.back() : UINT64_MAX;
       const uint64_t n = E.run_chunk(&src, lo, hi, thr, track, s);
       Delta d;
-      E.reduce_chunk(n, mh.num, track, track, s, &d);
+      E.reduce_chunk(n, mh.num, track, track, s, &d, nullptr, thr == UINT64_MAX ? 0 : thr);
       apply_num(mh, d, E, s);
       lo = hi;
       if (chunk < (1ull << 30)) chunk *= 8;
@@ -1041,10 +1043,10 @@ void KmerMinHash::add_sequences_host(const uint8_t* h_seq, uint64_t total, const
     Delta d;
     if (mins.empty() && !this->dev && n > 0) {
       auto ds = std::make_shared<DeviceSketch>();
-      E.reduce_chunk(n, 0, false, false, s, &d, ds.get());
+      E.reduce_chunk(n, 0, false, false, s, &d, ds.get(), max_hash);
       this->dev = ds;
     } else {
-      E.reduce_chunk(n, 0, false, false, s, &d);
+      E.reduce_chunk(n, 0, false, false, s, &d, nullptr, max_hash);
       apply_scaled(*this, d);
     }
   } catch (...) {

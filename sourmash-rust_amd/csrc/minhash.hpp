@@ -129,8 +129,10 @@ class Engine {
   bool run_chunk_small(HashSourceRef src, uint64_t lo, uint64_t hi, uint64_t thr, uint32_t expected, hipStream_t s,
                        DeviceSketch* out, uint64_t* n_out, uint64_t* cap_out);
   // sort the chunk by hash, collapse runs, keep the first `keep` runs (0 = all), fetch them
+  // key_bound (0 = unknown): no candidate exceeds it -- the sort then knows which byte passes can differ without reading
+  // the digit histograms back (one host round trip less per fold)
   void reduce_chunk(uint64_t n, uint32_t keep, bool have_pos, bool want_minpos, hipStream_t s, Delta* out,
-                    DeviceSketch* keep_on_device = nullptr);
+                    DeviceSketch* keep_on_device = nullptr, uint64_t key_bound = 0);
 
   // murmur64 of whole byte strings on the device (host pointers in, host pointer out)
   void hash_words(const uint8_t* bytes, const uint64_t* offsets, uint32_t n, uint64_t seed, uint64_t* out);

@@ -688,8 +688,8 @@ void small_fold_async(const uint64_t* keys, const unsigned long long* count_dev,
 }
 
 int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_t n,
-                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass) {
-  return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass);
+                   DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask) {
+  return radix_sort_impl(k0, k1, v0, v1, 8, n, scratch, s, first_pass, last_pass, pass_mask);
 }
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
                        hipStream_t s, uint32_t pass_mask) {
