@@ -139,11 +139,22 @@ def run_workers(specs):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", spec[0], out] + [str(x) for x in spec[1:]]
         procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True), out))
     res = []
-    for p, out in procs:
-        stdout, _ = p.communicate(timeout=600)
-        if p.returncode != 0:
-            raise RuntimeError("cpu worker failed: " + stdout[-500:])
-        res.append((json.loads(stdout.strip().splitlines()[-1]), out))
+    try:
+        for p, out in procs:
+            stdout, _ = p.communicate(timeout=600)
+            if p.returncode != 0:
+                raise RuntimeError("cpu worker failed: " + stdout[-500:])
+            res.append((json.loads(stdout.strip().splitlines()[-1]), out))
+    finally:
+        # a worker that timed out or failed must not leave the others burning the host's cores
+        for p, _ in procs:
+            if p.poll() is None:
+                p.kill()
+        for p, _ in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
     return res
 
 

@@ -164,6 +164,13 @@ void smh_compare_last_stats(SmhCompareStats *out);
  * scratch) between calls and only ever grows it; a long-running process can hand the memory back
  * after a large batch.  Sketches, resident indexes and their device copies are not touched. */
 int smh_release_workspace(void);
+/* Device blocks the library gives up (sketch buffers, mirrors, workspace) are parked in a pool inside the library, per
+ * device and size class, instead of hipFree'd: another allocator in the process (PyTorch's) cannot see that memory.
+ * The pool is capped (default 1 GiB; environment SOURMASH_AMD_POOL_MB=<MiB> at load time, 0 = no pooling); this call
+ * changes the cap at run time (and trims down to it), smh_pool_bytes reports what is parked right now, and
+ * smh_release_workspace() empties the pool together with the workspace. */
+void smh_pool_set_limit(uint64_t bytes);
+uint64_t smh_pool_bytes(void);
 
 /* HIP-event timing of the library's kernels, on the stream they run on.
  * name: "dna_rolling", "dna_generic", "protein_fused", "translate", "hash_windows", "compare_wave", "compare_few",

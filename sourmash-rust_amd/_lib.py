@@ -112,6 +112,8 @@ _SIGS = {
     "smh_index_most_common": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), u64p]),
     "smh_index_compare": (C.c_int, [C.c_void_p, C.c_void_p, f64p, u64p, u64p, u64p, f64p]),
     "smh_release_workspace": (C.c_int, []),
+    "smh_pool_set_limit": (None, [C.c_uint64]),
+    "smh_pool_bytes": (C.c_uint64, []),
     "smh_compare_last_stats": (None, [C.POINTER(SmhCompareStats)]),
     "smh_compare_get_tuning": (None, [C.POINTER(SmhCompareTuning)]),
     "smh_compare_set_tuning": (C.c_int, [C.POINTER(SmhCompareTuning)]),

@@ -1071,6 +1071,10 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   const uint64_t n = same ? nr_elems : (inside ? nc_elems : nr_elems + nc_elems);
   if (n >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
   const bool want_cc = out.count_common || out.containment;
+  // the AUTO route's pair limit, clamped ONCE so that the work list sized from it always holds what the device-side
+  // choice (k_plan_route, same value) can produce: a tuning value never changes a result or raises
+  const uint64_t kWorkCapMax = 1ull << 26;
+  const uint64_t comp_limit = std::min<uint64_t>(tune.comp_pairs_limit, kWorkCapMax > cols.n ? kWorkCapMax - cols.n : 0);
   T.plan.ensure(sizeof(PlanState));
   PlanState* st = T.plan.as<PlanState>();
   HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PlanState), s));
@@ -1156,7 +1160,7 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   if (!same)
     hipLaunchKernelGGL(k_plan_ranges, dim3((cols.n + 255) / 256), dim3(256), 0, s, ckey, cols.n, rkey, rows.n, row_lo, row_hi,
                        (PlanState*)nullptr);
-  hipLaunchKernelGGL(k_plan_route, dim3(1), dim3(1), 0, s, st, tune.route, tune.visit_all_tiles, (unsigned long long)tune.comp_pairs_limit);
+  hipLaunchKernelGGL(k_plan_route, dim3(1), dim3(1), 0, s, st, tune.route, tune.visit_all_tiles, (unsigned long long)comp_limit);
   HIP_CHECK(hipGetLastError());
 
   // ---- the per-sketch records of the frequent hashes (which of them it holds, and where)
@@ -1199,8 +1203,8 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     // the route is taken when pairs <= comp_pairs_limit: every item holds a pair, every column adds at most one
     // partly filled item.  (A forced route on a huge block is capped; the overflow is reported.)
     uint64_t cap = (tune.route == kRouteComponents ? ((uint64_t)cols.n * ((rows.n + kRowsPerItem - 1) / kRowsPerItem))
-                                                   : tune.comp_pairs_limit) + cols.n;
-    if (cap > (1ull << 26)) cap = 1ull << 26;
+                                                   : comp_limit) + cols.n;
+    if (cap > kWorkCapMax) cap = kWorkCapMax;
     work_cap = (uint32_t)cap;
     T.cnt.ensure((size_t)cols.n * 4);
     T.work.ensure((size_t)work_cap * sizeof(CompWork));

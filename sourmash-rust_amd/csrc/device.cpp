@@ -14,13 +14,23 @@ void throw_hip(hipError_t e, const char* what, const char* file, int line) {
 // ---- block pool -----------------------------------------------------------------------------
 // hipMalloc / hipFree of the buffers a sketch is made of cost hundreds of microseconds each at
 // the sizes of the benchmark configurations (a 10 GB batch leaves 80 MB of hashes, the protein
-// share 270 MB) -- more than the sort that fills them.  Freed blocks are kept by size class
-// (eight classes per power of two: at most 12.5 % slack) up to kPoolLimit bytes and handed out again.
+// share 270 MB) -- more than the sort that fills them.  Freed blocks are kept per DEVICE and size
+// class (eight classes per power of two: at most 12.5 % slack) and handed out again.
+//  * The pool is invisible to any other allocator in the process (PyTorch's caching allocator in
+//    bench.py / distributed.py): memory parked here is memory torch cannot use.  It is therefore
+//    capped -- 1 GiB by default, SOURMASH_AMD_POOL_MB=<MiB> (0 = no pooling) or smh_pool_set_limit()
+//    change it -- and smh_release_workspace() hands everything back.
+//  * A block freed with sync=false may be handed out again at once.  That is safe for the one caller
+//    that does it (DeviceMirror) because every entry point of the library returns with its device
+//    work complete (include/sourmash_amd.h): no kernel of a finished call can still be reading it.
 namespace {
 std::mutex g_pool_mu;
-std::map<size_t, std::vector<void*>> g_pool;
+std::map<std::pair<int, size_t>, std::vector<void*>> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t kPoolLimit = 4ull << 30;
+size_t g_pool_limit = [] {
+  if (const char* e = std::getenv("SOURMASH_AMD_POOL_MB")) return (size_t)std::strtoull(e, nullptr, 10) << 20;
+  return (size_t)1 << 30;
+}();
 
 size_t size_class(size_t need) {
   if (need <= 4096) return 4096;
@@ -28,13 +38,18 @@ size_t size_class(size_t need) {
   const size_t step = (size_t)1 << (lg - 3);
   return (need + step - 1) / step * step;
 }
+int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
 }  // namespace
 
 void* device_pool_alloc(size_t need, size_t* cap) {
   const size_t c = size_class(need);
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    auto it = g_pool.find(c);
+    auto it = g_pool.find({current_device(), c});
     if (it != g_pool.end() && !it->second.empty()) {
       void* p = it->second.back();
       it->second.pop_back();
@@ -62,8 +77,8 @@ void device_pool_free(void* ptr, size_t cap, bool sync) {
   if (sync) (void)hipDeviceSynchronize();
   if (cap >= 4096 && size_class(cap) == cap) {
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    if (g_pool_bytes + cap <= kPoolLimit) {
-      g_pool[cap].push_back(ptr);
+    if (g_pool_bytes + cap <= g_pool_limit) {
+      g_pool[{current_device(), cap}].push_back(ptr);
       g_pool_bytes += cap;
       return;
     }
@@ -76,6 +91,19 @@ void device_pool_trim() {
   for (auto& kv : g_pool) for (void* p : kv.second) (void)hipFree(p);
   g_pool.clear();
   g_pool_bytes = 0;
+}
+
+void device_pool_set_limit(size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pool_limit = bytes;
+    if (g_pool_bytes <= bytes) return;
+  }
+  device_pool_trim();
+}
+size_t device_pool_bytes() {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  return g_pool_bytes;
 }
 
 void DeviceBuffer::ensure(size_t need) {

@@ -29,6 +29,8 @@ namespace smh {
 void* device_pool_alloc(size_t need, size_t* cap);
 void device_pool_free(void* ptr, size_t cap, bool sync);
 void device_pool_trim();   // hipFree everything the pool holds
+void device_pool_set_limit(size_t bytes);   // cap on the bytes parked in the pool (default 1 GiB, SOURMASH_AMD_POOL_MB)
+size_t device_pool_bytes();
 
 // grow-only device allocation (never shrinks; released with the context or explicitly)
 struct DeviceBuffer {

@@ -213,7 +213,7 @@ uint64_t kmerminhash_get_min_idx(KmerMinHash* ptr, uint64_t idx) {
 }
 
 void kmerminhash_mins_push(KmerMinHash* ptr, uint64_t val) {
-  pad_void([&] { require(ptr, "ptr"); ptr->materialize(); ptr->mins.push_back(val); });
+  pad_void([&] { require(ptr, "ptr"); ptr->materialize(); ptr->mins.w().push_back(val); });
 }
 
 const uint64_t* kmerminhash_get_abunds(KmerMinHash* ptr) {
@@ -799,6 +799,9 @@ int smh_compare_set_tuning(const SmhCompareTuning* in) {
 int smh_release_workspace(void) {
   return pad_code([&] { smh::Engine::get().release_workspace(); });
 }
+
+void smh_pool_set_limit(uint64_t bytes) { (void)pad_code([&] { smh::device_pool_set_limit((size_t)bytes); }); }
+uint64_t smh_pool_bytes(void) { return (uint64_t)smh::device_pool_bytes(); }
 
 void smh_profile_enable(int on) {
   (void)pad_code([&] { smh::Device::get().profile_enable(on != 0); });

@@ -21,7 +21,7 @@ namespace smh {
 
 KmerMinHash::KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track)
     : num(n), ksize(k), is_protein(prot), seed(seed_), max_hash(mx), has_abunds(track) {
-  mins.reserve(n > 0 ? n : 1000);
+  mins.w().reserve(n > 0 ? n : 1000);
   if (track) abunds.reserve(mins.capacity());
 }
 
@@ -49,18 +49,6 @@ DeviceMirror::~DeviceMirror() {
   if (ptr) device_pool_free(ptr, cap, false);
 }
 
-// order-sensitive 64-bit checksum of a word array, four independent lanes
-static uint64_t words_checksum(const uint64_t* p, size_t n) {
-  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
-  size_t i = 0;
-  for (; i + 4 <= n; i += 4)
-    for (int k = 0; k < 4; k++) h[k] = (h[k] ^ p[i + k]) * 0xFF51AFD7ED558CCDull + 0x2545F4914F6CDD1Dull;
-  for (; i < n; i++) h[0] = (h[0] ^ p[i]) * 0xFF51AFD7ED558CCDull + 0x2545F4914F6CDD1Dull;
-  uint64_t r = 0;
-  for (int k = 0; k < 4; k++) { r = (r ^ h[k]) * 0xC4CEB9FE1A85EC53ull; r ^= r >> 29; }
-  return r;
-}
-
 void KmerMinHash::materialize() const {
   flush_pending();
   if (!dev) return;
@@ -68,8 +56,9 @@ void KmerMinHash::materialize() const {
   std::lock_guard<std::recursive_mutex> lock(d.mutex());
   hipStream_t s = d.stream();
   const size_t n = (size_t)dev->n;
-  mins.resize(n);
-  if (n) HIP_CHECK(hipMemcpyAsync(mins.data(), dev->uniq.ptr, n * 8, hipMemcpyDeviceToHost, s));
+  std::vector<uint64_t>& hm = mins.w();
+  hm.resize(n);
+  if (n) HIP_CHECK(hipMemcpyAsync(hm.data(), dev->uniq.ptr, n * 8, hipMemcpyDeviceToHost, s));
   std::vector<uint32_t> st;
   if (has_abunds && n) {
     st.resize(n);
@@ -85,7 +74,7 @@ void KmerMinHash::materialize() const {
   std::swap(m->ptr, dev->uniq.ptr);
   std::swap(m->cap, dev->uniq.bytes);
   m->n = n;
-  m->sum = words_checksum(mins.data(), n);
+  m->gen = mins.generation();
   mirror = m;
   dev.reset();
 }
@@ -103,23 +92,23 @@ void KmerMinHash::add_hash(uint64_t hash) {
   const uint64_t current_max = mins.empty() ? UINT64_MAX : mins.back();
   if (!(hash <= max_hash || max_hash == 0)) return;
   if (mins.empty()) {
-    mins.push_back(hash);
+    mins.w().push_back(hash);
     if (has_abunds) abunds.push_back(1);
     return;
   }
   if (hash <= max_hash || current_max > hash || (uint32_t)mins.size() < num) {
     size_t pos = std::lower_bound(mins.begin(), mins.end(), hash) - mins.begin();
     if (pos == mins.size()) {
-      mins.push_back(hash);
+      mins.w().push_back(hash);
       if (has_abunds) abunds.push_back(1);
     } else if (mins[pos] != hash) {
-      mins.insert(mins.begin() + pos, hash);
+      { auto& v = mins.w(); v.insert(v.begin() + pos, hash); }
       if (has_abunds) {
         if (pos > abunds.size()) throw_panic("insertion index is out of bounds");
         abunds.insert(abunds.begin() + pos, 1);
       }
       if (num != 0 && mins.size() > (size_t)num) {
-        mins.pop_back();
+        mins.w().pop_back();
         if (has_abunds && !abunds.empty()) abunds.pop_back();
       }
     } else if (has_abunds) {
@@ -207,7 +196,7 @@ void KmerMinHash::merge(const KmerMinHash& other) {
   if (o_has && oai < other.abunds.size())
     mab.insert(mab.end(), other.abunds.begin() + oai, other.abunds.end());
   if (!(merged.size() < (size_t)num || num == 0)) merged.resize(num);
-  mins.swap(merged);
+  mins.w().swap(merged);
   abunds.swap(mab);
   has_abunds = true;  // Q5: Some(..) even when nothing was tracked, and never truncated
 }
@@ -479,7 +468,7 @@ Mode mode_of(const KmerMinHash& mh) {
 void apply_scaled(KmerMinHash& mh, Delta& d) {
   if (d.uniq.empty()) return;
   if (mh.mins.empty()) {
-    mh.mins.swap(d.uniq);
+    mh.mins.w().swap(d.uniq);
     if (mh.has_abunds) {
       mh.abunds.resize(mh.mins.size());
       for (size_t k = 0; k < mh.mins.size(); k++) mh.abunds[k] = d.run_start[k + 1] - d.run_start[k];
@@ -506,7 +495,7 @@ void apply_scaled(KmerMinHash& mh, Delta& d) {
       i++; j++;
     }
   }
-  mh.mins.swap(nm);
+  mh.mins.w().swap(nm);
   if (mh.has_abunds) mh.abunds.swap(na);
 }
 
@@ -564,7 +553,7 @@ void apply_num(KmerMinHash& mh, const Delta& d, Engine& E, hipStream_t s) {
     }
     na.back() = (last_old ? last_old_ab : 0) + c;
   }
-  mh.mins.swap(nm);
+  mh.mins.w().swap(nm);
   if (track) mh.abunds.swap(na);
 }
 
@@ -748,7 +737,7 @@ bool KmerMinHash::merge_on_device(const KmerMinHash& other) {
   }
   HIP_CHECK(hipStreamSynchronize(s));
   if (!(nm.size() < (size_t)num || num == 0)) nm.resize(num);  // abundances are NOT truncated (Q5/Q6)
-  mins.swap(nm);
+  mins.w().swap(nm);
   abunds.swap(na_sum);   // untracked inputs: Some(vec![]) like the reference
   has_abunds = true;
   return true;
@@ -1527,18 +1516,18 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
-// The device copy of mh.mins: reused while (length, checksum) still match the host vector,
-// re-created (never overwritten: a published mirror is immutable) otherwise.
+// The device copy of mh.mins: reused while the vector's generation is the one the copy was made at
+// (TrackedMins: every mutation route bumps it -- exact, O(1), nothing is read), re-created (never
+// overwritten: a published mirror is immutable) otherwise.
 const uint64_t* Engine::mirror_of(const KmerMinHash& mh, hipStream_t s) {
   mh.materialize();
   const size_t n = mh.mins.size();
-  const uint64_t sum = words_checksum(mh.mins.data(), n);
-  if (!mh.mirror || mh.mirror->n != n || mh.mirror->sum != sum) {
+  if (!mh.mirror || mh.mirror->gen != mh.mins.generation()) {
     auto m = std::make_shared<DeviceMirror>();
     m->ptr = device_pool_alloc(n * 8 + 8, &m->cap);
     if (n) HIP_CHECK(hipMemcpyAsync(m->ptr, mh.mins.data(), n * 8, hipMemcpyHostToDevice, s));  // pageable source: staged before return
     m->n = n;
-    m->sum = sum;
+    m->gen = mh.mins.generation();
     mh.mirror = m;
   }
   return reinterpret_cast<const uint64_t*>(mh.mirror->ptr);

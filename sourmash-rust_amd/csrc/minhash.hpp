@@ -38,15 +38,43 @@ struct DeviceSketch {
   bool has_runs = false;
 };
 
+// The `mins` vector with a generation counter: reads go through the const forwarding methods, every
+// mutation goes through w(), which bumps the generation BEFORE handing out the vector.  A device
+// mirror made at generation g is valid exactly while generation() == g -- an O(1), exact test (no
+// non-const access to the vector exists outside w(), so no mutation route can be missed).
+class TrackedMins {
+ public:
+  using Vec = std::vector<uint64_t>;
+  size_t size() const { return v_.size(); }
+  bool empty() const { return v_.empty(); }
+  size_t capacity() const { return v_.capacity(); }
+  const uint64_t& operator[](size_t i) const { return v_[i]; }
+  const uint64_t& back() const { return v_.back(); }
+  const uint64_t* data() const { return v_.data(); }
+  Vec::const_iterator begin() const { return v_.begin(); }
+  Vec::const_iterator end() const { return v_.end(); }
+  const Vec& get() const { return v_; }
+  operator const Vec&() const { return v_; }
+  Vec& w() { ++gen_; return v_; }
+  TrackedMins& operator=(const Vec& o) { ++gen_; v_ = o; return *this; }
+  TrackedMins& operator=(Vec&& o) { ++gen_; v_ = std::move(o); return *this; }
+  TrackedMins& operator=(const TrackedMins& o) { ++gen_; v_ = o.v_; return *this; }
+  TrackedMins() = default;
+  TrackedMins(const TrackedMins& o) : v_(o.v_) {}
+  uint64_t generation() const { return gen_; }
+ private:
+  Vec v_;
+  uint64_t gen_ = 1;
+};
+
 // Device copy of a host-resident sketch's `mins`, kept between pairwise calls: compare / count_common
-// through the one-pair-per-call ABI would otherwise upload both sketches every time.  Validated by
-// (length, checksum of the words) against the host vector before every use, so no mutation site can
-// leave it stale; never modified in place once published.
+// through the one-pair-per-call ABI would otherwise upload both sketches every time.  Valid while the
+// sketch's TrackedMins generation is the one it was made at; never modified in place once published.
 struct DeviceMirror {
-  void* ptr = nullptr;   // from mirror_alloc() (pooled by power-of-two size) or adopted from a DeviceSketch
+  void* ptr = nullptr;   // from the device block pool, or adopted from a DeviceSketch
   size_t cap = 0;
   size_t n = 0;
-  uint64_t sum = 0;
+  uint64_t gen = 0;      // TrackedMins::generation() of the vector this is a copy of
   DeviceMirror() = default;
   DeviceMirror(const DeviceMirror&) = delete;
   DeviceMirror& operator=(const DeviceMirror&) = delete;
@@ -59,7 +87,7 @@ struct KmerMinHash {
   bool is_protein = false;
   uint64_t seed = 42;
   uint64_t max_hash = 0;
-  mutable std::vector<uint64_t> mins;
+  mutable TrackedMins mins;
   bool has_abunds = false;         // Option<Vec<u64>>::is_some()
   mutable std::vector<uint64_t> abunds;
   mutable std::shared_ptr<DeviceSketch> dev;  // non-null: the state lives here, mins/abunds are empty
@@ -71,7 +99,7 @@ struct KmerMinHash {
   mutable std::vector<uint64_t> pend_off;
   void flush_pending() const;
 
-  KmerMinHash() { mins.reserve(1000); }  // Default, src/lib.rs:48-60
+  KmerMinHash() { mins.w().reserve(1000); }  // Default, src/lib.rs:48-60
   KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track);  // 142-174
   KmerMinHash(const KmerMinHash& o);             // Clone: brings a device-resident state to the host first
   KmerMinHash& operator=(const KmerMinHash& o);

@@ -380,7 +380,7 @@ bool sketch_equal(const KmerMinHash& a, const KmerMinHash& b) {
   a.materialize();
   b.materialize();
   return a.num == b.num && a.ksize == b.ksize && a.is_protein == b.is_protein && a.seed == b.seed &&
-         a.max_hash == b.max_hash && a.mins == b.mins && a.has_abunds == b.has_abunds &&
+         a.max_hash == b.max_hash && a.mins.get() == b.mins.get() && a.has_abunds == b.has_abunds &&
          (!a.has_abunds || a.abunds == b.abunds);
 }
 

@@ -100,15 +100,15 @@ def test_row_sharded_matrix_and_sketch_union_gloo(n_total, coracle):
 
 def test_bench_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` (the shape of the driver's command, no torchrun around it) must
-    start two ranks by itself.  There is no GPU here, so each rank stops at its first line of GPU
-    set-up -- which proves the launch went through: both ranks ran, with RANK/WORLD_SIZE set."""
+    start two ranks by itself.  The children see NO GPU (HIP/CUDA_VISIBLE_DEVICES are emptied before
+    anything is launched, so this behaves the same on a CPU box, a 1-GPU box and a GPU node): each
+    rank stops at its first line of GPU set-up -- which proves the launch went through: both ranks
+    ran, with RANK/WORLD_SIZE set.  The real 2-rank run is tests/test_gpu_multirank.py."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
-    import torch
-    if torch.cuda.device_count() >= 2:
-        pytest.skip("a multi-GPU machine: the real run is the driver's")
     assert r.returncode != 0
     text = r.stdout + r.stderr
     assert "rank 0 needs cuda:0" in text and "rank 1 needs cuda:1" in text
