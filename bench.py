@@ -9,10 +9,14 @@ metric = k-mers hashed per second, whole job (all ranks).  Records are sharded a
 (weak scaling: 10 GB per GPU); there is no data-path collective in the sketch step.
 
 Secondary (configs[2]/[3], reported in the same JSON line under "compare"): all-vs-all Jaccard
-matrix of num=2000 signatures, rows sharded across ranks with one RCCL all-gather of the
-signatures -- on the family-structured collection of SURVEY.md 8d AND on the same collection with
-one hash shared by every signature (a contaminant k-mer: one connected component, every tile of
-the matrix has to be walked), each next to the C oracle on the host cores.
+matrix of num=2000 signatures.  N = 10 000 at EVERY world size (strong scaling: the 10 000 x 10 000
+matrix of configs[3] on 1, 2, 4, 8 GPUs; the 1 000 x 1 000 block of configs[2] additionally at
+world 1), row blocks sharded across ranks: all-gather of the signatures, the dictionary pre-pass
+sharded by hash range + one all-gather of its shares, every rank walks the pairs its rows OWN
+(half of its row block: the walk is symmetric) and one all-to-all hands over the mirrored blocks
+(sourmash-rust_amd/distributed.py) -- on the family-structured collection of SURVEY.md 8d, on the
+same collection with one hash shared by every signature (a contaminant k-mer), and on ONE family
+(every pair has to be walked), each next to the C oracle on the host cores.
 
 Also on the line: "roofline" for the dominant kernel (k_dna_rolling) from HIP events recorded by the
 library on the stream it launches on, and "cpu_baseline": the C oracle (a port of the reference's
@@ -46,6 +50,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 256 * 4                    # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 VALU_CYCLES = 2.0                  # ... a wave64 VALU instruction issues over 2 cycles
 MAX_CLOCK_HZ = 2.4e9               # ... max clock
+LDS_READ_B32_PEAK_TBS = 75.0       # ... LDS aggregate for ds_read_b32, every CU streaming
 CONTAMINANT = 1                    # the hash every signature of the one-component collection shares
 
 
@@ -99,9 +104,12 @@ def cpu_worker(argv):
                           "self_compare": j}))
     elif kind == "compare":
         n_sig, first, last, budget, kind_id = int(argv[2]), int(argv[3]), int(argv[4]), float(argv[5]), int(argv[6])
-        from __graft_entry__ import load_package
-        load_package()
-        sigs = collection(kind_id, 0, n_sig)
+        if len(argv) > 7:
+            sigs = np.load(argv[7], mmap_mode="r")          # the parent's copy of the collection (generation not timed)
+        else:
+            from __graft_entry__ import load_package
+            load_package()
+            sigs = collection(kind_id, 0, n_sig)
         cols = [sigs[i] for i in range(n_sig)]
         rows_done, spent, jac = 0, 0.0, []
         for r in range(first, last):
@@ -181,6 +189,7 @@ def main():
     ap.add_argument("--compare-n", type=int, default=0, help="signatures in the matrix (0 = by --gpus)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-core sketch sample (others scale with it)")
     ap.add_argument("--no-compare", action="store_true")
+    ap.add_argument("--host-gb", type=float, default=2.0, help="GB of the workload also timed from HOST memory (PCIe-inclusive; 0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -302,21 +311,29 @@ def main():
 
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
+    cmp_outs = {}
     if not args.no_compare:
         from sourmash_rust_amd import distributed as D, matrix as MX
-        n_sig = args.compare_n or {1: 1000, 2: 2500, 4: 5000, 8: 10000}.get(world, 1000 * world)
-        lo, hi, per = D.shard_range(n_sig, world, rank)
-        local_sigs = np.zeros((per, NUM), dtype=np.uint64)
-        local_sigs[: hi - lo] = collection(0, lo, hi)
+        # strong scaling: N fixed at 10 000 (configs[3]) whatever the world size; world 1 also runs configs[2]'s 1 000
+        sizes = [args.compare_n] if args.compare_n else ([10000, 1000] if world == 1 else [10000])
 
-        def time_collection(sig_block):
-            mine = torch.from_numpy(sig_block.view(np.int64)).cuda()
+        def prof(name):
+            ms, k = C.c_double(), C.c_uint64()
+            L.smh_profile_get(name, C.byref(ms), C.byref(k))
+            return ms.value, k.value
 
-            def compare_step():
-                # rows sharded by contiguous blocks; ONE all-gather (RCCL over xGMI) of the signatures
-                return D.compare_matrix_sharded(mine, n_sig, NUM, want=("jaccard",))
+        def time_collection(n_sig, kind_id):
+            lo, hi, per = D.shard_range(n_sig, world, rank)
+            blk = np.zeros((per, NUM), dtype=np.uint64)
+            blk[: hi - lo] = collection(kind_id, lo, hi)
+            mine = torch.from_numpy(blk.view(np.int64)).cuda()
+
+            def compare_step(timings=None):
+                return D.compare_matrix_sharded(mine, n_sig, NUM, want=("jaccard",), timings=timings)
 
             out = compare_step()
+            L.smh_profile_reset()
+            L.smh_profile_enable(1)
             barrier()
             t0 = time.perf_counter()
             reps = 3
@@ -324,6 +341,10 @@ def main():
                 out = compare_step()
             barrier()
             cdt = max_over_ranks((time.perf_counter() - t0) / reps)
+            L.smh_profile_enable(0)
+            kern = {k: prof(k.encode()) for k in ("compare_tiled", "compare_comp", "compare_fill")}
+            phases = {}
+            compare_step(phases)             # one more, untimed pass with a synchronisation after every phase
             diag_ok = True
             if hi > lo:
                 j = out["jaccard"]
@@ -335,33 +356,102 @@ def main():
                 dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             st = MX.last_stats()
             walked = min(st["tiles_visited"] * st["pairs_per_tile"], (hi - lo) * n_sig)   # pairs walked on this rank
-            return out, {"seconds": cdt, "pairs_per_s": n_sig * n_sig / cdt, "self_jaccard_is_1": bool(okt.item()),
-                         "route": st["route"], "tiles_visited": st["tiles_visited"], "tiles_total": st["tiles_total"],
-                         "pairs_per_tile": st["pairs_per_tile"], "rank0_pairs_walked": walked,
-                         "rank0_pairs_walked_per_s": walked / cdt,
-                         "rank0_union_elements_walked_per_s": walked * NUM / cdt}
+            kname = "compare_tiled" if st["route"] == "tiled" else "compare_comp"
+            kms = kern[kname][0] / max(1, kern[kname][1])
+            rec = {"seconds": cdt, "pairs_per_s": n_sig * n_sig / cdt, "self_jaccard_is_1": bool(okt.item()),
+                   "route": st["route"], "tiles_visited": st["tiles_visited"], "tiles_total": st["tiles_total"],
+                   "pairs_per_tile": st["pairs_per_tile"], "rank0_pairs_walked": walked,
+                   "rank0_kernel": "k_compare_" + ("tiled" if st["route"] == "tiled" else "comp"), "rank0_kernel_ms": kms,
+                   "rank0_fill_ms": kern["compare_fill"][0] / max(1, kern["compare_fill"][1]),
+                   "rank0_pairs_walked_per_s": walked / (kms * 1e-3) if kms > 0 else None,
+                   "rank0_union_elements_walked_per_s": walked * NUM / (kms * 1e-3) if kms > 0 else None,
+                   "rank0_phase_ms": {k: v * 1e3 for k, v in phases.items()}}
+            return out, rec
 
-        def local_block(kind_id):
-            blk = np.zeros((per, NUM), dtype=np.uint64)
-            blk[: hi - lo] = collection(kind_id, lo, hi)
-            return blk
-
-        out_fam, fam = time_collection(local_sigs)
-        out_one, onec = time_collection(local_block(1))
-        out_den, dense = time_collection(local_block(2))
-        compare = {"metric": "signature pairs compared/sec (ordered pairs, num=%d)" % NUM, "value": fam["pairs_per_s"],
-                   "unit": "pairs/s", "n_signatures": n_sig, "seconds": fam["seconds"], "self_jaccard_is_1": fam["self_jaccard_is_1"],
+        per_size = {}
+        for n_sig in sizes:
+            per_size[n_sig] = {}
+            for key, kind_id in (("families", 0), ("one_component", 1), ("one_family", 2)):
+                out, rec = time_collection(n_sig, kind_id)
+                per_size[n_sig][key] = rec
+                if world == 1 and n_sig == min(sizes):
+                    cmp_outs[key] = out                      # kept for the CPU-baseline check below (the smaller block)
+                del out
+        head = per_size[sizes[0]]
+        dense = head["one_family"]
+        # roofline of the matrix kernel on the collection where every pair is walked (rank 0's kernel, HIP events)
+        cmp_roof = None
+        if dense["rank0_kernel_ms"] > 0 and dense["route"] == "tiled":
+            pmc = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_compare_tiled.json")))
+            except Exception:
+                pass
+            walked, kms = dense["rank0_pairs_walked"], dense["rank0_kernel_ms"]
+            lds_bytes = pmc.get("lds_bytes_per_walked_pair") * walked if pmc and pmc.get("lds_bytes_per_walked_pair") else None
+            achieved = lds_bytes / (kms * 1e-3) / 1e12 if lds_bytes else None
+            cmp_roof = {"kernel": "k_compare_tiled", "bound": "lds", "unit": "TB/s", "peak": LDS_READ_B32_PEAK_TBS,
+                        "kernel_ms_avg": kms, "pairs_walked": walked, "n_signatures": sizes[0],
+                        "achieved": achieved, "frac": achieved / LDS_READ_B32_PEAK_TBS if achieved else None,
+                        "lds_bytes": lds_bytes,
+                        "lds_bytes_source": ("profiles/r03_pmc_compare_tiled.json (SQ_INSTS_LDS of a separate rocprofv3 --pmc pass "
+                                             "x 64 lanes x 4 B per walked pair; committed, not measured in this run)") if lds_bytes else None,
+                        "effective_bytes": walked * ((NUM + NUM) * 8 + 8),
+                        "effective_TBps": walked * ((NUM + NUM) * 8 + 8) / (kms * 1e-3) / 1e12,
+                        "compulsory_hbm_bytes": sizes[0] * NUM * 8 + D.shard_range(sizes[0], world, 0)[2] * sizes[0] * 8,
+                        "valu_insts_per_walked_pair": pmc.get("valu_insts_per_walked_pair") if pmc else None,
+                        "note": "integer compare/indexing, no MFMA.  'effective' = SURVEY.md 8d's (|A|+|B|)*8+8 B per walked pair, "
+                                "served from LDS/L2 (may exceed the HBM peak: it is not HBM traffic); 'achieved' = actual ds_read "
+                                "bytes against the guide's ds_read_b32 aggregate (~75 TB/s); compulsory HBM traffic is "
+                                "N*16 KB in + rows*N*8 B out"}
+        compare = {"metric": "signature pairs compared/sec (ordered pairs delivered, num=%d)" % NUM, "value": head["families"]["pairs_per_s"],
+                   "unit": "pairs/s", "n_signatures": sizes[0], "seconds": head["families"]["seconds"],
+                   "scaling": "strong: N = %d signatures at every world size (the %d x %d matrix of BASELINE configs[3])" % (sizes[0], sizes[0], sizes[0]),
+                   "symmetry": "used: all signatures have one num, so the union walk is symmetric; row i owns the pairs (i, j) with "
+                               "(j - i) mod N < N/2, every rank walks the pairs its rows own and the mirrored blocks are exchanged "
+                               "(world 1: upper triangle + mirror writes).  pairs/s counts ORDERED pairs delivered (N^2)",
+                   "self_jaccard_is_1": all(v["self_jaccard_is_1"] for v in head.values()),
                    "collection": "50 families of related signatures (SURVEY.md 8d): pairs across families share no hash and are "
                                  "filled without being walked (DESIGN.md 3.4) -- a property of the collection, not of the kernel",
-                   "families": fam,
-                   "one_component": dict(onec, collection="the same signatures with one hash (a contaminant k-mer) shared by all: one "
-                                                          "connected component; the frequent hash is set aside and pairs that share "
-                                                          "nothing else are decided from per-sketch records (DESIGN.md 3.4)"),
-                   "one_family": dict(dense, collection="ONE family: every pair shares hundreds of hashes, every pair has to be walked -- "
-                                                        "the kernel's own rate"),
+                   "families": head["families"],
+                   "one_component": dict(head["one_component"], collection="the same signatures with one hash (a contaminant k-mer) shared by all: one "
+                                                                            "connected component; the frequent hash is set aside and pairs that share "
+                                                                            "nothing else are decided from per-sketch records (DESIGN.md 3.4)"),
+                   "one_family": dict(head["one_family"], collection="ONE family: every pair shares hundreds of hashes, every pair has to be walked -- "
+                                                                     "the kernel's own rate"),
+                   "roofline": cmp_roof,
                    "note": "'union elements walked' = pairs walked x num: with two full num-sketches the truncated union walk ends "
                            "after exactly num elements (reference src/lib.rs:470-499); per walked pair the effective traffic of "
                            "SURVEY.md 8d is 32 008 B served from LDS/L2, compulsory HBM traffic is N*16 KB in + N^2*8 B out"}
+        for n_sig in sizes[1:]:
+            compare["block_%d" % n_sig] = dict(per_size[n_sig], workload="BASELINE configs[2]: %d x %d all-vs-all, num=%d" % (n_sig, n_sig, NUM))
+
+    # ---------------------------------------------------------------- host input (PCIe-inclusive, reported beside value)
+    host_input = None
+    if rank == 0 and world == 1 and args.host_gb > 0:
+        nh = min(int(args.host_gb * 1e9), total) // REC_LEN * REC_LEN
+        host = seq[:nh].cpu().numpy()                     # pageable host memory, like a caller's buffer
+        hoff = np.arange(nh // REC_LEN + 1, dtype=np.uint64) * np.uint64(REC_LEN)
+        best = None
+        for _ in range(3):
+            mhh = pkg.KmerMinHash(0, K, False, 42, MAX_HASH, False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = L.smh_add_sequences(mhh._p, host.ctypes.data_as(C.c_char_p), hoff.ctypes.data_as(C.POINTER(C.c_uint64)), nh // REC_LEN, True)
+            n_ret = len(mhh)
+            dth = time.perf_counter() - t0
+            assert rc == 0
+            best = dth if best is None else min(best, dth)
+        ref = pkg.KmerMinHash(0, K, False, 42, MAX_HASH, False)
+        ref.add_sequences_dev(seq.data_ptr(), nh, hoff, True, stream)
+        assert len(ref) == n_ret and (ref.mins_np() == mhh.mins_np()).all(), "host-input sketch differs from the device-input sketch"
+        host_input = {"bytes": nh, "seconds": best, "GB_per_s": nh / best / 1e9,
+                      "kmers_per_s": (nh // REC_LEN) * (REC_LEN - K + 1) / best,
+                      "what": "the same workload handed over as HOST bytes (pageable memory, what the reference's boundary passes: "
+                              "smh_add_sequences = kmerminhash_add_sequence per record): upload in chunks on a second stream while the "
+                              "chunks already on the device are hashed.  PCIe-inclusive; never `value`.  Sketch equal to the "
+                              "device-input sketch of the same bytes"}
+        del host
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
@@ -400,27 +490,32 @@ def main():
                "config0": {"workload": "BASELINE configs[0]: 1 MB synthetic DNA, k=31, num=500, compare to itself",
                            "sketch_kmers_per_s": r0["kmers"] / r0["sketch_seconds"], "compare_pairs_per_s": 1.0 / r0["compare_seconds"],
                            "self_compare": r0["self_compare"], "cores": 1, "gpu_sketch_equal": True}}
-        if compare is not None:
-            n_sig = compare["n_signatures"]
-            for key, contaminated, gpu_out in (("families", 0, out_fam), ("one_component", 1, out_one), ("one_family", 2, out_den)):
-                gj = gpu_out["jaccard"].cpu().numpy()
-                (rc1, pc1), = run_workers([["compare", n_sig, 0, n_sig, 2.0 * scale, contaminated]])
+        if compare is not None and cmp_outs:
+            n_sig = min(sizes)
+            tmpd = tempfile.mkdtemp(prefix="smh_sigs_")
+            for key, kind_id in (("families", 0), ("one_component", 1), ("one_family", 2)):
+                gj = cmp_outs[key]["jaccard"].cpu().numpy()
+                path = os.path.join(tmpd, "sigs%d.npy" % kind_id)
+                np.save(path, collection(kind_id, 0, n_sig))
+                (rc1, pc1), = run_workers([["compare", n_sig, 0, n_sig, 2.0 * scale, kind_id, path]])
                 j1 = np.load(pc1)
                 assert (gj[: j1.shape[0]] == j1).all(), "GPU matrix differs from the CPU oracle (%s, 1-core rows)" % key
                 per_w = max(1, n_sig // cores)
-                cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, 2.0 * scale, contaminated] for w in range(cores)
+                cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, 2.0 * scale, kind_id, path] for w in range(cores)
                                   if (w + 1) * per_w <= n_sig])
                 for w, (r, p) in enumerate(cw):
                     jw = np.load(p)
                     assert (gj[w * per_w: w * per_w + jw.shape[0]] == jw).all(), "GPU matrix differs from the CPU oracle (%s, worker %d)" % (key, w)
-                compare[key]["cpu_baseline"] = {
-                    "value": rc1["rows"] * n_sig / rc1["seconds"], "unit": "pairs/s", "cores": 1, "kind": "port",
+                target = compare[key] if n_sig == sizes[0] else compare["block_%d" % n_sig][key]
+                target["cpu_baseline"] = {
+                    "value": rc1["rows"] * n_sig / rc1["seconds"], "unit": "pairs/s", "cores": 1, "kind": "port", "n_signatures": n_sig,
                     "sample": "rows 0..%d x all %d columns through the C oracle's compare (two merges + two intersections per "
                               "pair, reference src/lib.rs:470-508); equal to the GPU's rows" % (rc1["rows"] - 1, n_sig),
                     "all_cores": {"value": sum(r["rows"] for r, _ in cw) * n_sig / max(r["seconds"] for r, _ in cw),
                                   "cores": len(cw), "host_cores": cores,
                                   "sample": "%d workers, one row block each (%d rows in all), equal to the GPU's rows"
                                             % (len(cw), sum(r["rows"] for r, _ in cw))}}
+                os.remove(path)
 
     if rank == 0:
         line = {
@@ -439,6 +534,7 @@ def main():
                          "note": "1 B per k-mer: the path is integer-VALU bound, not HBM bound (SURVEY.md 8d; DESIGN.md 'Roofline'); "
                                  "valu_bound prices the kernel against the guide's VALU issue peak"},
             "cpu_baseline": cpu,
+            "host_input": host_input,
             "compare": compare,
         }
         print(json.dumps(line))

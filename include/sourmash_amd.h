@@ -90,6 +90,39 @@ int smh_compare_block_dev(const uint64_t *row_hashes_dev, const uint64_t *row_of
                           uint32_t num, double *jaccard_dev, uint64_t *common_dev, uint64_t *size_dev,
                           uint64_t *count_common_dev, double *containment_dev, void *stream);
 
+/* The all-vs-all matrix of ONE collection resident in HBM, optionally computed by `world` cooperating ranks (one process
+ * per GPU) that each hold the whole collection (after an all-gather of the signatures):
+ *   1. smh_collection_begin   rank g sorts slice g of hash space (1/world of the pooled hashes: the dictionary pre-pass
+ *                             is sharded, not replicated) and leaves its findings in a "share" of smh_collection_share_bytes()
+ *                             bytes at smh_collection_share() (device memory, same size on every rank);
+ *   2. the caller all-gathers the shares (RCCL; world == 1: nothing to do);
+ *   3. smh_collection_finish  assembles the dictionary from the gathered shares (world x share_bytes, rank-major; NULL when
+ *                             world == 1): dense ranks of every hash, connected components, frequent hashes, range tables;
+ *   4. smh_collection_compare rows [row_lo, row_hi) x ALL columns, outputs row-major (row_hi - row_lo) x n in device memory
+ *                             (any may be NULL).  Every pair equals KmerMinHash::compare / count_common of the two sketches
+ *                             (reference src/lib.rs:428-436, 470-508) with the one `num` given.  ownership:
+ *        0  every pair of the block is computed here;
+ *        1  the block is the whole matrix: upper triangle + mirrors (the walk is symmetric when there is one num);
+ *        2  the block is this rank's share of a matrix the ranks compute together: row i OWNS the pairs (i, j) with
+ *           (j - i) mod n < n/2 (ties: i < j) -- every unordered pair has one owner, every row owns n/2 pairs.  Owned
+ *           pairs, pairs whose column is one of the block's own rows, and pairs that share no (non-frequent) hash are
+ *           final when the call returns; the others must be taken from their owner's rank, transposed
+ *           (sourmash-rust_amd/distributed.py does exactly that with one all-to-all).
+ * The dictionary can serve any number of compare calls.  offsets: n+1 HOST entries, sketch i = hashes_dev[offsets[i] ..
+ * offsets[i+1]) ascending and distinct; hashes_dev must stay valid until smh_collection_free. */
+typedef struct SmhCollection SmhCollection;
+SmhCollection *smh_collection_begin(const uint64_t *hashes_dev, const uint64_t *offsets, uint32_t n, uint32_t world,
+                                    uint32_t rank, void *stream);
+uint64_t smh_collection_share_bytes(const SmhCollection *collection);
+const void *smh_collection_share(const SmhCollection *collection);
+/* the share copied to dst_dev (e.g. this rank's slot of the all-gather's output buffer) */
+int smh_collection_share_to(const SmhCollection *collection, void *dst_dev, void *stream);
+int smh_collection_finish(SmhCollection *collection, const void *gathered_dev, void *stream);
+int smh_collection_compare(SmhCollection *collection, uint32_t row_lo, uint32_t row_hi, uint32_t num, uint32_t ownership,
+                           double *jaccard_dev, uint64_t *common_dev, uint64_t *size_dev, uint64_t *count_common_dev,
+                           double *containment_dev, void *stream);
+void smh_collection_free(SmhCollection *collection);
+
 /* One query against many nodes: LinearIndex::find (reference src/index/linear.rs:25-45) with
  * search_minhashes / search_minhashes_containment (reference src/index/search.rs:3-9).  Writes the
  * positions of the nodes whose node.similarity(query) -- or node.containment(query) =

@@ -103,6 +103,14 @@ _SIGS = {
     "smh_compare_block": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, f64p, u64p, u64p, u64p, f64p]),
     "smh_compare_block_dev": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_void_p, u64p, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smh_collection_begin": (C.c_void_p, [C.c_void_p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "smh_collection_share_bytes": (C.c_uint64, [C.c_void_p]),
+    "smh_collection_share": (C.c_void_p, [C.c_void_p]),
+    "smh_collection_share_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smh_collection_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smh_collection_compare": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "smh_collection_free": (None, [C.c_void_p]),
     "smh_find": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_double, C.c_bool, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smh_most_common": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), u64p]),
     "smh_index_new": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_uint32]),

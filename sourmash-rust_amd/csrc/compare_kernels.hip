@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include <cstdlib>
@@ -279,6 +280,28 @@ __global__ __launch_bounds__(256) void k_compare_few(SketchSet many, SketchSet f
 // each wave takes rows of the same component -- slots [r0, r1) of the row order -- and computes
 // the pair exactly like k_compare_few.  No rank encoding is needed on this route, and a pair
 // keeps 64 lanes busy instead of one, which is what a launch of a few thousand pairs needs.
+// Which pairs of a rows x cols block a launch is responsible for, and where a computed pair is ALSO written.
+//   own_mode 0  every pair of the block.
+//   own_mode 1  rows and columns are the same sketches in the same slot order (one process, all-vs-all, one num): tiles
+//               wholly below the diagonal of slot space are not launched; every pair writes its mirror.
+//   own_mode 2  the rows are a block of an all-vs-all matrix that several ranks share (columns = the whole collection,
+//               one num): row i owns the pairs (i, j) with (j - i) mod N < N/2 (ties: the smaller index) -- every unordered
+//               pair has exactly one owner, every row owns N/2 pairs.  Only owned pairs HAVE to be computed here (the
+//               other rank sends the rest, distributed.py); pairs whose column is one of this block's rows also write
+//               their mirror, so the diagonal block needs no exchange.
+// A pair (i, j) whose column j lies in [mir_lo, mir_hi) -- global indices of the local rows -- also writes (j, i).
+struct PairScope {
+  uint32_t own_mode;
+  uint32_t ntotal;      // N of the collection (own_mode 2)
+  uint32_t row_base;    // global index of local row 0
+  uint32_t col_base;    // global index of local column 0
+  uint32_t mir_lo, mir_hi;
+};
+__device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t N) {
+  const uint64_t d = j >= i ? (uint64_t)(j - i) : (uint64_t)j + N - i;
+  return 2 * d < N || (2 * d == N && i < j);
+}
+
 struct CompWork { uint32_t col, r0, r1; };
 // The work list and its length are produced on the device (see "device-side plan" below): a
 // persistent grid walks it.  rkey[slot] = (component << 32 | row): rows in component order.
@@ -286,7 +309,7 @@ template <bool QLds, bool WantCC>
 __global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet cols, const CompWork* __restrict__ work,
                                                       const uint32_t* __restrict__ nwork_dev, uint32_t work_cap,
                                                       const uint64_t* __restrict__ rkey, uint32_t num,
-                                                      const uint32_t* __restrict__ row_nums, uint32_t symmetric,
+                                                      const uint32_t* __restrict__ row_nums, PairScope sc,
                                                       CompareOut out) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds64[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -305,6 +328,8 @@ __global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet 
     }
     for (uint32_t slot = wk.r0 + w; slot < wk.r1; slot += 4) {
       const uint32_t row = (uint32_t)rkey[slot];
+      const uint32_t gi = sc.row_base + row, gj = sc.col_base + col;
+      if (sc.own_mode == 2 && !owns_pair(gi, gj, sc.ntotal)) continue;   // the owner's rank (or this one, as (j, i)) computes it
       const uint64_t ao = rows.offsets[row];
       const uint32_t la = (uint32_t)(rows.offsets[row + 1] - ao);
       uint32_t n = row_nums ? row_nums[row] : num;
@@ -322,8 +347,8 @@ __global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet 
           if (out.count_common) out.count_common[pid] = r.cc;
           if (out.containment) out.containment[pid] = (double)r.cc / (double)la;
         }
-        if (symmetric && row != col) {   // same list on both axes, one num: also pair (col, row)
-          const size_t pid2 = (size_t)col * cols.n + row;
+        if (gj >= sc.mir_lo && gj < sc.mir_hi && gi != gj) {   // the column is one of the local rows: also pair (col, row)
+          const size_t pid2 = (size_t)(gj - sc.mir_lo) * cols.n + (gi - sc.col_base);
           if (out.common) out.common[pid2] = r.cm;
           if (out.size) out.size[pid2] = size;
           if (out.jaccard) out.jaccard[pid2] = jac;
@@ -361,16 +386,19 @@ struct PlanState {
   unsigned long long pairs;      // sum over the components of rows x columns: pairs that CAN share a hash
   unsigned long long ovf_steps;  // tiled: (tile, range) steps that did not fit the LDS stage and merged from global memory
   uint32_t route;                // kRouteComponents or kRouteTiled
-  uint32_t skip_tiled;           // 1: the tiled pre-pass and kernels do nothing
+  uint32_t skip_tiled;           // 1: the tiled kernels do nothing
   uint32_t skip_comp;            // 1: the per-component pair kernel does nothing
   uint32_t rpw;                  // rows per wave of the tiled instantiation that runs (4, 2 or 1)
   uint32_t ntiles;               // tiles in the list
   uint32_t nwork;                // work items of the per-component kernel
-  uint32_t nruns;                // distinct hashes of the pool (dense ranks)
   uint32_t count16;              // tiles that hold sharing pairs at the 16-row geometry
   uint32_t next_tile[8];         // tiled: tiles handed out so far, per XCD stretch of the list
-  uint32_t nfreq_seen;           // runs of the pool longer than the frequency threshold
-  uint32_t nfreq;                // frequent hashes set aside (0 when there were more than kMaxFreq: nothing is set aside)
+};
+// What the owner of one slice of hash space finds in it (see "collection dictionary" below)
+struct RangeState {
+  uint32_t nruns;                // distinct hashes of the slice (local dense ranks)
+  uint32_t nfreq_seen;           // runs longer than the frequency threshold
+  uint32_t nfreq;                // frequent hashes set aside (0 when there were more than the slice's share of kMaxFreq)
   uint32_t freq_run[64];         // their run ids, ascending (= ascending hash) once k_freq_finalize has run
 };
 constexpr uint32_t kMaxFreq = 64;
@@ -386,7 +414,7 @@ struct TiledArgs {
   const uint64_t* ckey;
   PlanState* st;
   uint32_t use_xcd;        // give every XCD a contiguous stretch of the tile list
-  uint32_t symmetric;      // rows and columns are the same sketches with one num: pair (i, j) also writes (j, i)
+  PairScope scope;         // pair (i, j) also writes (j, i) when j is one of the local rows
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
   unsigned long long* ovf_steps;   // = &st->ovf_steps
   CompareOut out;
@@ -609,10 +637,11 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
           a.out.containment[pid] = (double)cc[q] / (double)la_full;
         }
       }
-      if (a.symmetric && row != col) {
-        // same sketches on both axes, one num: the walk is symmetric in its two inputs, so this is
-        // also pair (col, row) -- tiles below the diagonal are not launched
-        const size_t pid2 = (size_t)col * a.ncols + row;
+      const uint32_t gi = a.scope.row_base + row, gj = a.scope.col_base + col;
+      if (gj >= a.scope.mir_lo && gj < a.scope.mir_hi && gi != gj) {
+        // the column is one of the local rows and there is one num: the walk is symmetric in its two
+        // inputs, so this is also pair (col, row) -- tiles that hold no owned pair are not launched
+        const size_t pid2 = (size_t)(gj - a.scope.mir_lo) * a.ncols + (gi - a.scope.col_base);
         if (a.out.common) a.out.common[pid2] = common[q];
         if (a.out.size) a.out.size[pid2] = size;
         if (a.out.jaccard) a.out.jaccard[pid2] = (double)common[q] / (double)(size > 1 ? size : 1);
@@ -630,43 +659,40 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 }
 
 // ---- pre-pass kernels ---------------------------------------------------------------------
-// dense rank of every pooled element, back in pool order: rank[origin[i]] = run of sorted position i
+// local dense rank of every element of a slice, back in slice order: rank[origin[i]] = run of sorted position i
 __global__ __launch_bounds__(256) void k_rank_scatter(const uint32_t* __restrict__ runid, const uint32_t* __restrict__ origin,
-                                                      uint64_t n, uint32_t* __restrict__ rank, const PlanState* __restrict__ st) {
+                                                      uint64_t n, uint32_t* __restrict__ rank) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !st->skip_tiled) rank[origin[i]] = runid[i];
+  if (i < n) rank[origin[i]] = runid[i];
 }
-__global__ void k_iota(uint32_t* p, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (uint32_t)i;
-}
-// bound[r] = rank of the pooled element at sorted position r*n/R (bound[0] = 0, bound[R] = nruns)
-__global__ void k_bounds(const uint32_t* __restrict__ starts, const PlanState* __restrict__ st, uint32_t n, uint32_t R,
-                         uint32_t* __restrict__ bound) {
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > R || st->skip_tiled) return;
-  const uint32_t nruns = st->nruns;
-  if (r == 0) { bound[0] = 0; return; }
-  if (r == R) { bound[R] = nruns; return; }
-  uint32_t pos = (uint32_t)(((uint64_t)r * n) / R);
+// Range boundaries of the tiled kernel, as HASH values: out[0] = first hash value of the slice, out[k] = the hash at
+// sorted position k*n/Rg of the slice's pool -- Rg ranges with equal shares of the pooled elements.
+__global__ void k_hbounds(const uint32_t* __restrict__ starts, const uint64_t* __restrict__ uniq, const RangeState* __restrict__ rs,
+                          uint32_t n, uint32_t Rg, const uint64_t* __restrict__ slice_lo_p, uint64_t* __restrict__ out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Rg) return;
+  const uint64_t slice_lo = *slice_lo_p;
+  const uint32_t nruns = rs->nruns;
+  if (k == 0 || nruns == 0) { out[k] = slice_lo; return; }
+  const uint32_t pos = (uint32_t)(((uint64_t)k * n) / Rg);
   uint32_t lo = 0, hi = nruns;  // last run with starts[run] <= pos
   while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
+    const uint32_t mid = (lo + hi) >> 1;
     if (starts[mid] <= pos) lo = mid; else hi = mid;
   }
-  bound[r] = lo;
+  out[k] = max(uniq[lo], slice_lo);
 }
-// part[s][r] = first index in sketch s whose rank is >= bound[r]
-__global__ void k_partition(const uint32_t* __restrict__ rank, const uint64_t* __restrict__ off, uint32_t nsk,
-                            const uint32_t* __restrict__ bound, uint32_t R, uint32_t* __restrict__ part,
-                            const PlanState* __restrict__ st) {
+// part[s][r] = first index in sketch s whose hash is >= hbound[r]  (r < R);  part[s][R] = |s|
+__global__ void k_partition(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                            const uint64_t* __restrict__ hbound, uint32_t R, uint32_t* __restrict__ part) {
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint64_t)nsk * (R + 1) || st->skip_tiled) return;
+  if (g >= (uint64_t)nsk * (R + 1)) return;
   uint32_t s = (uint32_t)(g / (R + 1)), r = (uint32_t)(g % (R + 1));
-  const uint32_t* v = rank + off[s];
+  const uint64_t* v = hashes + off[s];
   uint32_t len = (uint32_t)(off[s + 1] - off[s]);
-  uint32_t lo = 0, hi = len, b = bound[r];
   if (r == R) { part[g] = len; return; }
+  uint32_t lo = 0, hi = len;
+  const uint64_t b = hbound[r];
   while (lo < hi) {
     uint32_t mid = (lo + hi) >> 1;
     if (v[mid] < b) lo = mid + 1; else hi = mid;
@@ -674,6 +700,133 @@ __global__ void k_partition(const uint32_t* __restrict__ rank, const uint64_t* _
   part[g] = lo;
 }
 
+// ---- collection dictionary: slices of hash space ----------------------------------------------
+// The dictionary of a collection (dense order-preserving ranks of all its hashes, components of the
+// "shares a hash" graph, frequent hashes, range boundaries) can be built by `world` cooperating owners:
+// hash space is cut into `world` slices holding equal shares of the pooled elements (splitters from a
+// sorted sample -- every owner computes the same ones from the same collection), owner g gathers slice g
+// of EVERY sketch (a contiguous piece of it: sketches are sorted), sorts it, and publishes what it found;
+// after one all-gather of those shares everybody assembles the whole dictionary.  world == 1: one slice.
+__global__ __launch_bounds__(256) void k_sample_keys(const uint64_t* __restrict__ hashes, uint64_t total, uint32_t S,
+                                                     uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < S) out[i] = hashes[(uint64_t)i * total / S];
+}
+__global__ void k_pick_splitters(const uint64_t* __restrict__ sorted, uint32_t S, uint32_t G, uint64_t* __restrict__ split) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  split[g] = (g == 0 || S == 0) ? 0ull : sorted[(uint64_t)g * S / G];
+}
+// spart[s][g] = first index of sketch s whose hash is >= split[g]  (g < G);  spart[s][G] = |s|
+__global__ __launch_bounds__(256) void k_slice_parts(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                                                     const uint64_t* __restrict__ split, uint32_t G, uint32_t* __restrict__ spart) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)nsk * (G + 1)) return;
+  const uint32_t s = (uint32_t)(t / (G + 1)), g = (uint32_t)(t % (G + 1));
+  const uint64_t* v = hashes + off[s];
+  const uint32_t len = (uint32_t)(off[s + 1] - off[s]);
+  uint32_t lo = 0, hi = len;
+  if (g == G) lo = len;
+  else if (g > 0) {
+    const uint64_t b = split[g];
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (v[mid] < b) lo = mid + 1; else hi = mid;
+    }
+  }
+  spart[t] = lo;
+}
+// segoff[g][s] = elements of slice g in the sketches before s (exclusive scan down column g; segoff[g][nsk] = slice size).
+// One workgroup per slice: every lane sums a stretch of sketches, the stretch sums are scanned in LDS.
+__global__ __launch_bounds__(1024) void k_slice_scan(const uint32_t* __restrict__ spart, uint32_t nsk, uint32_t G,
+                                                     uint32_t* __restrict__ segoff) {
+  __shared__ uint32_t part_sum[1024];
+  const uint32_t g = blockIdx.x, tid = threadIdx.x;
+  const uint32_t per = (nsk + 1023) / 1024;
+  const uint32_t s0 = min(tid * per, nsk), s1 = min(s0 + per, nsk);
+  uint32_t sum = 0;
+  for (uint32_t s = s0; s < s1; s++) sum += spart[(size_t)s * (G + 1) + g + 1] - spart[(size_t)s * (G + 1) + g];
+  part_sum[tid] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = tid >= off ? part_sum[tid - off] : 0u;
+    __syncthreads();
+    part_sum[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part_sum[tid] - sum;
+  uint32_t* dst = segoff + (size_t)g * (nsk + 1);
+  for (uint32_t s = s0; s < s1; s++) {
+    dst[s] = run;
+    run += spart[(size_t)s * (G + 1) + g + 1] - spart[(size_t)s * (G + 1) + g];
+  }
+  if (tid == 1023) dst[nsk] = part_sum[1023];
+}
+// slice g of every sketch, sketch after sketch: keys[t], node[t] = its sketch, org[t] = t
+__global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                                                      const uint32_t* __restrict__ spart, uint32_t G, uint32_t g,
+                                                      const uint32_t* __restrict__ segoff_g, uint32_t n,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ org, uint32_t* __restrict__ node) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint32_t lo = 0, hi = nsk;   // last s with segoff_g[s] <= t  (its segment is not empty: t < n)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (segoff_g[mid] <= t) lo = mid; else hi = mid;
+  }
+  keys[t] = hashes[off[lo] + spart[(size_t)lo * (G + 1) + g] + (t - segoff_g[lo])];
+  org[t] = t;
+  node[t] = lo;
+}
+// What an owner publishes about its slice.  The share is [SliceHeader][roots: nsk u32][hbound: Rg u64][ranks: nmax u32].
+struct SliceHeader {
+  uint32_t n_elems, nruns, nfreq, pad;
+  uint64_t freq_hash[64];
+};
+__global__ __launch_bounds__(64) void k_slice_header(const RangeState* __restrict__ rs, const uint64_t* __restrict__ uniq, uint32_t n,
+                                                     SliceHeader* __restrict__ h) {
+  const uint32_t k = threadIdx.x;
+  if (k == 0) { h->n_elems = n; h->nruns = rs->nruns; h->nfreq = rs->nfreq; h->pad = 0; }
+  h->freq_hash[k] = k < rs->nfreq ? uniq[rs->freq_run[k]] : 0ull;
+}
+// What everybody derives from the gathered headers: the rank offset of every slice, the frequent hashes (ascending)
+struct DictState {
+  uint32_t nruns;              // distinct hashes of the collection
+  uint32_t nfreq;              // frequent hashes set aside, over all slices (<= kMaxFreq)
+  uint32_t rbase[64];          // dense rank of the first hash of slice g
+  uint64_t freq_hash[64];
+};
+__global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint32_t G, DictState* __restrict__ ds) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t base = 0, nf = 0;
+  for (uint32_t g = 0; g < G; g++) {
+    const SliceHeader* h = reinterpret_cast<const SliceHeader*>(gathered + (size_t)g * share_bytes);
+    ds->rbase[g] = base;
+    base += h->nruns;
+    for (uint32_t k = 0; k < h->nfreq && nf < 64; k++) ds->freq_hash[nf++] = h->freq_hash[k];
+  }
+  ds->nruns = base;
+  ds->nfreq = nf;
+}
+// rank of every element of the collection, in collection order, from the slices' local ranks
+__global__ __launch_bounds__(256) void k_reassemble(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t total,
+                                                    const uint32_t* __restrict__ spart, uint32_t G, const uint32_t* __restrict__ segoff,
+                                                    const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint64_t ranks_at,
+                                                    const DictState* __restrict__ ds, uint32_t* __restrict__ rank) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= t
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= t) lo = mid; else hi = mid;
+  }
+  const uint32_t s = lo, p = (uint32_t)(t - off[s]);
+  const uint32_t* sp = spart + (size_t)s * (G + 1);
+  uint32_t g = 0;
+  while (g + 1 < G && sp[g + 1] <= p) g++;     // last g with sp[g] <= p
+  const uint32_t* seg = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * share_bytes + ranks_at);
+  rank[t] = ds->rbase[g] + seg[segoff[(size_t)g * (nsk + 1) + s] + (p - sp[g])];
+}
 
 // ---- components of the "shares a hash" graph ------------------------------------------------
 // Two sketches in different connected components have no hash in common: common = 0 and size =
@@ -701,19 +854,6 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t x, uint32_t 
     if (x > y) { const uint32_t t = x; x = y; y = t; }
     if (atomicCAS(parent + y, y, x) == y) return;   // the larger root goes under the smaller: parent[v] <= v always
   }
-}
-// node of pooled element e (rows' elements first, then columns'; `split` = number of row elements)
-__global__ __launch_bounds__(256) void k_elem_node(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t n_elems,
-                                                   uint32_t base_id, uint32_t* __restrict__ node) {
-  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_elems) return;
-  const uint64_t v = off[0] + e;
-  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= v
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= v) lo = mid; else hi = mid;
-  }
-  node[e] = base_id + lo;
 }
 __global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -743,12 +883,14 @@ __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ ke
   }
   uf_union(parent, a, b);
 }
-// a row block that is a slice of the column set: row element t IS column element delta + t
-__global__ __launch_bounds__(256) void k_uf_alias(const uint32_t* __restrict__ row_node, const uint32_t* __restrict__ col_node,
-                                                  uint64_t n_row_elems, uint64_t delta, uint32_t* parent) {
+// the slices' forests (root of every sketch within slice g) united into one
+__global__ __launch_bounds__(256) void k_uf_merge(const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint64_t roots_at,
+                                                  uint32_t G, uint32_t nsk, uint32_t* parent) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_row_elems) return;
-  uf_union(parent, row_node[t], col_node[delta + t]);
+  if (t >= (uint64_t)G * nsk) return;
+  const uint32_t g = (uint32_t)(t / nsk), i = (uint32_t)(t % nsk);
+  const uint32_t r = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * share_bytes + roots_at)[i];
+  if (r != i) uf_union(parent, i, r);
 }
 __global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, uint32_t* __restrict__ root) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -765,7 +907,7 @@ __global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, 
 // lies inside the first n of the union (reference src/lib.rs:470-499); |A u B| = |A| + |B| - shared.
 // Exact for any threshold: the threshold only moves work between the walk and this rule.
 __global__ __launch_bounds__(256) void k_freq_mark(const uint32_t* __restrict__ starts, uint32_t n, uint32_t threshold,
-                                                   PlanState* st) {
+                                                   RangeState* st) {
   const uint32_t nruns = st->nruns;
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += gridDim.x * blockDim.x) {
     const uint32_t len = (r + 1 < nruns ? starts[r + 1] : n) - starts[r];
@@ -776,43 +918,34 @@ __global__ __launch_bounds__(256) void k_freq_mark(const uint32_t* __restrict__ 
   }
 }
 // one wave: sort the (at most 64) run ids, decide, mark
-__global__ __launch_bounds__(64) void k_freq_finalize(PlanState* st, uint8_t* __restrict__ isfreq) {
+// (cap: this slice's share of the kMaxFreq hashes that can be set aside in all)
+__global__ __launch_bounds__(64) void k_freq_finalize(RangeState* st, uint8_t* __restrict__ isfreq, uint32_t cap) {
   const uint32_t seen = st->nfreq_seen, lane = threadIdx.x;
-  if (seen == 0 || seen > kMaxFreq) { if (lane == 0) st->nfreq = 0; return; }
+  if (seen == 0 || seen > cap) { if (lane == 0) st->nfreq = 0; return; }
   const uint32_t mine = lane < seen ? st->freq_run[lane] : 0xffffffffu;
   uint32_t rank = 0;
   for (uint32_t k = 0; k < seen; k++) rank += (uint32_t)__shfl((int)mine, (int)k) < mine ? 1u : 0u;   // run ids are distinct
   if (lane < seen) { st->freq_run[rank] = mine; isfreq[mine] = (uint8_t)(rank + 1); }
   if (lane == 0) st->nfreq = seen;
 }
-// mask / position records of every sketch (node): walks the elements of the frequent runs
-__global__ __launch_bounds__(256) void k_freq_fill(const uint32_t* __restrict__ starts, uint32_t n, const uint32_t* __restrict__ origin,
-                                                   const uint32_t* __restrict__ node, const uint64_t* __restrict__ node_first,
-                                                   const uint32_t* __restrict__ alias_node, uint64_t alias_lo, uint64_t alias_n,
-                                                   const PlanState* __restrict__ st, unsigned long long* __restrict__ mask,
-                                                   uint32_t* __restrict__ pos) {
-  const uint32_t b = blockIdx.y;
-  if (b >= st->nfreq) return;
-  const uint32_t r = st->freq_run[b], nruns = st->nruns;
-  const uint32_t lo = starts[r], hi = r + 1 < nruns ? starts[r + 1] : n;
-  for (uint32_t e = lo + blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += gridDim.x * blockDim.x) {
-    const uint32_t o = origin[e];                     // pooled element index
-    const uint32_t nd = node[o];
-    atomicOr(&mask[nd], 1ull << b);
-    pos[(size_t)nd * kMaxFreq + b] = (uint32_t)(o - node_first[nd]);
-    if (alias_node && o >= alias_lo && o - alias_lo < alias_n) {
-      // a row block that is a view of the columns: the element is also element o - alias_lo of the rows
-      const uint32_t rn = alias_node[o - alias_lo];
-      atomicOr(&mask[rn], 1ull << b);
-      pos[(size_t)rn * kMaxFreq + b] = (uint32_t)(o - alias_lo - node_first[rn]);
-    }
+// mask / position records of every sketch: which of the frequent hashes it holds, and where (binary search per pair)
+__global__ __launch_bounds__(256) void k_freq_records(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                                                      const DictState* __restrict__ ds, unsigned long long* __restrict__ mask,
+                                                      uint32_t* __restrict__ pos) {
+  const uint32_t b = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= ds->nfreq || s >= nsk) return;
+  const uint64_t f = ds->freq_hash[b];
+  const uint64_t* v = hashes + off[s];
+  const uint32_t len = (uint32_t)(off[s + 1] - off[s]);
+  uint32_t lo = 0, hi = len;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (v[mid] < f) lo = mid + 1; else hi = mid;
   }
-}
-// pooled index of the first element of every node (sketch)
-__global__ __launch_bounds__(256) void k_node_first(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t pool_base, uint32_t node_base,
-                                                    uint64_t* __restrict__ node_first) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nsk) node_first[node_base + i] = pool_base + (off[i] - off[0]);
+  if (lo < len && v[lo] == f) {
+    atomicOr(&mask[s], 1ull << b);
+    pos[(size_t)s * kMaxFreq + b] = lo;
+  }
 }
 
 // every pair as if it shared nothing but frequent hashes (none, usually); the compare kernels then
@@ -820,18 +953,18 @@ __global__ __launch_bounds__(256) void k_node_first(const uint64_t* __restrict__
 __global__ __launch_bounds__(256) void k_fill_disjoint(const uint64_t* __restrict__ roff, uint32_t nrows,
                                                        const uint64_t* __restrict__ coff, uint32_t ncols, uint32_t num,
                                                        const uint32_t* __restrict__ row_nums, CompareOut out,
-                                                       const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ pos,
-                                                       uint32_t col_node_base) {
+                                                       const unsigned long long* __restrict__ rmask, const uint32_t* __restrict__ rpos,
+                                                       const unsigned long long* __restrict__ cmask, const uint32_t* __restrict__ cpos) {
   const uint64_t pid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= (uint64_t)nrows * ncols) return;
   const uint32_t i = (uint32_t)(pid / ncols), j = (uint32_t)(pid % ncols);
   const uint64_t la = roff[i + 1] - roff[i], lb = coff[j + 1] - coff[j];
   const uint64_t n = row_nums ? row_nums[i] : num;
   uint64_t cc = 0, common = 0;
-  if (mask) {
-    unsigned long long m = mask[i] & mask[col_node_base + j];
-    const uint32_t* pa = pos + (size_t)i * kMaxFreq;
-    const uint32_t* pb = pos + (size_t)(col_node_base + j) * kMaxFreq;
+  if (rmask) {
+    unsigned long long m = rmask[i] & cmask[j];
+    const uint32_t* pa = rpos + (size_t)i * kMaxFreq;
+    const uint32_t* pb = cpos + (size_t)j * kMaxFreq;
     while (m) {
       const int b = __ffsll((long long)m) - 1;
       m &= m - 1;
@@ -927,27 +1060,41 @@ __global__ __launch_bounds__(256) void k_comp_fill(const uint64_t* __restrict__ 
   for (uint32_t k = 0; k < n; k++)
     if (off[c] + k < work_cap) work[off[c] + k] = CompWork{col, rs + k * kRowsPerItem, min(row_hi[c], rs + (k + 1) * kRowsPerItem)};
 }
-// does the tr x 64 tile (ti, tj) of the slot orders hold a pair of one component?
-__device__ __forceinline__ bool tile_shares(uint32_t ti, uint32_t tj, uint32_t tr, uint32_t nrows, uint32_t ncols,
-                                            const uint32_t* __restrict__ col_lo, const uint32_t* __restrict__ col_hi,
-                                            uint32_t symmetric, uint32_t all_on) {
-  // a tile wholly below the diagonal: its pairs are written as mirrors of the tile above
-  if (symmetric && (uint64_t)tj * kTB + kTB - 1 < (uint64_t)ti * tr) return false;
-  if (all_on) return true;
-  const uint32_t cbeg = tj * kTB, cend = min(cbeg + (uint32_t)kTB, ncols);
-  const uint32_t r1 = min((ti + 1) * tr, nrows);
-  for (uint32_t i = ti * tr; i < r1; i++)
-    if (col_lo[i] < cend && col_hi[i] > cbeg) return true;
+// does the tr x 64 tile (ti, tj) of the slot orders hold a pair of one component (that this launch is responsible for)?
+struct TileTest {
+  uint32_t nrows, ncols;
+  const uint32_t* col_lo; const uint32_t* col_hi;   // per row slot: the column slots of its component
+  const uint64_t* rkey; const uint64_t* ckey;       // slot -> (component << 32 | local index)
+  PairScope sc;
+  uint32_t all_on;
+};
+__device__ __forceinline__ bool tile_shares(uint32_t ti, uint32_t tj, uint32_t tr, const TileTest& t) {
+  // own_mode 1: a tile wholly below the diagonal of slot space -- its pairs are written as mirrors of the tile above
+  if (t.sc.own_mode == 1 && (uint64_t)tj * kTB + kTB - 1 < (uint64_t)ti * tr) return false;
+  if (t.all_on) return true;
+  const uint32_t cbeg = tj * kTB, cend = min(cbeg + (uint32_t)kTB, t.ncols);
+  const uint32_t r1 = min((ti + 1) * tr, t.nrows);
+  for (uint32_t i = ti * tr; i < r1; i++) {
+    const uint32_t c0 = max(t.col_lo[i], cbeg), c1 = min(t.col_hi[i], cend);
+    if (c0 >= c1) continue;
+    if (t.sc.own_mode != 2) return true;
+    // own_mode 2: columns of one component ascend with the slot, so [c0, c1) spans the indices [ja, jb]; row i owns
+    // the circular interval [i, i + N/2].  Interval overlap is a superset test (a tile flagged in vain only costs time).
+    const uint32_t gi = t.sc.row_base + (uint32_t)t.rkey[i];
+    const uint32_t ja = (uint32_t)t.ckey[c0], jb = (uint32_t)t.ckey[c1 - 1];
+    const uint64_t top = (uint64_t)gi + t.sc.ntotal / 2;
+    if (jb >= gi && ja <= top) return true;
+    if (top >= t.sc.ntotal && ja <= top - t.sc.ntotal) return true;
+  }
   return false;
 }
-__global__ __launch_bounds__(256) void k_tiles_count16(uint32_t nrows, uint32_t ncols, const uint32_t* __restrict__ col_lo,
-                                                       const uint32_t* __restrict__ col_hi, uint32_t symmetric, PlanState* st) {
+__global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st) {
   if (st->skip_tiled) return;
-  const uint32_t tiles_r = (nrows + 15) / 16, tiles_c = (ncols + kTB - 1) / kTB;
+  const uint32_t tiles_r = (t.nrows + 15) / 16, tiles_c = (t.ncols + kTB - 1) / kTB;
   const uint64_t all = (uint64_t)tiles_r * tiles_c;
   uint32_t mine = 0;
-  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < all; t += (uint64_t)gridDim.x * blockDim.x)
-    mine += tile_shares((uint32_t)(t / tiles_c), (uint32_t)(t % tiles_c), 16, nrows, ncols, col_lo, col_hi, symmetric, 0) ? 1u : 0u;
+  for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < all; x += (uint64_t)gridDim.x * blockDim.x)
+    mine += tile_shares((uint32_t)(x / tiles_c), (uint32_t)(x % tiles_c), 16, t) ? 1u : 0u;
   const uint32_t wsum = (uint32_t)wave_sum64(mine);
   if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&st->count16, wsum);
 }
@@ -958,23 +1105,22 @@ __global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t fil
   if (!rpw) rpw = st->count16 >= fill_tiles ? 4u : (2 * st->count16 >= fill_tiles ? 2u : 1u);
   st->rpw = rpw;
 }
-__global__ __launch_bounds__(256) void k_flag_tiles(uint32_t nrows, uint32_t ncols, const uint32_t* __restrict__ col_lo,
-                                                    const uint32_t* __restrict__ col_hi, uint32_t symmetric, uint32_t all_on,
-                                                    uint32_t wpb, uint32_t* __restrict__ tiles, uint32_t tiles_cap, PlanState* st) {
+__global__ __launch_bounds__(256) void k_flag_tiles(TileTest t, uint32_t wpb, uint32_t* __restrict__ tiles, uint32_t tiles_cap,
+                                                    PlanState* st) {
   __shared__ uint32_t wcnt[4], base_s;
   if (st->skip_tiled) return;
   const uint32_t tr = st->rpw * wpb;
-  const uint32_t tiles_r = (nrows + tr - 1) / tr, tiles_c = (ncols + kTB - 1) / kTB;
+  const uint32_t tiles_r = (t.nrows + tr - 1) / tr, tiles_c = (t.ncols + kTB - 1) / kTB;
   const uint64_t all = (uint64_t)tiles_r * tiles_c;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // chunks of 256 consecutive tiles; inside a chunk the list keeps tile order
   for (uint64_t c0 = (uint64_t)blockIdx.x * 256; c0 < all; c0 += (uint64_t)gridDim.x * 256) {
-    const uint64_t t = c0 + threadIdx.x;
+    const uint64_t x = c0 + threadIdx.x;
     uint32_t ti = 0, tj = 0;
     bool on = false;
-    if (t < all) {
-      ti = (uint32_t)(t / tiles_c); tj = (uint32_t)(t % tiles_c);
-      on = tile_shares(ti, tj, tr, nrows, ncols, col_lo, col_hi, symmetric, all_on);
+    if (x < all) {
+      ti = (uint32_t)(x / tiles_c); tj = (uint32_t)(x % tiles_c);
+      on = tile_shares(ti, tj, tr, t);
     }
     const uint64_t m = __ballot(on);
     if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
@@ -993,9 +1139,10 @@ __global__ __launch_bounds__(256) void k_flag_tiles(uint32_t nrows, uint32_t nco
   }
 }
 
+// temporaries of building a dictionary and of planning one block compare: process-wide, grow-only, used under the device mutex
 struct TiledScratch {
-  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, rank, bound, rpart, cpart, node, parent, root, tiles, work, plan,
-      pk0, pk1, pk2, pk3, rng, cnt, runid, isfreq, fmask, fpos, nfirst;
+  DeviceBuffer keys0, keys1, org0, org1, uniq, starts, node, parent, tiles, work, plan, pk0, pk1, pk2, pk3, rng, cnt, runid, isfreq,
+      sample0, sample1, rstate, cat;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -1038,11 +1185,14 @@ static const TiledExperiments& tiled_experiments() {
   return ex;
 }
 
+static void release_implicit_dict();
 void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
-  for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.rank, &T.bound, &T.rpart, &T.cpart,
-                          &T.node, &T.parent, &T.root, &T.tiles, &T.work, &T.plan, &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt, &T.runid, &T.isfreq, &T.fmask, &T.fpos, &T.nfirst})
+  for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.node, &T.parent, &T.tiles, &T.work, &T.plan,
+                          &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt, &T.runid, &T.isfreq, &T.sample0, &T.sample1, &T.rstate,
+                          &T.cat})
     b->release();
+  release_implicit_dict();
 }
 
 // byte passes of a radix sort that can differ among keys (component << 32 | index) with
@@ -1056,143 +1206,288 @@ static uint32_t plan_key_passes(uint32_t M, uint32_t n) {
   return mask;
 }
 
-static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
-                         uint32_t max_len, uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
-                         hipStream_t s, bool same_sets) {
+// ---- the dictionary of one collection ------------------------------------------------------------
+// Everything a block compare needs to know about the collection as a whole, built once (by one owner, or by `world`
+// cooperating owners with one all-gather between collection_begin and collection_finish) and then used by any number of
+// collection_compare calls over sub-blocks of it:
+//   rank[total]        dense order-preserving u32 rank of every hash (the tiled kernel compares ranks)
+//   root[n]            component of every sketch in the "shares a (non-frequent) hash" graph
+//   fmask / fpos       which of the frequent hashes a sketch holds, and where
+//   part[n][R+1]       where every sketch crosses the R range boundaries of the tiled kernel
+struct CollectionDict {
+  const uint64_t* hashes = nullptr;   // not owned: collection element t is hashes[t]
+  uint32_t n = 0, world = 1, rank = 0, max_len = 0;
+  uint64_t total = 0;
+  uint32_t Rg = 1, R = 1;             // ranges of the tiled kernel per slice / in all
+  uint32_t n_mine = 0, n_max = 0;     // elements of this owner's slice / of the largest slice
+  uint64_t roots_at = 0, hbound_at = 0, ranks_at = 0, share_bytes = 0;
+  bool finished = false, split = false;
+  DeviceBuffer off, splitters, spart, segoff, share, dstate, rankv, root, fmask, fpos, hbound, part;
+};
+
+static inline uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
+
+static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev, const uint64_t* offsets_dev, const uint64_t* offsets_host,
+                                  uint32_t n, uint32_t world, uint32_t rank, Device& dev, hipStream_t s) {
+  if (world == 0 || world > 64 || rank >= world) throw_internal("collection: world must be 1..64 and rank < world");
+  if (n == 0) throw_internal("collection: no sketches");
+  D.finished = false;
+  D.max_len = 0;
+  TiledScratch& T = tiled_scratch();
+  const TiledExperiments& ex = tiled_experiments();
+  const uint64_t base = offsets_host[0];
+  D.hashes = hashes_dev + base; D.n = n; D.world = world; D.rank = rank;
+  D.total = offsets_host[n] - base;
+  if (D.total >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
+  for (uint32_t i = 0; i < n; i++) D.max_len = std::max<uint32_t>(D.max_len, (uint32_t)(offsets_host[i + 1] - offsets_host[i]));
+  // offsets relative to the first element (a copy the dictionary owns: the caller's array may be reused)
+  D.off.ensure((size_t)(n + 1) * 8);
+  if (offsets_dev && base == 0) HIP_CHECK(hipMemcpyAsync(D.off.ptr, offsets_dev, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, s));
+  else {
+    std::vector<uint64_t> rel(n + 1);
+    for (uint32_t i = 0; i <= n; i++) rel[i] = offsets_host[i] - base;
+    HIP_CHECK(hipMemcpyAsync(D.off.ptr, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));   // `rel` is a pageable temporary
+  }
+  const uint64_t* off = D.off.as<uint64_t>();
+  const uint32_t G = world;
+  // ranges of the tiled kernel: about 24 pooled elements per sketch per range, granularity from the LONGEST sketch
+  // (its segments must fit the LDS stage); tiles of shorter sketches walk several ranges per step
+  uint32_t R0 = (uint32_t)(((uint64_t)D.max_len + ex.per_range - 1) / ex.per_range);
+  R0 = std::min<uint32_t>(std::max<uint32_t>(R0, 1), 8192);
+  D.Rg = (R0 + G - 1) / G; D.R = D.Rg * G;
+
+  // ---- slices of hash space: splitters from a sorted sample, where every sketch crosses them, slice sizes
+  D.splitters.ensure((size_t)G * 8);
+  const uint32_t S = G == 1 ? 0u : (uint32_t)std::min<uint64_t>(D.total, 8192);
+  if (S) {
+    T.sample0.ensure((size_t)S * 8); T.sample1.ensure((size_t)S * 8);
+    hipLaunchKernelGGL(k_sample_keys, dim3((S + 255) / 256), dim3(256), 0, s, D.hashes, D.total, S, T.sample0.as<uint64_t>());
+    const int cur = radix_sort_u64_keys(T.sample0.as<uint64_t>(), T.sample1.as<uint64_t>(), S, dev.scratch, s, 0xffu);
+    hipLaunchKernelGGL(k_pick_splitters, dim3(1), dim3(64), 0, s, cur ? T.sample1.as<uint64_t>() : T.sample0.as<uint64_t>(), S, G,
+                       D.splitters.as<uint64_t>());
+  } else {
+    HIP_CHECK(hipMemsetAsync(D.splitters.ptr, 0, (size_t)G * 8, s));
+  }
+  D.spart.ensure((size_t)n * (G + 1) * 4);
+  D.segoff.ensure((size_t)G * (n + 1) * 4);
+  hipLaunchKernelGGL(k_slice_parts, dim3((unsigned)(((uint64_t)n * (G + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, n,
+                     D.splitters.as<uint64_t>(), G, D.spart.as<uint32_t>());
+  hipLaunchKernelGGL(k_slice_scan, dim3(G), dim3(1024), 0, s, D.spart.as<uint32_t>(), n, G, D.segoff.as<uint32_t>());
+  HIP_CHECK(hipGetLastError());
+  if (G == 1) {
+    D.n_mine = D.n_max = (uint32_t)D.total;
+  } else {
+    // the one read-back of building a shared dictionary: the slice sizes (every owner computes the same table)
+    std::vector<uint32_t> sizes(G);
+    for (uint32_t g = 0; g < G; g++)
+      HIP_CHECK(hipMemcpyAsync(&sizes[g], D.segoff.as<uint32_t>() + (size_t)g * (n + 1) + n, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    D.n_mine = sizes[rank];
+    D.n_max = *std::max_element(sizes.begin(), sizes.end());
+  }
+  const uint32_t nm = D.n_mine;
+  D.roots_at = align8(sizeof(SliceHeader));
+  D.hbound_at = align8(D.roots_at + (uint64_t)n * 4);
+  D.ranks_at = align8(D.hbound_at + (uint64_t)D.Rg * 8);
+  D.share_bytes = align8(D.ranks_at + (uint64_t)D.n_max * 4);
+  D.share.ensure(D.share_bytes);
+  uint8_t* share = D.share.as<uint8_t>();
+  T.rstate.ensure(sizeof(RangeState));
+  RangeState* rs = T.rstate.as<RangeState>();
+  HIP_CHECK(hipMemsetAsync(rs, 0, sizeof(RangeState), s));
+
+  // ---- my slice: gather, sort (hash, place), runs of equal hashes = local dense ranks + document frequencies
+  const size_t ne = std::max<uint32_t>(nm, 1);
+  T.keys0.ensure(ne * 8); T.keys1.ensure(ne * 8); T.org0.ensure(ne * 4); T.org1.ensure(ne * 4); T.node.ensure(ne * 4);
+  T.uniq.ensure(ne * 8); T.starts.ensure((ne + 1) * 4); T.runid.ensure(ne * 4);
+  uint64_t* sk = T.keys0.as<uint64_t>();
+  uint32_t* so = T.org0.as<uint32_t>();
+  if (nm) {
+    hipLaunchKernelGGL(k_slice_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
+                       D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.org0.as<uint32_t>(),
+                       T.node.as<uint32_t>());
+    // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
+    const int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
+                                       dev.scratch, s, 0xffu);
+    if (cur) { sk = T.keys1.as<uint64_t>(); so = T.org1.as<uint32_t>(); }
+  }
+  run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr, &rs->nruns,
+                              nullptr, T.runid.as<uint32_t>());
+  // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
+  D.split = compare_get_tuning().split_frequent != 0 && n >= 32;
+  const uint8_t* isfreq = nullptr;
+  if (D.split && nm) {
+    T.isfreq.ensure(ne);
+    HIP_CHECK(hipMemsetAsync(T.isfreq.ptr, 0, ne, s));
+    const uint32_t threshold = std::max<uint32_t>(16u, n / 4);
+    hipLaunchKernelGGL(k_freq_mark, dim3((unsigned)std::min<uint64_t>((nm + 255) / 256, 2048)), dim3(256), 0, s, T.starts.as<uint32_t>(),
+                       nm, threshold, rs);
+    hipLaunchKernelGGL(k_freq_finalize, dim3(1), dim3(64), 0, s, rs, T.isfreq.as<uint8_t>(), std::max<uint32_t>(1u, kMaxFreq / G));
+    isfreq = T.isfreq.as<uint8_t>();
+  }
+  // ---- components of the "shares a hash" graph within my slice (lock-free union-find over the runs of equal hashes)
+  T.parent.ensure((size_t)n * 4);
+  uint32_t* roots = reinterpret_cast<uint32_t*>(share + D.roots_at);
+  hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
+  if (nm) {
+    // 1/256 sample straight to the atomic path, then 1/16 and everything through the cached filter
+    hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+                       (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+    hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+                       (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+    hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+                       (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+  }
+  hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, roots);
+  // ---- what the slice publishes: header, roots (written above), range boundaries, local ranks in slice order
+  hipLaunchKernelGGL(k_slice_header, dim3(1), dim3(64), 0, s, rs, T.uniq.as<uint64_t>(), nm, reinterpret_cast<SliceHeader*>(share));
+  hipLaunchKernelGGL(k_hbounds, dim3((D.Rg + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), T.uniq.as<uint64_t>(), rs, nm, D.Rg,
+                     D.splitters.as<uint64_t>() + rank, reinterpret_cast<uint64_t*>(share + D.hbound_at));   // (slice's lower end: by pointer)
+  if (nm)
+    hipLaunchKernelGGL(k_rank_scatter, dim3((nm + 255) / 256), dim3(256), 0, s, T.runid.as<uint32_t>(), so, (uint64_t)nm,
+                       reinterpret_cast<uint32_t*>(share + D.ranks_at));
+  HIP_CHECK(hipGetLastError());
+}
+
+CollectionDict* collection_begin(const uint64_t* hashes_dev, const uint64_t* offsets_dev, const uint64_t* offsets_host, uint32_t n,
+                                 uint32_t world, uint32_t rank, Device& dev, hipStream_t s) {
+  std::unique_ptr<CollectionDict> D(new CollectionDict());
+  collection_begin_into(*D, hashes_dev, offsets_dev, offsets_host, n, world, rank, dev, s);
+  return D.release();
+}
+
+uint64_t collection_share_bytes(const CollectionDict* D) { return D->share_bytes; }
+const void* collection_share(const CollectionDict* D) { return D->share.ptr; }
+uint32_t collection_len(const CollectionDict* D) { return D->n; }
+
+// gathered: world x share_bytes, owner-major (what an all-gather of the shares returns); world == 1: may be null
+void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev, hipStream_t s) {
+  CollectionDict& D = *Dp;
+  TiledScratch& T = tiled_scratch();
+  const uint32_t G = D.world, n = D.n;
+  const uint8_t* gathered = reinterpret_cast<const uint8_t*>(gathered_dev);
+  if (!gathered) {
+    if (G != 1) throw_internal("collection_finish: the gathered shares are missing");
+    gathered = D.share.as<uint8_t>();
+  }
+  const uint64_t* off = D.off.as<uint64_t>();
+  D.dstate.ensure(sizeof(DictState));
+  DictState* ds = D.dstate.as<DictState>();
+  hipLaunchKernelGGL(k_dict_state, dim3(1), dim3(1), 0, s, gathered, D.share_bytes, G, ds);
+  // ranks of every element, in collection order
+  D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4);
+  if (D.total)
+    hipLaunchKernelGGL(k_reassemble, dim3((unsigned)((D.total + 255) / 256)), dim3(256), 0, s, off, n, D.total, D.spart.as<uint32_t>(), G,
+                       D.segoff.as<uint32_t>(), gathered, D.share_bytes, D.ranks_at, ds, D.rankv.as<uint32_t>());
+  // components: the slices' forests united
+  T.parent.ensure((size_t)n * 4);
+  D.root.ensure((size_t)n * 4);
+  hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
+  hipLaunchKernelGGL(k_uf_merge, dim3((unsigned)(((uint64_t)G * n + 255) / 256)), dim3(256), 0, s, gathered, D.share_bytes, D.roots_at, G, n,
+                     T.parent.as<uint32_t>());
+  hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, D.root.as<uint32_t>());
+  // frequent hashes: the per-sketch records (which of them it holds, and where)
+  if (D.split) {
+    D.fmask.ensure((size_t)n * 8); D.fpos.ensure((size_t)n * kMaxFreq * 4);
+    HIP_CHECK(hipMemsetAsync(D.fmask.ptr, 0, (size_t)n * 8, s));
+    hipLaunchKernelGGL(k_freq_records, dim3((n + 255) / 256, kMaxFreq), dim3(256), 0, s, D.hashes, off, n, ds,
+                       D.fmask.as<unsigned long long>(), D.fpos.as<uint32_t>());
+  }
+  // range boundaries of the tiled kernel (slice after slice) and where every sketch crosses them
+  D.hbound.ensure((size_t)D.R * 8);
+  for (uint32_t g = 0; g < G; g++)
+    HIP_CHECK(hipMemcpyAsync(D.hbound.as<uint64_t>() + (size_t)g * D.Rg, gathered + (size_t)g * D.share_bytes + D.hbound_at,
+                             (size_t)D.Rg * 8, hipMemcpyDeviceToDevice, s));
+  D.part.ensure((size_t)n * (D.R + 1) * 4);
+  hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)n * (D.R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, n,
+                     D.hbound.as<uint64_t>(), D.R, D.part.as<uint32_t>());
+  HIP_CHECK(hipGetLastError());
+  D.finished = true;
+  (void)dev;
+}
+
+void collection_free(CollectionDict* D) { delete D; }
+static CollectionDict& implicit_dict();
+static void release_implicit_dict() {
+  CollectionDict& D = implicit_dict();
+  for (DeviceBuffer* b : {&D.off, &D.splitters, &D.spart, &D.segoff, &D.share, &D.dstate, &D.rankv, &D.root, &D.fmask, &D.fpos,
+                          &D.hbound, &D.part})
+    b->release();
+  D.finished = false;
+}
+
+// rows [row_lo, row_hi) x columns [col_lo, col_hi) of the collection's all-vs-all matrix; outputs row-major
+// (row_hi - row_lo) x (col_hi - col_lo).  own_mode: see PairScope (1 needs rows == columns == everything, 2 needs
+// columns == everything; both need one num).
+void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, uint32_t col_lo, uint32_t col_hi, uint32_t num,
+                        const uint32_t* row_nums, uint32_t own_mode, const CompareOut& out, Device& dev, hipStream_t s) {
+  CollectionDict& D = *Dp;
+  if (!D.finished) throw_internal("collection_compare before collection_finish");
+  if (row_lo > row_hi || row_hi > D.n || col_lo > col_hi || col_hi > D.n) throw_internal("collection_compare: block outside the collection");
+  const uint32_t nrows = row_hi - row_lo, ncols = col_hi - col_lo;
+  if (nrows == 0 || ncols == 0) return;
   TiledScratch& T = tiled_scratch();
   const CompareTuning tune = compare_get_tuning();
   const TiledExperiments& ex = tiled_experiments();
-  // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
-  const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
-  const bool symmetric = same && row_nums == nullptr && tune.use_symmetry != 0;
-  // a row block that is a slice of the column set (one rank's rows of the gathered signatures):
-  // its ranks are a slice of the columns' ranks, nothing extra to sort
-  const bool inside = !same && rows.hashes >= cols.hashes && rows.hashes + nr_elems <= cols.hashes + nc_elems;
-  const uint64_t n = same ? nr_elems : (inside ? nc_elems : nr_elems + nc_elems);
-  if (n >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
+  const bool all_cols = col_lo == 0 && col_hi == D.n;
+  if (row_nums || !tune.use_symmetry) own_mode = 0;
+  if (own_mode == 1 && !(all_cols && row_lo == 0 && row_hi == D.n)) own_mode = 0;
+  if (own_mode == 2 && !all_cols) own_mode = 0;
+  const bool same = own_mode == 1;      // one slot order serves both axes
+  PairScope sc;
+  sc.own_mode = own_mode; sc.ntotal = D.n; sc.row_base = row_lo; sc.col_base = col_lo;
+  sc.mir_lo = own_mode ? row_lo : 0; sc.mir_hi = own_mode ? row_hi : 0;
   const bool want_cc = out.count_common || out.containment;
+  const uint64_t* off = D.off.as<uint64_t>();
+  SketchSet rows, cols;
+  rows.hashes = D.hashes; rows.offsets = off + row_lo; rows.n = nrows;
+  cols.hashes = D.hashes; cols.offsets = off + col_lo; cols.n = ncols;
   // the AUTO route's pair limit, clamped ONCE so that the work list sized from it always holds what the device-side
   // choice (k_plan_route, same value) can produce: a tuning value never changes a result or raises
   const uint64_t kWorkCapMax = 1ull << 26;
-  const uint64_t comp_limit = std::min<uint64_t>(tune.comp_pairs_limit, kWorkCapMax > cols.n ? kWorkCapMax - cols.n : 0);
+  const uint64_t comp_limit = std::min<uint64_t>(tune.comp_pairs_limit, kWorkCapMax > ncols ? kWorkCapMax - ncols : 0);
   T.plan.ensure(sizeof(PlanState));
   PlanState* st = T.plan.as<PlanState>();
   HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PlanState), s));
 
-  // ---- dictionary-encode: sort (hash, origin), then run ids -> rank[origin]
-  T.keys0.ensure(n * 8); T.keys1.ensure(n * 8); T.org0.ensure(n * 4); T.org1.ensure(n * 4);   // origins: element indices < 2^31
-  if (inside) {
-    HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
-  } else {
-    HIP_CHECK(hipMemcpyAsync(T.keys0.ptr, rows.hashes, nr_elems * 8, hipMemcpyDeviceToDevice, s));
-    if (!same) HIP_CHECK(hipMemcpyAsync(T.keys0.as<uint64_t>() + nr_elems, cols.hashes, nc_elems * 8, hipMemcpyDeviceToDevice, s));
-  }
-  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.org0.as<uint32_t>(), n);
-  // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
-  int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), n,
-                               dev.scratch, s, 0xffu);
-  uint64_t* sk = cur ? T.keys1.as<uint64_t>() : T.keys0.as<uint64_t>();
-  uint32_t* so = cur ? T.org1.as<uint32_t>() : T.org0.as<uint32_t>();
-
-  // ---- runs of equal hashes: dense ranks (for the tiled kernel) and run lengths (document frequencies)
-  const uint32_t M = same ? cols.n : rows.n + cols.n;
-  T.uniq.ensure(n * 8); T.starts.ensure((n + 1) * 4); T.rank.ensure(n * 4); T.runid.ensure(n * 4);
-  run_length_encode_u64_async(sk, n, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr,
-                              &st->nruns, nullptr, T.runid.as<uint32_t>());   // (ranks by origin: k_rank_scatter, tiled route only)
-  // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
-  const bool split = tune.split_frequent != 0 && M >= 32;
-  const uint8_t* isfreq = nullptr;
-  if (split) {
-    T.isfreq.ensure(n);
-    HIP_CHECK(hipMemsetAsync(T.isfreq.ptr, 0, n, s));
-    const uint32_t threshold = std::max<uint32_t>(16u, M / 4);
-    hipLaunchKernelGGL(k_freq_mark, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, T.starts.as<uint32_t>(),
-                       (uint32_t)n, threshold, st);
-    hipLaunchKernelGGL(k_freq_finalize, dim3(1), dim3(64), 0, s, st, T.isfreq.as<uint8_t>());
-    isfreq = T.isfreq.as<uint8_t>();
-  }
-
-  // ---- components of the "shares a hash" graph (lock-free union-find over the runs of equal hashes)
-  T.node.ensure((size_t)(n + (inside ? nr_elems : 0)) * 4);
-  T.parent.ensure((size_t)M * 4); T.root.ensure((size_t)M * 4);
-  uint32_t* d_node = T.node.as<uint32_t>();
-  auto elem_nodes = [&](const SketchSet& set, uint64_t ne, uint32_t base, uint32_t* dst) {
-    if (ne) hipLaunchKernelGGL(k_elem_node, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, set.offsets, set.n, ne, base, dst);
-  };
-  if (same) elem_nodes(cols, nc_elems, 0, d_node);
-  else if (inside) { elem_nodes(cols, nc_elems, rows.n, d_node); elem_nodes(rows, nr_elems, 0, d_node + n); }
-  else { elem_nodes(rows, nr_elems, 0, d_node); elem_nodes(cols, nc_elems, rows.n, d_node + nr_elems); }
-  hipLaunchKernelGGL(k_uf_init, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M);
-  // 1/256 sample straight to the atomic path, then 1/16 and everything through the cached filter
-  hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((n / 256 + 256) / 256)), dim3(256), 0, s, sk, so, d_node, n,
-                     T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
-  hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((n / 16 + 256) / 256)), dim3(256), 0, s, sk, so, d_node, n,
-                     T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
-  hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sk, so, d_node, n,
-                     T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
-  if (inside && nr_elems)
-    hipLaunchKernelGGL(k_uf_alias, dim3((unsigned)((nr_elems + 255) / 256)), dim3(256), 0, s, d_node + n, d_node, nr_elems,
-                       (uint64_t)(rows.hashes - cols.hashes), T.parent.as<uint32_t>());
-  hipLaunchKernelGGL(k_uf_roots, dim3((M + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), M, T.root.as<uint32_t>());
-  HIP_CHECK(hipGetLastError());
-
   // ---- slot orders: sketches sorted by component (stable: the index is the low half of the key)
-  const uint32_t* root_r = T.root.as<uint32_t>();
-  const uint32_t* root_c = same ? root_r : root_r + rows.n;
-  T.pk0.ensure((size_t)rows.n * 8); T.pk1.ensure((size_t)rows.n * 8);
-  hipLaunchKernelGGL(k_plan_keys, dim3((rows.n + 255) / 256), dim3(256), 0, s, root_r, rows.n, T.pk0.as<uint64_t>());
-  const uint64_t* rkey = radix_sort_u64_keys(T.pk0.as<uint64_t>(), T.pk1.as<uint64_t>(), rows.n, dev.scratch, s,
-                                             plan_key_passes(M, rows.n)) ? T.pk1.as<uint64_t>() : T.pk0.as<uint64_t>();
+  const uint32_t* root_r = D.root.as<uint32_t>() + row_lo;
+  const uint32_t* root_c = D.root.as<uint32_t>() + col_lo;
+  T.pk0.ensure((size_t)nrows * 8); T.pk1.ensure((size_t)nrows * 8);
+  hipLaunchKernelGGL(k_plan_keys, dim3((nrows + 255) / 256), dim3(256), 0, s, root_r, nrows, T.pk0.as<uint64_t>());
+  const uint64_t* rkey = radix_sort_u64_keys(T.pk0.as<uint64_t>(), T.pk1.as<uint64_t>(), nrows, dev.scratch, s,
+                                             plan_key_passes(D.n, nrows)) ? T.pk1.as<uint64_t>() : T.pk0.as<uint64_t>();
   const uint64_t* ckey = rkey;
   if (!same) {
-    T.pk2.ensure((size_t)cols.n * 8); T.pk3.ensure((size_t)cols.n * 8);
-    hipLaunchKernelGGL(k_plan_keys, dim3((cols.n + 255) / 256), dim3(256), 0, s, root_c, cols.n, T.pk2.as<uint64_t>());
-    ckey = radix_sort_u64_keys(T.pk2.as<uint64_t>(), T.pk3.as<uint64_t>(), cols.n, dev.scratch, s, plan_key_passes(M, cols.n))
+    T.pk2.ensure((size_t)ncols * 8); T.pk3.ensure((size_t)ncols * 8);
+    hipLaunchKernelGGL(k_plan_keys, dim3((ncols + 255) / 256), dim3(256), 0, s, root_c, ncols, T.pk2.as<uint64_t>());
+    ckey = radix_sort_u64_keys(T.pk2.as<uint64_t>(), T.pk3.as<uint64_t>(), ncols, dev.scratch, s, plan_key_passes(D.n, ncols))
                ? T.pk3.as<uint64_t>() : T.pk2.as<uint64_t>();
   }
   // ---- per slot, the other side's slots of the same component; pairs that can share a hash
-  T.rng.ensure(((size_t)rows.n + cols.n) * 2 * 4);
-  uint32_t* col_lo = T.rng.as<uint32_t>();           // by row slot
-  uint32_t* col_hi = col_lo + rows.n;
-  uint32_t* row_lo = same ? col_lo : col_hi + rows.n; // by column slot
-  uint32_t* row_hi = same ? col_hi : row_lo + cols.n;
-  hipLaunchKernelGGL(k_plan_ranges, dim3((rows.n + 255) / 256), dim3(256), 0, s, rkey, rows.n, ckey, cols.n, col_lo, col_hi, st);
+  T.rng.ensure(((size_t)nrows + ncols) * 2 * 4);
+  uint32_t* col_lo_s = T.rng.as<uint32_t>();              // by row slot
+  uint32_t* col_hi_s = col_lo_s + nrows;
+  uint32_t* row_lo_s = same ? col_lo_s : col_hi_s + nrows; // by column slot
+  uint32_t* row_hi_s = same ? col_hi_s : row_lo_s + ncols;
+  hipLaunchKernelGGL(k_plan_ranges, dim3((nrows + 255) / 256), dim3(256), 0, s, rkey, nrows, ckey, ncols, col_lo_s, col_hi_s, st);
   if (!same)
-    hipLaunchKernelGGL(k_plan_ranges, dim3((cols.n + 255) / 256), dim3(256), 0, s, ckey, cols.n, rkey, rows.n, row_lo, row_hi,
+    hipLaunchKernelGGL(k_plan_ranges, dim3((ncols + 255) / 256), dim3(256), 0, s, ckey, ncols, rkey, nrows, row_lo_s, row_hi_s,
                        (PlanState*)nullptr);
   hipLaunchKernelGGL(k_plan_route, dim3(1), dim3(1), 0, s, st, tune.route, tune.visit_all_tiles, (unsigned long long)comp_limit);
   HIP_CHECK(hipGetLastError());
 
-  // ---- the per-sketch records of the frequent hashes (which of them it holds, and where)
-  const unsigned long long* fmask = nullptr;
-  if (split) {
-    T.nfirst.ensure((size_t)M * 8); T.fmask.ensure((size_t)M * 8); T.fpos.ensure((size_t)M * kMaxFreq * 4);
-    HIP_CHECK(hipMemsetAsync(T.fmask.ptr, 0, (size_t)M * 8, s));
-    uint64_t* nf = T.nfirst.as<uint64_t>();
-    if (same) {
-      hipLaunchKernelGGL(k_node_first, dim3((cols.n + 255) / 256), dim3(256), 0, s, cols.offsets, cols.n, (uint64_t)0, 0u, nf);
-    } else {
-      // rows are nodes 0 .. rows.n-1 (their elements start the pool, or -- a view of the columns -- are counted from the
-      // view's first element); columns are nodes rows.n ..
-      hipLaunchKernelGGL(k_node_first, dim3((rows.n + 255) / 256), dim3(256), 0, s, rows.offsets, rows.n, (uint64_t)0, 0u, nf);
-      hipLaunchKernelGGL(k_node_first, dim3((cols.n + 255) / 256), dim3(256), 0, s, cols.offsets, cols.n,
-                         (uint64_t)(inside ? 0 : nr_elems), rows.n, nf);
-    }
-    hipLaunchKernelGGL(k_freq_fill, dim3((unsigned)std::min<uint32_t>((M + 255) / 256, 64u), kMaxFreq), dim3(256), 0, s,
-                       T.starts.as<uint32_t>(), (uint32_t)n, so, d_node, nf, inside ? d_node + n : (const uint32_t*)nullptr,
-                       inside ? (uint64_t)(rows.hashes - cols.hashes) : 0ull, inside ? nr_elems : 0ull, st,
-                       T.fmask.as<unsigned long long>(), T.fpos.as<uint32_t>());
-    HIP_CHECK(hipGetLastError());
-    fmask = T.fmask.as<unsigned long long>();
-  }
-
   // ---- every pair as if it shared nothing but frequent hashes; the compare kernels overwrite the pairs they walk
   // (with every tile launched nothing would be left: skipped)
-  const uint64_t np = (uint64_t)rows.n * cols.n;
+  const uint64_t np = (uint64_t)nrows * ncols;
   if (!(tune.visit_all_tiles && tune.route == kRouteTiled)) {
+    const unsigned long long* fm = D.split ? D.fmask.as<unsigned long long>() : nullptr;
+    const uint32_t* fp = D.split ? D.fpos.as<uint32_t>() : nullptr;
     dev.prof_begin(s);
-    hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, rows.n, cols.offsets,
-                       cols.n, num, row_nums, out, fmask, T.fpos.as<uint32_t>(), same ? 0u : rows.n);
+    hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, nrows, cols.offsets, ncols, num,
+                       row_nums, out, fm ? fm + row_lo : nullptr, fp ? fp + (size_t)row_lo * kMaxFreq : nullptr,
+                       fm ? fm + col_lo : nullptr, fp ? fp + (size_t)col_lo * kMaxFreq : nullptr);
     HIP_CHECK(hipGetLastError());
     dev.prof_end("compare_fill", s);
   }
@@ -1200,27 +1495,26 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   // ---- per-component pair kernel: one workgroup per (column, <= 32 rows of its component)
   uint32_t work_cap = 0;
   if (tune.route != kRouteTiled) {
-    // the route is taken when pairs <= comp_pairs_limit: every item holds a pair, every column adds at most one
+    // the route is taken when pairs <= comp_limit: every item holds a pair, every column adds at most one
     // partly filled item.  (A forced route on a huge block is capped; the overflow is reported.)
-    uint64_t cap = (tune.route == kRouteComponents ? ((uint64_t)cols.n * ((rows.n + kRowsPerItem - 1) / kRowsPerItem))
-                                                   : comp_limit) + cols.n;
+    uint64_t cap = (tune.route == kRouteComponents ? ((uint64_t)ncols * ((nrows + kRowsPerItem - 1) / kRowsPerItem)) : comp_limit) + ncols;
     if (cap > kWorkCapMax) cap = kWorkCapMax;
     work_cap = (uint32_t)cap;
-    T.cnt.ensure((size_t)cols.n * 4);
+    T.cnt.ensure((size_t)ncols * 4);
     T.work.ensure((size_t)work_cap * sizeof(CompWork));
-    hipLaunchKernelGGL(k_comp_count, dim3((cols.n + 255) / 256), dim3(256), 0, s, cols.n, row_lo, row_hi, symmetric ? 1u : 0u,
+    hipLaunchKernelGGL(k_comp_count, dim3((ncols + 255) / 256), dim3(256), 0, s, ncols, row_lo_s, row_hi_s, same ? 1u : 0u,
                        T.cnt.as<uint32_t>(), st);
-    exclusive_scan_u32_dev(T.cnt.as<uint32_t>(), cols.n, &st->nwork, dev.scratch, s);
-    hipLaunchKernelGGL(k_comp_fill, dim3((cols.n + 255) / 256), dim3(256), 0, s, ckey, cols.n, row_lo, row_hi, symmetric ? 1u : 0u,
+    exclusive_scan_u32_dev(T.cnt.as<uint32_t>(), ncols, &st->nwork, dev.scratch, s);
+    hipLaunchKernelGGL(k_comp_fill, dim3((ncols + 255) / 256), dim3(256), 0, s, ckey, ncols, row_lo_s, row_hi_s, same ? 1u : 0u,
                        T.cnt.as<uint32_t>(), reinterpret_cast<CompWork*>(T.work.ptr), work_cap, st);
-    const uint32_t col_max = max_len;   // bound on the longest column (max over both sides)
+    const uint32_t col_max = D.max_len;
     const bool q_lds = col_max <= 8192;
     const size_t lds = q_lds ? (size_t)(col_max ? col_max : 1) * 8 : 16;
     const unsigned grid = (unsigned)std::min<uint64_t>(work_cap, (uint64_t)dev.cu_count() * 8);
     dev.prof_begin(s);
 #define SMH_CC(L_, C_) hipLaunchKernelGGL((k_compare_comp<L_, C_>), dim3(grid), dim3(256), lds, s, rows, cols, \
                                           reinterpret_cast<const CompWork*>(T.work.ptr), &st->nwork, work_cap, rkey, num, row_nums, \
-                                          symmetric ? 1u : 0u, out)
+                                          sc, out)
     if (q_lds) { if (want_cc) SMH_CC(true, true); else SMH_CC(true, false); }
     else { if (want_cc) SMH_CC(false, true); else SMH_CC(false, false); }
 #undef SMH_CC
@@ -1228,68 +1522,48 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     dev.prof_end("compare_comp", s);
   }
 
-  // ---- tiled kernel: dense ranks, ranges of rank space, partition table, tile list, launch
+  // ---- tiled kernel: tile list, launch
   const int wpb = ex.wpb, minw = ex.minw;
   uint32_t tiles_cap = 0;
   if (tune.route != kRouteComponents) {
-    hipLaunchKernelGGL(k_rank_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T.runid.as<uint32_t>(), so, n,
-                       T.rank.as<uint32_t>(), st);
-    // ranges: about 24 pooled elements per sketch per range, so a 64+64 tile stages ~3000 dwords;
-    // granularity from the LONGEST sketch (its segments must fit the LDS stage); tiles of shorter
-    // sketches walk several ranges per step
-    uint32_t R = (uint32_t)(((uint64_t)max_len + ex.per_range - 1) / ex.per_range);
-    if (R < 1) R = 1;
-    if (R > 8192) R = 8192;
-    T.bound.ensure((size_t)(R + 1) * 4);
-    hipLaunchKernelGGL(k_bounds, dim3((R + 1 + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), st, (uint32_t)n, R,
-                       T.bound.as<uint32_t>());
-    const uint32_t* rrank = T.rank.as<uint32_t>();
-    const uint32_t* crank = same ? rrank : rrank + nr_elems;
-    if (inside) { crank = T.rank.as<uint32_t>(); rrank = crank + (rows.hashes - cols.hashes); }
-    T.rpart.ensure((size_t)rows.n * (R + 1) * 4);
-    hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)rows.n * (R + 1) + 255) / 256)), dim3(256), 0, s, rrank, rows.offsets,
-                       rows.n, T.bound.as<uint32_t>(), R, T.rpart.as<uint32_t>(), st);
-    const uint32_t* cpart = T.rpart.as<uint32_t>();
-    if (!same) {
-      T.cpart.ensure((size_t)cols.n * (R + 1) * 4);
-      hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)cols.n * (R + 1) + 255) / 256)), dim3(256), 0, s, crank, cols.offsets,
-                         cols.n, T.bound.as<uint32_t>(), R, T.cpart.as<uint32_t>(), st);
-      cpart = T.cpart.as<uint32_t>();
-    }
+    const uint32_t R = D.R;
+    TileTest tt;
+    tt.nrows = nrows; tt.ncols = ncols; tt.col_lo = col_lo_s; tt.col_hi = col_hi_s; tt.rkey = rkey; tt.ckey = ckey; tt.sc = sc;
+    tt.all_on = 0;
     // rows per tile: decided on the device from the number of 16-row tiles that hold sharing pairs
     // (fewer than ~4 rounds over the chip: 8-row, then 4-row tiles keep all wave slots busy;
     // profiles/r01_compare_small_geometry.txt).  With every tile launched the count is known here.
     const uint32_t fill_tiles = (uint32_t)dev.cu_count() * 32;
-    const uint32_t tiles_c = (cols.n + kTB - 1) / kTB;
+    const uint32_t tiles_c = (ncols + kTB - 1) / kTB;
     uint32_t forced_rpw = ex.rpw > 0 ? (uint32_t)ex.rpw : 0u;
     if (!forced_rpw && tune.visit_all_tiles) {
-      const uint64_t all16 = (uint64_t)((rows.n + 15) / 16) * tiles_c * (symmetric ? 1 : 2) / 2;
+      const uint64_t all16 = (uint64_t)((nrows + 15) / 16) * tiles_c * (same ? 1 : 2) / 2;
       forced_rpw = all16 >= fill_tiles ? 4u : (2 * all16 >= fill_tiles ? 2u : 1u);
     }
     if (!forced_rpw)
-      hipLaunchKernelGGL(k_tiles_count16, dim3((unsigned)std::min<uint64_t>(((uint64_t)((rows.n + 15) / 16) * tiles_c + 255) / 256, 4096)),
-                         dim3(256), 0, s, rows.n, cols.n, col_lo, col_hi, symmetric ? 1u : 0u, st);
+      hipLaunchKernelGGL(k_tiles_count16, dim3((unsigned)std::min<uint64_t>(((uint64_t)((nrows + 15) / 16) * tiles_c + 255) / 256, 4096)),
+                         dim3(256), 0, s, tt, st);
     hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, fill_tiles);
     // the list: at 16 rows per tile at most every tile; shorter tiles are only chosen when fewer than
     // fill_tiles 16-row tiles are flagged (each splits into at most 4)
     const uint32_t rows_min = (forced_rpw ? forced_rpw : 1u) * (uint32_t)wpb;
-    uint64_t cap = forced_rpw ? (uint64_t)((rows.n + rows_min - 1) / rows_min) * tiles_c
-                              : std::max<uint64_t>((uint64_t)((rows.n + 4 * wpb - 1) / (4 * wpb)) * tiles_c, 4ull * fill_tiles);
+    uint64_t cap = forced_rpw ? (uint64_t)((nrows + rows_min - 1) / rows_min) * tiles_c
+                              : std::max<uint64_t>((uint64_t)((nrows + 4 * wpb - 1) / (4 * wpb)) * tiles_c, 4ull * fill_tiles);
     if (cap >= (1ull << 30)) throw_internal("compare block: too many tiles");
     tiles_cap = (uint32_t)cap;
     T.tiles.ensure((size_t)tiles_cap * 8 + 8);
-    const uint64_t flag_tiles = (uint64_t)((rows.n + rows_min - 1) / rows_min) * tiles_c;   // the finest geometry the plan may pick
-    hipLaunchKernelGGL(k_flag_tiles, dim3((unsigned)std::min<uint64_t>((flag_tiles + 255) / 256, 8192)), dim3(256), 0, s, rows.n, cols.n,
-                       col_lo, col_hi, symmetric ? 1u : 0u, tune.visit_all_tiles ? 1u : 0u, (uint32_t)wpb, T.tiles.as<uint32_t>(),
-                       tiles_cap, st);
+    const uint64_t flag_tiles = (uint64_t)((nrows + rows_min - 1) / rows_min) * tiles_c;   // the finest geometry the plan may pick
+    tt.all_on = tune.visit_all_tiles ? 1u : 0u;
+    hipLaunchKernelGGL(k_flag_tiles, dim3((unsigned)std::min<uint64_t>((flag_tiles + 255) / 256, 8192)), dim3(256), 0, s, tt, (uint32_t)wpb,
+                       T.tiles.as<uint32_t>(), tiles_cap, st);
     HIP_CHECK(hipGetLastError());
     TiledArgs a;
-    a.rrank = rrank; a.roff = rows.offsets; a.rpart = T.rpart.as<uint32_t>(); a.nrows = rows.n;
-    a.crank = crank; a.coff = cols.offsets; a.cpart = cpart; a.ncols = cols.n;
+    a.rrank = D.rankv.as<uint32_t>(); a.roff = rows.offsets; a.rpart = D.part.as<uint32_t>() + (size_t)row_lo * (R + 1); a.nrows = nrows;
+    a.crank = D.rankv.as<uint32_t>(); a.coff = cols.offsets; a.cpart = D.part.as<uint32_t>() + (size_t)col_lo * (R + 1); a.ncols = ncols;
     a.R = R; a.num = num; a.row_nums = row_nums;
     a.tiles = T.tiles.as<uint32_t>(); a.tiles_cap = tiles_cap; a.rkey = rkey; a.ckey = ckey; a.st = st;
     a.use_xcd = ex.xcd ? 1u : 0u;
-    a.symmetric = symmetric ? 1u : 0u;
+    a.scope = sc;
     // LDS budget per workgroup ~18 KB so that 8 workgroups of 4 waves fit a CU: the merge loop is a
     // dependent LDS-read -> compare -> advance chain, and occupancy is what hides its latency
     // (profiles/r01_compare_geometry.txt: 575 -> 1000 M pairs/s from 3 to 8 waves per SIMD)
@@ -1320,7 +1594,9 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
 
   // ---- the one synchronisation of the call: what the plan decided, for the record
   PlanState h;
+  uint32_t hd[2] = {0, 0};   // DictState: nruns, nfreq
   HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(PlanState), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(hd, D.dstate.ptr, 8, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
   CompareStats rec;
   rec.route = h.route;
@@ -1332,12 +1608,62 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
     const uint32_t tr = h.rpw * (uint32_t)wpb;
     rec.rows_per_tile = tr;
     rec.tiles_visited = h.ntiles;
-    rec.tiles_total = (uint64_t)((rows.n + tr - 1) / tr) * ((cols.n + kTB - 1) / kTB);
+    rec.tiles_total = (uint64_t)((nrows + tr - 1) / tr) * ((ncols + kTB - 1) / kTB);
     rec.pairs_per_tile = (uint64_t)tr * kTB;
     rec.lds_overflow_steps = h.ovf_steps;
   }
-  rec.frequent_hashes = h.nfreq;
+  rec.frequent_hashes = D.split ? hd[1] : 0;
   set_stats(rec);
+}
+
+// rows x cols through the dictionary path: the same CSR on both axes is one collection compared with itself (upper
+// triangle + mirrors when there is one num); two different sets are concatenated into one collection and the block
+// rows x cols of its matrix is computed.
+static CollectionDict& implicit_dict() {
+  static CollectionDict* d = new CollectionDict();
+  return *d;
+}
+static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t nr_elems, uint64_t nc_elems,
+                         uint32_t num, const uint32_t* row_nums, const CompareOut& out, Device& dev,
+                         hipStream_t s, bool same_sets) {
+  TiledScratch& T = tiled_scratch();
+  // same_sets: the caller vouches that rows and columns are one CSR (same hashes, same offsets)
+  const bool same = same_sets && rows.hashes == cols.hashes && rows.n == cols.n && nr_elems == nc_elems;
+  std::vector<uint64_t> tmp_r, tmp_c, cat_off;
+  auto host_offsets = [&](const SketchSet& set, std::vector<uint64_t>& tmp) -> const uint64_t* {
+    if (set.h_offsets) return set.h_offsets;      // the caller had them at hand: no read-back
+    tmp.resize((size_t)set.n + 1);
+    HIP_CHECK(hipMemcpyAsync(tmp.data(), set.offsets, tmp.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return tmp.data();
+  };
+  const uint64_t* h_off = nullptr;
+  const uint64_t* hashes = nullptr;
+  const uint64_t* d_off = nullptr;
+  uint32_t n = 0;
+  if (same) {
+    h_off = host_offsets(cols, tmp_c);
+    hashes = cols.hashes; d_off = cols.offsets; n = cols.n;
+  } else {
+    // one collection: the rows' sketches, then the columns'
+    const uint64_t* ro = host_offsets(rows, tmp_r);
+    const uint64_t* co = host_offsets(cols, tmp_c);
+    n = rows.n + cols.n;
+    cat_off.resize((size_t)n + 1);
+    for (uint32_t i = 0; i <= rows.n; i++) cat_off[i] = ro[i] - ro[0];
+    for (uint32_t j = 0; j <= cols.n; j++) cat_off[rows.n + j] = nr_elems + (co[j] - co[0]);
+    h_off = cat_off.data();
+    T.cat.ensure(std::max<uint64_t>(nr_elems + nc_elems, 1) * 8);
+    if (nr_elems) HIP_CHECK(hipMemcpyAsync(T.cat.ptr, rows.hashes + ro[0], nr_elems * 8, hipMemcpyDeviceToDevice, s));
+    if (nc_elems) HIP_CHECK(hipMemcpyAsync(T.cat.as<uint64_t>() + nr_elems, cols.hashes + co[0], nc_elems * 8, hipMemcpyDeviceToDevice, s));
+    hashes = T.cat.as<uint64_t>();
+  }
+  // the dictionary object of these one-off calls is kept (its buffers only grow): no allocation per call
+  CollectionDict& D = implicit_dict();
+  collection_begin_into(D, hashes, d_off, h_off, n, 1, 0, dev, s);
+  collection_finish(&D, nullptr, dev, s);
+  if (same) collection_compare(&D, 0, n, 0, n, num, row_nums, 1, out, dev, s);
+  else collection_compare(&D, 0, rows.n, rows.n, n, num, row_nums, 0, out, dev, s);
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,
@@ -1371,8 +1697,7 @@ void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t
   const bool block_ok = nr_elems + nc_elems > 0;
   if (block_ok && (route == kRouteAuto ? (npairs >= 4096 && rows.n >= 8 && cols.n >= 16)
                                        : (route == kRouteComponents || route == kRouteTiled))) {
-    launch_tiled(rows, cols, nr_elems, nc_elems, max_row_len > max_col_len ? max_row_len : max_col_len, num, row_nums, out,
-                 dev, s, same_sets);
+    launch_tiled(rows, cols, nr_elems, nc_elems, num, row_nums, out, dev, s, same_sets);
     return;
   }
   // a few against many: the few side sits in LDS, the many side streams

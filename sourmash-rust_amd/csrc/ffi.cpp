@@ -534,8 +534,8 @@ int smh_compare_block_dev(const uint64_t* row_hashes_dev, const uint64_t* row_of
     HIP_CHECK(hipMemcpyAsync(E.cmp_oa.ptr, row_offsets, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(E.cmp_ob.ptr, col_offsets, (size_t)(n_cols + 1) * 8, hipMemcpyHostToDevice, s));
     smh::SketchSet R, C;
-    R.hashes = row_hashes_dev; R.offsets = E.cmp_oa.as<uint64_t>(); R.n = n_rows;
-    C.hashes = col_hashes_dev; C.offsets = E.cmp_ob.as<uint64_t>(); C.n = n_cols;
+    R.hashes = row_hashes_dev; R.offsets = E.cmp_oa.as<uint64_t>(); R.n = n_rows; R.h_offsets = row_offsets;
+    C.hashes = col_hashes_dev; C.offsets = E.cmp_ob.as<uint64_t>(); C.n = n_cols; C.h_offsets = col_offsets;
     smh::CompareOut o;
     o.jaccard = jaccard_dev; o.common = common_dev; o.size = size_dev; o.count_common = count_common_dev;
     o.containment = containment_dev;
@@ -721,6 +721,7 @@ int smh_index_compare(SmhIndex* rows, SmhIndex* cols, double* jaccard, uint64_t*
     smh::SketchSet R, C;
     R.hashes = rows->hashes.as<uint64_t>(); R.offsets = rows->offsets.as<uint64_t>(); R.n = rows->n;
     C.hashes = cols->hashes.as<uint64_t>(); C.offsets = cols->offsets.as<uint64_t>(); C.n = cols->n;
+    R.h_offsets = rows->h_offsets.data(); C.h_offsets = cols->h_offsets.data();
     smh::CompareOut o;
     o.common = common ? d_common : nullptr; o.size = size ? d_size : nullptr; o.jaccard = jaccard ? d_jac : nullptr;
     o.count_common = count_common ? d_cc : nullptr; o.containment = containment ? d_cont : nullptr;
@@ -734,6 +735,72 @@ int smh_index_compare(SmhIndex* rows, SmhIndex* cols, double* jaccard, uint64_t*
     if (jaccard) HIP_CHECK(hipMemcpyAsync(jaccard, d_jac, np * 8, hipMemcpyDeviceToHost, s));
     if (count_common) HIP_CHECK(hipMemcpyAsync(count_common, d_cc, np * 8, hipMemcpyDeviceToHost, s));
     if (containment) HIP_CHECK(hipMemcpyAsync(containment, d_cont, np * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
+// ---- SmhCollection: the dictionary of one collection (all-vs-all, shareable among ranks) ----
+struct SmhCollection { smh::CollectionDict* d = nullptr; };
+
+SmhCollection* smh_collection_begin(const uint64_t* hashes_dev, const uint64_t* offsets, uint32_t n, uint32_t world, uint32_t rank,
+                                    void* stream) {
+  SmhCollection* out = nullptr;
+  (void)pad_code([&] {
+    require(hashes_dev, "hashes_dev"); require(offsets, "offsets");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    std::unique_ptr<SmhCollection> c(new SmhCollection());
+    c->d = smh::collection_begin(hashes_dev, nullptr, offsets, n, world, rank, dev, s);
+    HIP_CHECK(hipStreamSynchronize(s));   // the share is complete when the call returns (the caller all-gathers it next)
+    out = c.release();
+  });
+  return out;
+}
+void smh_collection_free(SmhCollection* c) {
+  if (!c) return;
+  (void)pad_code([&] {
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    smh::collection_free(c->d);
+    delete c;
+  });
+}
+uint64_t smh_collection_share_bytes(const SmhCollection* c) { return c && c->d ? smh::collection_share_bytes(c->d) : 0; }
+const void* smh_collection_share(const SmhCollection* c) { return c && c->d ? smh::collection_share(c->d) : nullptr; }
+int smh_collection_share_to(const SmhCollection* c, void* dst_dev, void* stream) {
+  return pad_code([&] {
+    require(c, "collection"); require(dst_dev, "dst_dev");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    HIP_CHECK(hipMemcpyAsync(dst_dev, smh::collection_share(c->d), smh::collection_share_bytes(c->d), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+int smh_collection_finish(SmhCollection* c, const void* gathered_dev, void* stream) {
+  return pad_code([&] {
+    require(c, "collection");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    smh::collection_finish(c->d, gathered_dev, dev, s);
+    HIP_CHECK(hipStreamSynchronize(s));   // the gathered buffer may be released by the caller now
+  });
+}
+int smh_collection_compare(SmhCollection* c, uint32_t row_lo, uint32_t row_hi, uint32_t num, uint32_t ownership,
+                           double* jaccard_dev, uint64_t* common_dev, uint64_t* size_dev, uint64_t* count_common_dev,
+                           double* containment_dev, void* stream) {
+  return pad_code([&] {
+    require(c, "collection");
+    if (ownership > 2) smh::throw_internal("smh_collection_compare: ownership must be 0, 1 or 2");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    smh::CompareOut o;
+    o.jaccard = jaccard_dev; o.common = common_dev; o.size = size_dev; o.count_common = count_common_dev;
+    o.containment = containment_dev;
+    smh::collection_compare(c->d, row_lo, row_hi, 0, smh::collection_len(c->d), num, nullptr, ownership, o, dev, s);
     HIP_CHECK(hipStreamSynchronize(s));
   });
 }

@@ -145,8 +145,9 @@ void run_reduce(const uint32_t* starts, uint32_t nruns, uint32_t total_runs, uin
 // Sketches as CSR: hashes[offsets[i] .. offsets[i+1]) ascending and unique.
 struct SketchSet {
   const uint64_t* hashes = nullptr;
-  const uint64_t* offsets = nullptr;  // n+1 entries
+  const uint64_t* offsets = nullptr;  // n+1 entries (device)
   uint32_t n = 0;
+  const uint64_t* h_offsets = nullptr;  // the same n+1 entries in host memory when the caller has them (saves a read-back)
 };
 struct CompareOut {
   uint64_t* common = nullptr;  // |A ^ B ^ bottom_n(A u B)|   (reference src/lib.rs:470-499)
@@ -185,6 +186,24 @@ void compare_set_tuning(const CompareTuning& t);
 CompareTuning compare_get_tuning();
 CompareStats compare_last_stats();
 void release_compare_scratch();   // frees the tiled kernel's pre-pass buffers
+// The dictionary of one collection of sketches resident in HBM (CSR; element t of the collection is hashes_dev[offsets[0] + t]):
+// dense ranks of all its hashes, components, frequent hashes, range tables -- built once, by one owner or by `world`
+// cooperating owners (each holding the same CSR; owner `rank` sorts slice `rank` of hash space) with ONE all-gather of
+// collection_share() between collection_begin and collection_finish; then any number of block compares over it.
+// own_mode of collection_compare: 0 every pair of the block; 1 rows == columns == the whole collection with one num
+// (upper triangle + mirrors); 2 the rows are one rank's block of the all-vs-all matrix, columns == everything, one num:
+// only pairs (i, j) with (j - i) mod N < N/2 (ties: i < j) must be computed here, the others arrive from their owner's rank.
+struct CollectionDict;
+CollectionDict* collection_begin(const uint64_t* hashes_dev, const uint64_t* offsets_dev /*nullable*/, const uint64_t* offsets_host,
+                                 uint32_t n, uint32_t world, uint32_t rank, Device& dev, hipStream_t s);
+uint64_t collection_share_bytes(const CollectionDict* d);
+const void* collection_share(const CollectionDict* d);
+uint32_t collection_len(const CollectionDict* d);
+void collection_finish(CollectionDict* d, const void* gathered_dev, Device& dev, hipStream_t s);
+void collection_compare(CollectionDict* d, uint32_t row_lo, uint32_t row_hi, uint32_t col_lo, uint32_t col_hi, uint32_t num,
+                        const uint32_t* row_nums, uint32_t own_mode, const CompareOut& out, Device& dev, hipStream_t s);
+void collection_free(CollectionDict* d);
+
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
                           hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,

@@ -1480,9 +1480,11 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   uint32_t mr = 0, mc = 0;
   // the same list on both axes (all-vs-all): one upload, and the block compare may use symmetry
   const bool same_sets = rows.size() == cols.size() && std::equal(rows.begin(), rows.end(), cols.begin());
-  pack_sketches(rows, cmp_a, cmp_oa, &R, &mr, nullptr, s);
+  std::vector<uint64_t> h_off_r, h_off_c;
+  pack_sketches(rows, cmp_a, cmp_oa, &R, &mr, &h_off_r, s);
+  R.h_offsets = h_off_r.data();
   if (same_sets) { C = R; mc = mr; }
-  else pack_sketches(cols, cmp_b, cmp_ob, &C, &mc, nullptr, s);
+  else { pack_sketches(cols, cmp_b, cmp_ob, &C, &mc, &h_off_c, s); C.h_offsets = h_off_c.data(); }
   uint64_t row_total = 0, col_total = 0;
   for (auto* m : rows) row_total += m->mins.size();
   for (auto* m : cols) col_total += m->mins.size();

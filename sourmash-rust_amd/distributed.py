@@ -1,15 +1,27 @@
 """Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the
-GPU node, "gloo" in the CPU tests).  The reference has no distributed code at all;
-what is sharded here is what the path offers:
+GPU node, "gloo" in the CPU tests and in the shared-GPU rehearsals).  The reference has no distributed
+code at all; what is sharded here is what the path offers.
 
-  * compare matrix: independent pairs.  Rows are sharded in contiguous blocks; ONE all-gather of
-    the signatures gives every rank all columns; each rank computes its row block; nothing else is
-    exchanged (the row blocks stay on their rank).
-  * sketching: independent records.  Every rank sketches its shard of the records with no
-    collective at all; merge_sketch_across_ranks() is the optional final union.
+Compare matrix (N x N, all-vs-all, row blocks stay on their rank).  Every pair is still exactly
+KmerMinHash::compare of the two sketches (reference src/lib.rs:470-508); what is split is the work:
 
-The compute is injected (`compute_block`) so that the CPU tests can drive the same sharding and
-collective code with the oracle; the product default is the HIP path and raises without a GPU."""
+  1. ONE all-gather of the signatures: every rank holds every column.
+  2. The dictionary pre-pass (pooled sort of all hashes -> dense ranks, components of the "shares a
+     hash" graph, frequent hashes) is SHARDED by hash range: rank g sorts slice g of hash space
+     (1/world of the pooled hashes), then ONE all-gather of the ranks' shares (a few bytes per hash)
+     lets everybody assemble the whole dictionary (smh_collection_begin / _finish).
+  3. Symmetry is kept: row i OWNS the pairs (i, j) with (j - i) mod N < N/2 (ties: i < j) -- every
+     unordered pair has exactly one owner, every row owns N/2 pairs, so every rank walks 1/world of
+     the upper triangle's work.  A rank computes the pairs its rows own (plus the mirrors inside its
+     own diagonal block).
+  4. ONE all-to-all hands every rank the transposed blocks its rows do NOT own: rank c sends
+     out_c[:, rows of r]^T to rank r, which keeps the entries c's rows own.
+
+Sketching shards records across ranks with no data-path collective; union_across_ranks() is the
+optional final union of the per-rank partial sketches.
+
+The compute is injected (`engine`) so that the CPU tests drive the same sharding, ownership and
+exchange code with the oracle; the product default is the HIP path and raises without a GPU."""
 import numpy as np
 
 
@@ -21,35 +33,248 @@ def shard_range(n_total, world, rank):
     return lo, hi, per
 
 
-def _hip_compute_block(rows_t, n_rows, cols_t, n_cols, num, want):
-    from . import matrix
-    width = rows_t.shape[1]
-    row_off = np.arange(n_rows + 1, dtype=np.uint64) * np.uint64(width)
-    col_off = np.arange(n_cols + 1, dtype=np.uint64) * np.uint64(width)
-    out = matrix.compare_block_dev(rows_t, row_off, cols_t, col_off, num, want=want)
-    return {k: v[:n_rows, :n_cols] for k, v in out.items()}
+# ---------------------------------------------------------------------------------------------
+# pair ownership (the same rule as owns_pair() in csrc/compare_kernels.hip)
+
+def owns(i, j, n):
+    """Does row i own the pair (i, j) of an n x n all-vs-all matrix?  i, j: integer arrays/tensors
+    (broadcastable).  (j - i) mod n < n/2, ties (n even, distance n/2) go to the smaller index."""
+    d = (j - i) % n
+    return (2 * d < n) | ((2 * d == n) & (i < j))
 
 
-def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), compute_block=None, group=None):
+def block_needs(src_lo, src_hi, dst_lo, dst_hi, n):
+    """Does any row of [src_lo, src_hi) own a pair with a row of [dst_lo, dst_hi)?  Decides whether
+    src sends dst a block -- sender and receiver evaluate the same function.  (A superset test:
+    distances (j - i) mod n of the two intervals form one circular interval.)"""
+    if src_hi <= src_lo or dst_hi <= dst_lo:
+        return False
+    if (src_lo, src_hi) == (dst_lo, dst_hi):
+        return False
+    length = (src_hi - src_lo) + (dst_hi - dst_lo) - 1      # number of distinct differences j - i
+    if length >= n:
+        return True
+    a = (dst_lo - (src_hi - 1)) % n                         # smallest difference, mod n
+    half = n // 2                                           # distances 0..half may be owned
+    return a <= half or a + length > n
+
+
+# ---------------------------------------------------------------------------------------------
+# transports
+
+class _Comm:
+    """all_gather / all_to_all over torch.distributed.  With gloo and CUDA tensors (the shared-GPU
+    rehearsal) the data is staged through host memory."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.stage = self.on and dist.get_backend(group) == "gloo"
+
+    def all_gather(self, t):
+        """t: contiguous tensor, same shape on every rank -> (world * t.shape[0], ...)"""
+        import torch
+        if self.world == 1:
+            return t
+        src = t.contiguous()
+        if self.stage and src.is_cuda:
+            h = src.cpu()
+            out = torch.empty((self.world * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+            self.dist.all_gather_into_tensor(out, h, group=self.group)
+            return out.to(t.device)
+        out = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        self.dist.all_gather_into_tensor(out, src, group=self.group)
+        return out
+
+    def all_to_all(self, send, recv_numel, dtype, device):
+        """send: list (per peer) of flat contiguous tensors (possibly empty); recv_numel: elements
+        expected from every peer -> list of flat tensors."""
+        import torch
+        if self.world == 1:
+            return [send[0]]
+        dev = torch.device("cpu") if self.stage else device
+        inp = torch.cat([s.reshape(-1).to(dev) for s in send]) if sum(s.numel() for s in send) else torch.empty(0, dtype=dtype, device=dev)
+        out = torch.empty(sum(recv_numel), dtype=dtype, device=dev)
+        self.dist.all_to_all_single(out, inp, list(recv_numel), [s.numel() for s in send], group=self.group)
+        out = out.to(device)
+        res, at = [], 0
+        for k in recv_numel:
+            res.append(out[at:at + k])
+            at += k
+        return res
+
+
+# ---------------------------------------------------------------------------------------------
+# engines: what computes a rank's row block
+
+class HipEngine:
+    """The product path: smh_collection_* (csrc/compare_kernels.hip)."""
+
+    def begin(self, allsigs, n_total, world, rank):
+        from . import matrix
+        width = allsigs.shape[1]
+        self.offsets = np.arange(n_total + 1, dtype=np.uint64) * np.uint64(width)
+        self.coll = matrix.Collection(allsigs, self.offsets, world, rank)
+        self.device = allsigs.device
+        self.world, self.rank = world, rank
+
+    def share(self):
+        import torch
+        t = torch.empty(self.coll.share_bytes, dtype=torch.uint8, device=self.device)
+        self.coll.share_to(t)
+        return t
+
+    def finish(self, gathered):
+        self.coll.finish(gathered)
+
+    def compare(self, lo, hi, num, want, ownership):
+        return self.coll.compare(lo, hi, num, want=want, ownership=ownership)
+
+    def lengths(self, n_total):
+        import torch
+        return torch.from_numpy(np.diff(self.offsets).astype(np.int64)).to(self.device)
+
+    def close(self):
+        self.coll.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the exchange of the blocks a rank's rows do not own
+
+def mirror_send_list(out, blocks, rank, n_total):
+    """out: (n_local, n_total) tensor of this rank's row block.  -> per peer the flat transposed
+    block out[:, rows of peer]^T when this rank's rows own pairs with the peer's rows, else empty."""
+    lo, hi = blocks[rank]
+    send = []
+    for c, (clo, chi) in enumerate(blocks):
+        if c != rank and block_needs(lo, hi, clo, chi, n_total):
+            send.append(out[:, clo:chi].t().contiguous().reshape(-1))
+        else:
+            send.append(out.new_empty(0))
+    return send
+
+
+def mirror_recv_sizes(blocks, rank, n_total):
+    lo, hi = blocks[rank]
+    return [(hi - lo) * (phi - plo) if p != rank and block_needs(plo, phi, lo, hi, n_total) else 0
+            for p, (plo, phi) in enumerate(blocks)]
+
+
+def mirror_apply(out, recv, blocks, rank, n_total):
+    """keeps, from every received block, the entries the sender's rows own"""
+    import torch
+    lo, hi = blocks[rank]
+    rows = torch.arange(lo, hi, device=out.device).unsqueeze(1)
+    for p, (plo, phi) in enumerate(blocks):
+        if p == rank or recv[p].numel() == 0:
+            continue
+        cols = torch.arange(plo, phi, device=out.device).unsqueeze(0)
+        theirs = owns(cols, rows, n_total)               # the sender's row j owns (j, i)
+        blk = recv[p].reshape(hi - lo, phi - plo)
+        out[:, plo:phi] = torch.where(theirs, blk, out[:, plo:phi])
+
+
+def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), engine=None, group=None, symmetric=True,
+                           timings=None):
     """local_sigs: (per, width) int64 tensor holding this rank's rows (rows beyond its share are
     padding), every rank with the same `per` = ceil(n_total / world).  Returns this rank's row
-    block: dict name -> (n_local, n_total) tensor.  One all_gather_into_tensor, no other collective."""
+    block: dict name -> (n_local, n_total) tensor.  Collectives: all-gather of the signatures,
+    all-gather of the dictionary shares, all-to-all of the mirrored blocks (see the module text);
+    symmetric=False computes every pair of the row block locally instead (no all-to-all)."""
+    import time
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    lo, hi, per = shard_range(n_total, world, rank)
+    comm = _Comm(group)
+    world, rank = comm.world, comm.rank
+    blocks = [shard_range(n_total, world, r)[:2] for r in range(world)]
+    lo, hi = blocks[rank]
+    per = shard_range(n_total, world, rank)[2]
     assert local_sigs.shape[0] == per, "every rank passes ceil(n_total/world) rows (pad the last block)"
-    if world > 1:
-        allsigs = torch.empty((world * per, local_sigs.shape[1]), dtype=local_sigs.dtype, device=local_sigs.device)
-        dist.all_gather_into_tensor(allsigs, local_sigs.contiguous(), group=group)
-    else:
-        allsigs = local_sigs
-    fn = compute_block or _hip_compute_block
-    # the row block as a VIEW of the gathered set: the block compare then sees that its rows are a
-    # slice of its columns and encodes the columns only
-    rows = allsigs[lo:lo + per] if world > 1 else local_sigs
-    return fn(rows, hi - lo, allsigs, n_total, num, want)
+    eng = engine or HipEngine()
+    want = tuple(want)
+    mark = []
+
+    def tick(name):
+        if timings is not None:
+            if local_sigs.is_cuda:
+                torch.cuda.synchronize()
+            mark.append((name, time.perf_counter()))
+
+    tick("start")
+    allsigs = comm.all_gather(local_sigs.contiguous())
+    tick("all_gather_signatures")
+    eng.begin(allsigs, n_total, world, rank)
+    tick("dictionary_slice")
+    gathered = comm.all_gather(eng.share()) if world > 1 else None
+    tick("all_gather_shares")
+    eng.finish(gathered)
+    del gathered
+    tick("dictionary_assemble")
+    exchange = symmetric and world > 1
+    # containment = count_common / |row|: the mirrored value has the other denominator, so it is
+    # derived after the exchange from the (symmetric) count
+    kernel_want = tuple(k for k in want if k != "containment") + (("count_common",) if "containment" in want and "count_common" not in want else ()) \
+        if exchange else want
+    out = eng.compare(lo, hi, num, kernel_want, (2 if exchange else (1 if world == 1 and symmetric else 0)))
+    tick("compare")
+    if exchange:
+        for name in kernel_want:
+            t = out[name]
+            recv = comm.all_to_all(mirror_send_list(t, blocks, rank, n_total), mirror_recv_sizes(blocks, rank, n_total),
+                                   t.dtype, t.device)
+            mirror_apply(t, recv, blocks, rank, n_total)
+        if "containment" in want:
+            lens = eng.lengths(n_total)[lo:hi].to(torch.float64).unsqueeze(1)
+            out["containment"] = out["count_common"].to(torch.float64) / lens
+            if "count_common" not in want:
+                del out["count_common"]
+        tick("exchange_mirrors")
+    eng.close()
+    if timings is not None:
+        for (_, t0), (name, t1) in zip(mark[:-1], mark[1:]):
+            timings[name] = timings.get(name, 0.0) + (t1 - t0)
+    return out
+
+
+def simulate_sharded(allsigs, n_total, num, world, want=("jaccard",), engine_factory=None, symmetric=True):
+    """The same steps as compare_matrix_sharded for `world` ranks run one after the other in ONE
+    process (no process group): the collectives become concatenations and list shuffles, everything
+    else -- slices of the dictionary, ownership, the mirrored blocks -- is the code the ranks run.
+    allsigs: (>= n_total, width) tensor.  Returns the list of the ranks' row blocks."""
+    import torch
+    blocks = [shard_range(n_total, world, r)[:2] for r in range(world)]
+    engs = [(engine_factory or HipEngine)() for _ in range(world)]
+    for r, e in enumerate(engs):
+        e.begin(allsigs, n_total, world, r)
+    gathered = torch.cat([e.share() for e in engs]) if world > 1 else None
+    for e in engs:
+        e.finish(gathered)
+    want = tuple(want)
+    exchange = symmetric and world > 1
+    kernel_want = tuple(k for k in want if k != "containment") + (("count_common",) if "containment" in want and "count_common" not in want else ()) \
+        if exchange else want
+    outs = [e.compare(blocks[r][0], blocks[r][1], num, kernel_want, (2 if exchange else (1 if world == 1 and symmetric else 0)))
+            for r, e in enumerate(engs)]
+    if exchange:
+        for name in kernel_want:
+            sends = [mirror_send_list(outs[r][name], blocks, r, n_total) for r in range(world)]
+            for r in range(world):
+                sizes = mirror_recv_sizes(blocks, r, n_total)
+                recv = [sends[p][r] for p in range(world)]
+                assert [t.numel() for t in recv] == sizes, "sender and receiver disagree about a block"
+                mirror_apply(outs[r][name], recv, blocks, r, n_total)
+        if "containment" in want:
+            for r, e in enumerate(engs):
+                lens = e.lengths(n_total)[blocks[r][0]:blocks[r][1]].to(torch.float64).unsqueeze(1)
+                outs[r]["containment"] = outs[r]["count_common"].to(torch.float64) / lens
+                if "count_common" not in want:
+                    del outs[r]["count_common"]
+    for e in engs:
+        e.close()
+    return outs
 
 
 def shard_records(n_records, world, rank):

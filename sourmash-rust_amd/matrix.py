@@ -87,3 +87,68 @@ def compare_block_dev(row_hashes, row_offsets, col_hashes, col_offsets, num, wan
          C.c_void_p(col_hashes.data_ptr()), co.ctypes.data_as(u64p), m, num,
          p("jaccard"), p("common"), p("size"), p("count_common"), p("containment"), C.c_void_p(stream))
     return outs
+
+
+OWN_ALL, OWN_TRIANGLE, OWN_CIRCULAR = 0, 1, 2
+
+
+class Collection:
+    """The dictionary of one collection of sketches resident in HBM (additive ABI smh_collection_*): dense ranks of
+    all hashes, components, frequent hashes -- built once, by this process alone (world=1) or together with the other
+    ranks of a job (each sorts one slice of hash space; ONE all-gather of the shares in between), then any number of
+    block compares.  hashes: CUDA int64/uint64 tensor (kept alive by this object); offsets: host uint64 array, n+1."""
+
+    def __init__(self, hashes, offsets, world=1, rank=0, stream=None):
+        import torch
+        self._hashes = hashes
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n = len(self.offsets) - 1
+        self.world, self.rank = world, rank
+        self._stream = stream if stream is not None else torch.cuda.current_stream(hashes.device).cuda_stream
+        L = lib()
+        self._p = None
+        self._p = call(L.smh_collection_begin, C.c_void_p(hashes.data_ptr()), self.offsets.ctypes.data_as(u64p), self.n, world, rank,
+                       C.c_void_p(self._stream))
+        self.share_bytes = int(L.smh_collection_share_bytes(self._p))
+
+    def share_to(self, dst):
+        """copies this rank's share into `dst` (a CUDA uint8 tensor of share_bytes bytes, e.g. its slot of the gather buffer)"""
+        assert dst.numel() * dst.element_size() == self.share_bytes and dst.is_contiguous()
+        call(lib().smh_collection_share_to, self._p, C.c_void_p(dst.data_ptr()), C.c_void_p(self._stream))
+
+    def finish(self, gathered=None):
+        """gathered: CUDA uint8 tensor, world x share_bytes, rank-major (None when world == 1)"""
+        if gathered is not None:
+            assert gathered.is_contiguous() and gathered.numel() * gathered.element_size() == self.world * self.share_bytes
+        self._gathered = gathered
+        call(lib().smh_collection_finish, self._p, C.c_void_p(gathered.data_ptr() if gathered is not None else 0),
+             C.c_void_p(self._stream))
+        self._gathered = None
+
+    def compare(self, row_lo, row_hi, num, want=("jaccard",), ownership=OWN_ALL):
+        """rows [row_lo, row_hi) x all columns -> dict name -> CUDA tensor (row_hi - row_lo, n)"""
+        import torch
+        dev = self._hashes.device
+        outs = {}
+        for k in want:
+            dt = torch.float64 if k in ("jaccard", "containment") else torch.int64
+            outs[k] = torch.empty((row_hi - row_lo, self.n), dtype=dt, device=dev)
+
+        def p(name):
+            return C.c_void_p(outs[name].data_ptr()) if name in outs and outs[name].numel() else C.c_void_p(0)
+
+        if row_hi > row_lo:
+            call(lib().smh_collection_compare, self._p, row_lo, row_hi, num, ownership, p("jaccard"), p("common"), p("size"),
+                 p("count_common"), p("containment"), C.c_void_p(self._stream))
+        return outs
+
+    def close(self):
+        if self._p:
+            lib().smh_collection_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

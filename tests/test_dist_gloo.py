@@ -18,6 +18,51 @@ def _free_port():
     return p
 
 
+class OracleEngine:
+    """What computes a rank's row block in these CPU tests: the C oracle, pair by pair.  It honours the
+    ownership contract of smh_collection_compare exactly as loosely as the contract allows: with
+    ownership 2 every pair the rank's rows do NOT own (and whose column is not one of its own rows) is
+    POISONED, so a test only passes if the exchange really delivers those entries from their owners."""
+
+    def __init__(self, coracle, num_k=31):
+        self.coracle = coracle
+
+    def begin(self, allsigs, n_total, world, rank):
+        self.sigs = [allsigs[i].numpy().view(np.uint64) for i in range(n_total)]
+        self.n, self.world, self.rank = n_total, world, rank
+
+    def share(self):
+        import torch
+        return torch.full((16,), self.rank, dtype=torch.uint8)
+
+    def finish(self, gathered):
+        assert (gathered is None) == (self.world == 1)
+        if gathered is not None:       # rank-major concatenation of the shares
+            assert gathered.reshape(self.world, 16)[:, 0].tolist() == list(range(self.world))
+
+    def compare(self, lo, hi, num, want, ownership):
+        import torch
+        from sourmash_rust_amd import distributed as D
+        common, size, jac = self.coracle.compare_matrix(self.sigs[lo:hi], self.sigs, num, 31, 0)
+        cc = np.array([[len(np.intersect1d(a, b)) for b in self.sigs] for a in self.sigs[lo:hi]], dtype=np.int64).reshape(hi - lo, self.n)
+        out = {"jaccard": jac.copy(), "common": common.view(np.int64).copy(), "size": size.view(np.int64).copy(), "count_common": cc}
+        if ownership == 2 and hi > lo:
+            i = np.arange(lo, hi)[:, None]
+            j = np.arange(self.n)[None, :]
+            final = D.owns(i, j, self.n) | ((j >= lo) & (j < hi))
+            out["jaccard"][~final] = np.nan
+            for k in ("common", "size", "count_common"):
+                out[k][~final] = -7
+        return {k: torch.from_numpy(out[k]) for k in want}
+
+    def lengths(self, n_total):
+        import torch
+        return torch.tensor([len(s) for s in self.sigs], dtype=torch.int64)
+
+    def close(self):
+        pass
+
+
 def _worker(rank, world, port, n_total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -36,13 +81,11 @@ def _worker(rank, world, port, n_total, q):
     local[: hi - lo] = synth.family_signatures(lo, hi, num=num, n_families=3, pool=300, private=60, seed=5)
     local_t = torch.from_numpy(local.view(np.int64))
 
-    def oracle_block(rows_t, n_rows, cols_t, n_cols, num_, want):
-        rows = [rows_t[i].numpy().view(np.uint64) for i in range(n_rows)]
-        cols = [cols_t[j].numpy().view(np.uint64) for j in range(n_cols)]
-        common, size, jac = coracle.compare_matrix(rows, cols, num_, 31, 0)
-        return {"jaccard": torch.from_numpy(jac), "common": torch.from_numpy(common.view(np.int64))}
-
-    out = D.compare_matrix_sharded(local_t, n_total, num, want=("jaccard", "common"), compute_block=oracle_block)
+    want = ("jaccard", "common", "size", "count_common", "containment")
+    out = D.compare_matrix_sharded(local_t, n_total, num, want=want, engine=OracleEngine(coracle))
+    # and without the symmetric split: every pair of the row block computed locally, no all-to-all
+    out_ns = D.compare_matrix_sharded(local_t, n_total, num, want=("jaccard",), engine=OracleEngine(coracle), symmetric=False)
+    assert bool((out_ns["jaccard"] == out["jaccard"]).all())
 
     # the sketch side: every rank sketches its records, then the optional union
     recs_lo, recs_hi = D.shard_records(7, world, rank)
@@ -51,27 +94,31 @@ def _worker(rank, world, port, n_total, q):
         mh.add_sequence(bytes(coracle.synth_dna(r * 5000, 5000, 9, 0)), True)
     parts = D.merge_sketch_across_ranks(torch.from_numpy(mh.mins_np().view(np.int64)),
                                         torch.from_numpy(mh.abunds_np().view(np.int64)))
-    q.put((rank, lo, hi, out["jaccard"].numpy(), out["common"].numpy(),
+    q.put((rank, lo, hi, {k: v.numpy() for k, v in out.items()},
            [(m.numpy().view(np.uint64), a.numpy().view(np.uint64)) for m, a in parts]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [9, 10])
-def test_row_sharded_matrix_and_sketch_union_gloo(n_total, coracle):
+@pytest.mark.parametrize("world,n_total", [(2, 9), (2, 10), (4, 10), (4, 13), (4, 3)])
+def test_row_sharded_matrix_and_sketch_union_gloo(world, n_total, coracle):
+    """world-2 and world-4 runs of the sharded matrix over gloo: all-gather of the signatures, all-gather of the
+    dictionary shares, pair ownership, the all-to-all of the mirrored blocks (the oracle engine poisons every entry a
+    rank does not own, so only a complete exchange passes) -- against coracle.compare_matrix of the whole collection.
+    (4, 13): short last block; (4, 3): an EMPTY last block; even and odd N (ties of the circular-half rule)."""
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
     from __graft_entry__ import load_package
     load_package()
     from sourmash_rust_amd import synth
 
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -79,10 +126,13 @@ def test_row_sharded_matrix_and_sketch_union_gloo(n_total, coracle):
     sigs = synth.family_signatures(0, n_total, num=200, n_families=3, pool=300, private=60, seed=5)
     rows = [sigs[i] for i in range(n_total)]
     common, size, jac = coracle.compare_matrix(rows, rows, 200, 31, 0)
-    got_j = np.concatenate([r[3] for r in res], axis=0)
-    got_c = np.concatenate([r[4] for r in res], axis=0)
-    assert [(r[1], r[2]) for r in res] == [(0, (n_total + 1) // 2), ((n_total + 1) // 2, n_total)]
-    assert (got_j == jac).all() and (got_c.view(np.uint64) == common).all()
+    cc = np.array([[len(np.intersect1d(a, b)) for b in rows] for a in rows], dtype=np.int64)
+    per = -(-n_total // world)
+    assert [(r[1], r[2]) for r in res] == [(min(n_total, k * per), min(n_total, (k + 1) * per)) for k in range(world)]
+    got = {k: np.concatenate([r[3][k] for r in res], axis=0) for k in res[0][3]}
+    assert (got["jaccard"] == jac).all() and (got["common"].view(np.uint64) == common).all()
+    assert (got["size"].view(np.uint64) == size).all() and (got["count_common"] == cc).all()
+    assert (got["containment"] == cc.astype(np.float64) / 200.0).all()
 
     # union of the per-rank scaled sketches == sketch of all records on one rank (exact, abundances add)
     whole = coracle.MinHash(0, 21, False, 42, 1 << 60, True)
@@ -90,7 +140,7 @@ def test_row_sharded_matrix_and_sketch_union_gloo(n_total, coracle):
         whole.add_sequence(bytes(coracle.synth_dna(r * 5000, 5000, 9, 0)), True)
     for rank_res in res:
         merged = coracle.MinHash(0, 21, False, 42, 1 << 60, True)
-        for m, a in rank_res[5]:
+        for m, a in rank_res[4]:
             part = coracle.MinHash(0, 21, False, 42, 1 << 60, True)
             for h, c in zip(m, a):
                 part.mins_push(int(h)); part.abunds_push(int(c))
@@ -98,12 +148,37 @@ def test_row_sharded_matrix_and_sketch_union_gloo(n_total, coracle):
         assert merged.mins == whole.mins and merged.abunds == whole.abunds
 
 
+def test_pair_ownership_rule():
+    """Every unordered pair has exactly one owner, every row owns floor(N/2) or so pairs, and block_needs() never
+    says "nothing to send" for two blocks one of whose rows owns a pair with a row of the other."""
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    load_package()
+    from sourmash_rust_amd import distributed as D
+    for n in (1, 2, 3, 4, 7, 10, 11, 64):
+        i = np.arange(n)[:, None]; j = np.arange(n)[None, :]
+        own = D.owns(i, j, n)
+        assert own.diagonal().all()
+        off = ~np.eye(n, dtype=bool)
+        assert ((own ^ own.T) | ~off).all(), n                 # exactly one of (i, j), (j, i)
+        per_row = (own & off).sum(axis=1)
+        assert per_row.max() - per_row.min() <= 1 and per_row.sum() == n * (n - 1) // 2
+        for world in (1, 2, 3, 4, 8):
+            blocks = [D.shard_range(n, world, r)[:2] for r in range(world)]
+            for a, (alo, ahi) in enumerate(blocks):
+                for b, (blo, bhi) in enumerate(blocks):
+                    if a == b:
+                        continue
+                    truth = bool(own[alo:ahi, blo:bhi].any())
+                    assert D.block_needs(alo, ahi, blo, bhi, n) or not truth, (n, world, a, b)
+
+
 def test_bench_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` (the shape of the driver's command, no torchrun around it) must
     start two ranks by itself.  The children see NO GPU (HIP/CUDA_VISIBLE_DEVICES are emptied before
     anything is launched, so this behaves the same on a CPU box, a 1-GPU box and a GPU node): each
-    rank stops at its first line of GPU set-up -- which proves the launch went through: both ranks
-    ran, with RANK/WORLD_SIZE set.  The real 2-rank run is tests/test_gpu_multirank.py."""
+    rank stops at its first line of GPU set-up -- which proves the launch went through: ranks ran
+    with RANK/WORLD_SIZE set.  The real 2-rank run is tests/test_gpu_multirank.py."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
@@ -111,7 +186,9 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     text = r.stdout + r.stderr
-    assert "rank 0 needs cuda:0" in text and "rank 1 needs cuda:1" in text
+    # (the launcher stops the other rank as soon as one has failed, so only the first message is certain)
+    assert "rank 0 needs cuda:0" in text or "rank 1 needs cuda:1" in text
+    assert "but only 0 GPU(s) are visible" in text
 
 
 def test_bench_cpu_workers(tmp_path, coracle):

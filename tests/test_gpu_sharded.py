@@ -1,0 +1,149 @@
+"""GPU parity of the SHARDED all-vs-all matrix (north_star: row blocks across the GPUs of a node): the dictionary
+pre-pass split by hash range among `world` owners, pair ownership by the circular-half rule, the exchange of the
+mirrored blocks.  The ranks of a job are played one after the other in THIS process on the one GPU of the test box
+(distributed.simulate_sharded: the collectives become concatenations; everything else is the code the ranks run);
+tests/test_gpu_multirank.py runs real processes over a process group.  Every matrix must equal, bit for bit, the
+single-rank matrix and the C oracle (reference src/lib.rs:428-436, 470-508)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALL = ("jaccard", "common", "size", "count_common", "containment")
+
+
+def _collection(kind, n, num):
+    from sourmash_rust_amd import synth
+    if kind == "one_family":
+        return synth.family_signatures(0, n, num=num, n_families=1, pool=2 * num, private=num // 2, seed=17)
+    sigs = synth.family_signatures(0, n, num=num, n_families=7, pool=2 * num, private=num // 2, seed=17)
+    if kind == "one_component":
+        sigs[:, 0] = 1          # a contaminant k-mer held by every signature
+    return sigs
+
+
+def _oracle_rows(coracle, sigs, rows, num):
+    cols = [sigs[j] for j in range(sigs.shape[0])]
+    common, size, jac = coracle.compare_matrix([sigs[i] for i in rows], cols, num, 31, 0)
+    return common, size, jac
+
+
+@pytest.mark.parametrize("tune", [dict(), dict(route="tiled"), dict(route="components"), dict(route="tiled", split_frequent=False)],
+                         ids=["auto", "tiled", "components", "tiled-no-split"])
+@pytest.mark.parametrize("kind", ["families", "one_component", "one_family"])
+@pytest.mark.parametrize("world,n", [(2, 333), (3, 400), (4, 333), (8, 400), (8, 5)])
+def test_sharded_matrix_equals_single_rank_and_oracle(world, n, kind, tune, pkg, coracle):
+    import torch
+    from sourmash_rust_amd import distributed as D
+    num = 300
+    sigs = _collection(kind, n, num)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(num)
+    single = pkg.matrix.compare_block_dev(t, off, t, off, num, want=ALL)
+    with pkg.matrix.tuning(**tune):
+        outs = D.simulate_sharded(t, n, num, world, want=ALL)
+        outs_ns = D.simulate_sharded(t, n, num, world, want=("jaccard", "containment"), symmetric=False)
+    blocks = [D.shard_range(n, world, r)[:2] for r in range(world)]
+    for name in ALL:
+        got = torch.cat([o[name] for o in outs], dim=0)
+        assert got.shape == single[name].shape
+        assert bool((got == single[name]).all()), (name, world, kind, tune)
+    assert bool((torch.cat([o["jaccard"] for o in outs_ns]) == single["jaccard"]).all())
+    assert bool((torch.cat([o["containment"] for o in outs_ns]) == single["containment"]).all())
+    assert [tuple(o["jaccard"].shape) for o in outs] == [(hi - lo, n) for lo, hi in blocks]
+    rows = sorted(set([0, n // 2, n - 1] + list(range(1, n, max(1, n // 9)))))
+    ocommon, osize, ojac = _oracle_rows(coracle, sigs, rows, num)
+    idx = torch.tensor(rows, device="cuda")
+    assert (single["jaccard"][idx].cpu().numpy() == ojac).all()
+    assert (single["common"][idx].cpu().numpy().view(np.uint64) == ocommon).all()
+    assert (single["size"][idx].cpu().numpy().view(np.uint64) == osize).all()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_dictionary_on_ragged_and_skewed_sketches(world, pkg, coracle):
+    """The dictionary slices on what the fixed-width benchmark collection never shows: ragged sketches (0 ... 900
+    hashes, some EMPTY), hash values crowded into a corner of hash space (bottom-num sketches of genomes of very
+    different sizes), heavy duplication across sketches, one hash held by everybody.  Every simulated rank computes
+    its row block with ownership 0 (every pair) and with ownership 2 (owned pairs + own diagonal block + pairs that
+    share nothing are final): both against the oracle."""
+    import torch
+    from sourmash_rust_amd import distributed as D, matrix as MX
+    rng = np.random.RandomState(77 + world)
+    n = 157
+    pools = [np.unique(rng.randint(0, 1 << 62, size=1500, dtype=np.int64).astype(np.uint64) >> np.uint64(rng.choice([0, 8, 20, 33])))
+             for _ in range(5)]
+    sks = []
+    for i in range(n):
+        pool = pools[i % 5]
+        k = int(rng.choice([0, 1, 17, 300, 900]))
+        s = np.sort(rng.choice(pool, min(k, pool.size), replace=False)) if k else np.zeros(0, np.uint64)
+        if k and i % 3:
+            s = np.unique(np.concatenate([s, np.array([12345], dtype=np.uint64)]))      # a hash most sketches hold
+        sks.append(s.astype(np.uint64))
+    flat, off = MX.csr_from_sketches(sks)
+    t = torch.from_numpy(flat.view(np.int64)).cuda()
+    for num in (0, 250):
+        common, size, jac = coracle.compare_matrix(sks, sks, num, 31, 0)
+        colls = [MX.Collection(t, off, world, r) for r in range(world)]
+        gathered = None
+        if world > 1:
+            gathered = torch.empty(world * colls[0].share_bytes, dtype=torch.uint8, device="cuda")
+            for r, c in enumerate(colls):
+                assert c.share_bytes == colls[0].share_bytes
+                c.share_to(gathered[r * c.share_bytes:(r + 1) * c.share_bytes])
+        for c in colls:
+            c.finish(gathered)
+        for r, c in enumerate(colls):
+            lo, hi, _ = D.shard_range(n, world, r)
+            full = c.compare(lo, hi, num, want=("jaccard", "common", "size"), ownership=MX.OWN_ALL)
+            assert (full["common"].cpu().numpy().view(np.uint64) == common[lo:hi]).all(), (world, r, num)
+            assert (full["size"].cpu().numpy().view(np.uint64) == size[lo:hi]).all()
+            jg = full["jaccard"].cpu().numpy()
+            assert ((jg == jac[lo:hi]) | (np.isnan(jg) & np.isnan(jac[lo:hi]))).all()
+            own = c.compare(lo, hi, num, want=("common",), ownership=MX.OWN_CIRCULAR if world > 1 else MX.OWN_TRIANGLE)
+            i = np.arange(lo, hi)[:, None]; j = np.arange(n)[None, :]
+            final = D.owns(i, j, n) | ((j >= lo) & (j < hi)) if world > 1 else np.ones((hi - lo, n), bool)
+            got = own["common"].cpu().numpy().view(np.uint64)
+            assert (got[final] == common[lo:hi][final]).all(), (world, r, num)
+        for c in colls:
+            c.close()
+
+
+def test_c4_dense_matrix_on_four_simulated_ranks(pkg, coracle):
+    """BASELINE configs[3] at full size (10 000 x 10 000, num = 2000) on the collection where EVERY pair has to be
+    walked (one family), as four ranks: the row blocks equal the single-rank matrix bit for bit, sampled rows equal the
+    oracle, and the four ranks together walk about what one rank walks alone -- symmetry survives the sharding (round 2:
+    a rank's row block walked the full square)."""
+    import ctypes as C
+    import torch
+    from sourmash_rust_amd import distributed as D, synth
+    n, num, world = 10000, 2000, 4
+    sigs = synth.family_signatures(0, n, num=num, n_families=1, seed=3)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(num)
+    L = pkg.lib()
+
+    def tiled_ms():
+        ms, k = C.c_double(), C.c_uint64()
+        L.smh_profile_get(b"compare_tiled", C.byref(ms), C.byref(k))
+        return ms.value
+
+    single = pkg.matrix.compare_block_dev(t, off, t, off, num, want=("jaccard",))["jaccard"]      # warm-up + reference
+    L.smh_profile_reset(); L.smh_profile_enable(1)
+    pkg.matrix.compare_block_dev(t, off, t, off, num, want=("jaccard",))
+    one = tiled_ms()
+    st1 = pkg.matrix.last_stats()
+    L.smh_profile_reset()
+    outs = D.simulate_sharded(t, n, num, world, want=("jaccard",))
+    four = tiled_ms()
+    L.smh_profile_enable(0)
+    got = torch.cat([o["jaccard"] for o in outs], dim=0)
+    assert bool((got == single).all())
+    rows = [0, 1, 2499, 2500, 5000, 7777, 9999]
+    _, _, ojac = _oracle_rows(coracle, sigs, rows, num)
+    assert (got[torch.tensor(rows, device="cuda")].cpu().numpy() == ojac).all()
+    assert st1["route"] == "tiled"
+    # the four ranks' tiled kernels together against the one rank's: at most 30 % more (the tiles along the ownership
+    # boundary are walked by both sides)
+    print("tiled kernel: 1 rank %.2f ms, 4 ranks summed %.2f ms" % (one, four))
+    assert four <= 1.3 * one, (one, four)
