@@ -683,10 +683,12 @@ __global__ void k_hbounds(const uint32_t* __restrict__ starts, const uint64_t* _
   out[k] = max(uniq[lo], slice_lo);
 }
 // part[s][r] = first index in sketch s whose hash is >= hbound[r]  (r < R);  part[s][R] = |s|
+// (built by the first block compare that may take the tiled route: skip = that call's plan does not, built = done already)
 __global__ void k_partition(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
-                            const uint64_t* __restrict__ hbound, uint32_t R, uint32_t* __restrict__ part) {
+                            const uint64_t* __restrict__ hbound, uint32_t R, uint32_t* __restrict__ part,
+                            const uint32_t* __restrict__ skip, const uint32_t* __restrict__ built) {
   uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (uint64_t)nsk * (R + 1)) return;
+  if (g >= (uint64_t)nsk * (R + 1) || *skip || *built) return;
   uint32_t s = (uint32_t)(g / (R + 1)), r = (uint32_t)(g % (R + 1));
   const uint64_t* v = hashes + off[s];
   uint32_t len = (uint32_t)(off[s + 1] - off[s]);
@@ -778,6 +780,21 @@ __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict
   org[t] = t;
   node[t] = lo;
 }
+// world == 1: the one slice is the collection itself
+__global__ __launch_bounds__(256) void k_whole_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                                                      uint32_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ org,
+                                                      uint32_t* __restrict__ node) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= t
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= t) lo = mid; else hi = mid;
+  }
+  keys[t] = hashes[t];
+  org[t] = t;
+  node[t] = lo;
+}
 // What an owner publishes about its slice.  The share is [SliceHeader][roots: nsk u32][hbound: Rg u64][ranks: nmax u32].
 struct SliceHeader {
   uint32_t n_elems, nruns, nfreq, pad;
@@ -793,6 +810,8 @@ __global__ __launch_bounds__(64) void k_slice_header(const RangeState* __restric
 struct DictState {
   uint32_t nruns;              // distinct hashes of the collection
   uint32_t nfreq;              // frequent hashes set aside, over all slices (<= kMaxFreq)
+  uint32_t part_built;         // the range partition table exists (k_partition, k_plan_geometry)
+  uint32_t pad;
   uint32_t rbase[64];          // dense rank of the first hash of slice g
   uint64_t freq_hash[64];
 };
@@ -807,6 +826,7 @@ __global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t shar
   }
   ds->nruns = base;
   ds->nfreq = nf;
+  ds->part_built = 0;
 }
 // rank of every element of the collection, in collection order, from the slices' local ranks
 __global__ __launch_bounds__(256) void k_reassemble(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t total,
@@ -1100,7 +1120,8 @@ __global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st
 }
 // rows per wave (x 4 waves = rows per tile): 16-row tiles amortise the staging best; when few tiles
 // hold sharing pairs, shorter ones keep the chip full (the kernel is latency bound)
-__global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t fill_tiles) {
+__global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t fill_tiles, uint32_t* part_built) {
+  if (!st->skip_tiled) *part_built = 1;   // k_partition ran just before this launch (same stream)
   uint32_t rpw = forced_rpw;
   if (!rpw) rpw = st->count16 >= fill_tiles ? 4u : (2 * st->count16 >= fill_tiles ? 2u : 1u);
   st->rpw = rpw;
@@ -1222,7 +1243,12 @@ struct CollectionDict {
   uint32_t n_mine = 0, n_max = 0;     // elements of this owner's slice / of the largest slice
   uint64_t roots_at = 0, hbound_at = 0, ranks_at = 0, share_bytes = 0;
   bool finished = false, split = false;
+  // where compare reads them: buffers of their own, or -- one owner -- straight inside the share
+  const uint32_t* rank_ptr = nullptr;
+  const uint32_t* root_ptr = nullptr;
+  const uint64_t* hbound_ptr = nullptr;
   DeviceBuffer off, splitters, spart, segoff, share, dstate, rankv, root, fmask, fpos, hbound, part;
+  std::vector<uint64_t> rel_off;
 };
 
 static inline uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
@@ -1244,10 +1270,9 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   D.off.ensure((size_t)(n + 1) * 8);
   if (offsets_dev && base == 0) HIP_CHECK(hipMemcpyAsync(D.off.ptr, offsets_dev, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, s));
   else {
-    std::vector<uint64_t> rel(n + 1);
-    for (uint32_t i = 0; i <= n; i++) rel[i] = offsets_host[i] - base;
-    HIP_CHECK(hipMemcpyAsync(D.off.ptr, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipStreamSynchronize(s));   // `rel` is a pageable temporary
+    D.rel_off.resize((size_t)n + 1);      // (a member: the copy may read it after this function has returned)
+    for (uint32_t i = 0; i <= n; i++) D.rel_off[i] = offsets_host[i] - base;
+    HIP_CHECK(hipMemcpyAsync(D.off.ptr, D.rel_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
   }
   const uint64_t* off = D.off.as<uint64_t>();
   const uint32_t G = world;
@@ -1269,15 +1294,15 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   } else {
     HIP_CHECK(hipMemsetAsync(D.splitters.ptr, 0, (size_t)G * 8, s));
   }
-  D.spart.ensure((size_t)n * (G + 1) * 4);
-  D.segoff.ensure((size_t)G * (n + 1) * 4);
-  hipLaunchKernelGGL(k_slice_parts, dim3((unsigned)(((uint64_t)n * (G + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, n,
-                     D.splitters.as<uint64_t>(), G, D.spart.as<uint32_t>());
-  hipLaunchKernelGGL(k_slice_scan, dim3(G), dim3(1024), 0, s, D.spart.as<uint32_t>(), n, G, D.segoff.as<uint32_t>());
-  HIP_CHECK(hipGetLastError());
   if (G == 1) {
-    D.n_mine = D.n_max = (uint32_t)D.total;
+    D.n_mine = D.n_max = (uint32_t)D.total;      // one slice: the collection in its own order, no slice tables
   } else {
+    D.spart.ensure((size_t)n * (G + 1) * 4);
+    D.segoff.ensure((size_t)G * (n + 1) * 4);
+    hipLaunchKernelGGL(k_slice_parts, dim3((unsigned)(((uint64_t)n * (G + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, n,
+                       D.splitters.as<uint64_t>(), G, D.spart.as<uint32_t>());
+    hipLaunchKernelGGL(k_slice_scan, dim3(G), dim3(1024), 0, s, D.spart.as<uint32_t>(), n, G, D.segoff.as<uint32_t>());
+    HIP_CHECK(hipGetLastError());
     // the one read-back of building a shared dictionary: the slice sizes (every owner computes the same table)
     std::vector<uint32_t> sizes(G);
     for (uint32_t g = 0; g < G; g++)
@@ -1304,9 +1329,13 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   uint64_t* sk = T.keys0.as<uint64_t>();
   uint32_t* so = T.org0.as<uint32_t>();
   if (nm) {
-    hipLaunchKernelGGL(k_slice_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
-                       D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.org0.as<uint32_t>(),
-                       T.node.as<uint32_t>());
+    if (G == 1)
+      hipLaunchKernelGGL(k_whole_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, nm, T.keys0.as<uint64_t>(),
+                         T.org0.as<uint32_t>(), T.node.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_slice_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
+                         D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.org0.as<uint32_t>(),
+                         T.node.as<uint32_t>());
     // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
     const int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
                                        dev.scratch, s, 0xffu);
@@ -1367,26 +1396,37 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
   TiledScratch& T = tiled_scratch();
   const uint32_t G = D.world, n = D.n;
   const uint8_t* gathered = reinterpret_cast<const uint8_t*>(gathered_dev);
-  if (!gathered) {
-    if (G != 1) throw_internal("collection_finish: the gathered shares are missing");
-    gathered = D.share.as<uint8_t>();
-  }
+  if (G == 1) gathered = D.share.as<uint8_t>();   // a single owner's share is the whole dictionary
+  if (!gathered) throw_internal("collection_finish: the gathered shares are missing");
   const uint64_t* off = D.off.as<uint64_t>();
   D.dstate.ensure(sizeof(DictState));
   DictState* ds = D.dstate.as<DictState>();
   hipLaunchKernelGGL(k_dict_state, dim3(1), dim3(1), 0, s, gathered, D.share_bytes, G, ds);
-  // ranks of every element, in collection order
-  D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4);
-  if (D.total)
-    hipLaunchKernelGGL(k_reassemble, dim3((unsigned)((D.total + 255) / 256)), dim3(256), 0, s, off, n, D.total, D.spart.as<uint32_t>(), G,
-                       D.segoff.as<uint32_t>(), gathered, D.share_bytes, D.ranks_at, ds, D.rankv.as<uint32_t>());
-  // components: the slices' forests united
-  T.parent.ensure((size_t)n * 4);
-  D.root.ensure((size_t)n * 4);
-  hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
-  hipLaunchKernelGGL(k_uf_merge, dim3((unsigned)(((uint64_t)G * n + 255) / 256)), dim3(256), 0, s, gathered, D.share_bytes, D.roots_at, G, n,
-                     T.parent.as<uint32_t>());
-  hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, D.root.as<uint32_t>());
+  if (G == 1) {
+    // one owner: its share already IS the dictionary (slice order == collection order, one forest, one boundary list)
+    D.rank_ptr = reinterpret_cast<const uint32_t*>(gathered + D.ranks_at);
+    D.root_ptr = reinterpret_cast<const uint32_t*>(gathered + D.roots_at);
+    D.hbound_ptr = reinterpret_cast<const uint64_t*>(gathered + D.hbound_at);
+  } else {
+    // ranks of every element, in collection order
+    D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4);
+    if (D.total)
+      hipLaunchKernelGGL(k_reassemble, dim3((unsigned)((D.total + 255) / 256)), dim3(256), 0, s, off, n, D.total, D.spart.as<uint32_t>(), G,
+                         D.segoff.as<uint32_t>(), gathered, D.share_bytes, D.ranks_at, ds, D.rankv.as<uint32_t>());
+    // components: the slices' forests united
+    T.parent.ensure((size_t)n * 4);
+    D.root.ensure((size_t)n * 4);
+    hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
+    hipLaunchKernelGGL(k_uf_merge, dim3((unsigned)(((uint64_t)G * n + 255) / 256)), dim3(256), 0, s, gathered, D.share_bytes, D.roots_at, G, n,
+                       T.parent.as<uint32_t>());
+    hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, D.root.as<uint32_t>());
+    // range boundaries of the tiled kernel, slice after slice
+    D.hbound.ensure((size_t)D.R * 8);
+    for (uint32_t g = 0; g < G; g++)
+      HIP_CHECK(hipMemcpyAsync(D.hbound.as<uint64_t>() + (size_t)g * D.Rg, gathered + (size_t)g * D.share_bytes + D.hbound_at,
+                               (size_t)D.Rg * 8, hipMemcpyDeviceToDevice, s));
+    D.rank_ptr = D.rankv.as<uint32_t>(); D.root_ptr = D.root.as<uint32_t>(); D.hbound_ptr = D.hbound.as<uint64_t>();
+  }
   // frequent hashes: the per-sketch records (which of them it holds, and where)
   if (D.split) {
     D.fmask.ensure((size_t)n * 8); D.fpos.ensure((size_t)n * kMaxFreq * 4);
@@ -1394,14 +1434,7 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
     hipLaunchKernelGGL(k_freq_records, dim3((n + 255) / 256, kMaxFreq), dim3(256), 0, s, D.hashes, off, n, ds,
                        D.fmask.as<unsigned long long>(), D.fpos.as<uint32_t>());
   }
-  // range boundaries of the tiled kernel (slice after slice) and where every sketch crosses them
-  D.hbound.ensure((size_t)D.R * 8);
-  for (uint32_t g = 0; g < G; g++)
-    HIP_CHECK(hipMemcpyAsync(D.hbound.as<uint64_t>() + (size_t)g * D.Rg, gathered + (size_t)g * D.share_bytes + D.hbound_at,
-                             (size_t)D.Rg * 8, hipMemcpyDeviceToDevice, s));
-  D.part.ensure((size_t)n * (D.R + 1) * 4);
-  hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)n * (D.R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, n,
-                     D.hbound.as<uint64_t>(), D.R, D.part.as<uint32_t>());
+  D.part.ensure((size_t)n * (D.R + 1) * 4);    // filled by the first block compare that may take the tiled route
   HIP_CHECK(hipGetLastError());
   D.finished = true;
   (void)dev;
@@ -1452,8 +1485,8 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
   HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PlanState), s));
 
   // ---- slot orders: sketches sorted by component (stable: the index is the low half of the key)
-  const uint32_t* root_r = D.root.as<uint32_t>() + row_lo;
-  const uint32_t* root_c = D.root.as<uint32_t>() + col_lo;
+  const uint32_t* root_r = D.root_ptr + row_lo;
+  const uint32_t* root_c = D.root_ptr + col_lo;
   T.pk0.ensure((size_t)nrows * 8); T.pk1.ensure((size_t)nrows * 8);
   hipLaunchKernelGGL(k_plan_keys, dim3((nrows + 255) / 256), dim3(256), 0, s, root_r, nrows, T.pk0.as<uint64_t>());
   const uint64_t* rkey = radix_sort_u64_keys(T.pk0.as<uint64_t>(), T.pk1.as<uint64_t>(), nrows, dev.scratch, s,
@@ -1543,7 +1576,10 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     if (!forced_rpw)
       hipLaunchKernelGGL(k_tiles_count16, dim3((unsigned)std::min<uint64_t>(((uint64_t)((nrows + 15) / 16) * tiles_c + 255) / 256, 4096)),
                          dim3(256), 0, s, tt, st);
-    hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, fill_tiles);
+    DictState* ds = D.dstate.as<DictState>();
+    hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, D.n,
+                       D.hbound_ptr, R, D.part.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
+    hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, fill_tiles, &ds->part_built);
     // the list: at 16 rows per tile at most every tile; shorter tiles are only chosen when fewer than
     // fill_tiles 16-row tiles are flagged (each splits into at most 4)
     const uint32_t rows_min = (forced_rpw ? forced_rpw : 1u) * (uint32_t)wpb;
@@ -1558,8 +1594,8 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
                        T.tiles.as<uint32_t>(), tiles_cap, st);
     HIP_CHECK(hipGetLastError());
     TiledArgs a;
-    a.rrank = D.rankv.as<uint32_t>(); a.roff = rows.offsets; a.rpart = D.part.as<uint32_t>() + (size_t)row_lo * (R + 1); a.nrows = nrows;
-    a.crank = D.rankv.as<uint32_t>(); a.coff = cols.offsets; a.cpart = D.part.as<uint32_t>() + (size_t)col_lo * (R + 1); a.ncols = ncols;
+    a.rrank = D.rank_ptr; a.roff = rows.offsets; a.rpart = D.part.as<uint32_t>() + (size_t)row_lo * (R + 1); a.nrows = nrows;
+    a.crank = D.rank_ptr; a.coff = cols.offsets; a.cpart = D.part.as<uint32_t>() + (size_t)col_lo * (R + 1); a.ncols = ncols;
     a.R = R; a.num = num; a.row_nums = row_nums;
     a.tiles = T.tiles.as<uint32_t>(); a.tiles_cap = tiles_cap; a.rkey = rkey; a.ckey = ckey; a.st = st;
     a.use_xcd = ex.xcd ? 1u : 0u;

@@ -752,7 +752,9 @@ SmhCollection* smh_collection_begin(const uint64_t* hashes_dev, const uint64_t* 
     hipStream_t s = dev.user_stream(stream);
     std::unique_ptr<SmhCollection> c(new SmhCollection());
     c->d = smh::collection_begin(hashes_dev, nullptr, offsets, n, world, rank, dev, s);
-    HIP_CHECK(hipStreamSynchronize(s));   // the share is complete when the call returns (the caller all-gathers it next)
+    // the share is complete when the call returns (the caller all-gathers it next); a single owner has nobody to hand it
+    // to: its calls are only ordered on the stream
+    if (world > 1) HIP_CHECK(hipStreamSynchronize(s));
     out = c.release();
   });
   return out;
@@ -785,7 +787,7 @@ int smh_collection_finish(SmhCollection* c, const void* gathered_dev, void* stre
     std::lock_guard<std::recursive_mutex> lock(dev.mutex());
     hipStream_t s = dev.user_stream(stream);
     smh::collection_finish(c->d, gathered_dev, dev, s);
-    HIP_CHECK(hipStreamSynchronize(s));   // the gathered buffer may be released by the caller now
+    if (gathered_dev) HIP_CHECK(hipStreamSynchronize(s));   // the gathered buffer may be released by the caller now
   });
 }
 int smh_collection_compare(SmhCollection* c, uint32_t row_lo, uint32_t row_hi, uint32_t num, uint32_t ownership,
