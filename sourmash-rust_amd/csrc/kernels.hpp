@@ -132,6 +132,15 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
                                DeviceBuffer& scratch, hipStream_t s, const uint32_t* origin = nullptr,
                                uint32_t* rank_out = nullptr, const uint64_t* key2 = nullptr,
                                uint64_t* uniq2 = nullptr, int key2_shift = 0);   // key2 is compared as key2 >> key2_shift
+// Union of a device-resident sketch S (ascending distinct hashes + optional u64 counts, which are UPDATED in place for the
+// hashes D also holds) with the fold D of one more batch (ascending distinct hashes + optional run starts): out / out_cnt
+// (room for n_s + n_d entries) receive the merged sketch, *n_new_dev the number of hashes that were new (result size =
+// n_s + that).  tmp: (2 n_d + n_s + 1) u32 of work space.  No sort, no host round trip.
+void sorted_union_async(const uint64_t* S, uint64_t* S_cnt, uint32_t n_s, const uint64_t* D, const uint32_t* D_starts, uint32_t n_d,
+                        uint32_t d_total, uint64_t* out, uint64_t* out_cnt, uint32_t* n_new_dev, DeviceBuffer& tmp, DeviceBuffer& scratch,
+                        hipStream_t s);
+// counts[i] = starts[i+1] - starts[i] (the last run ends at total)
+void starts_to_counts(const uint32_t* starts, uint32_t n, uint32_t total, uint64_t* counts, hipStream_t s);
 // cand_pos[i] (a k-mer start position of the batch) -> the sketch group of the record holding it
 // keep_bits != 0: the position is kept in the low keep_bits bits, the group goes above them
 void launch_pos_to_group(uint64_t* pos, uint64_t n, const uint64_t* rec_starts, uint32_t nrec,

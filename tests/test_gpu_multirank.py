@@ -53,3 +53,20 @@ def test_bench_gpus_2_with_no_launcher_around_it(pkg):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["compare"]["self_jaccard_is_1"] is True
     assert d["compare"]["one_component"]["self_jaccard_is_1"] is True
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_matrix_over_a_real_process_group(world, pkg):
+    """`world` processes sharing the test box's one GPU, a real process group (gloo standing in for RCCL): the all-gather of
+    the signatures, the all-gather of the dictionary shares, the all-to-all of the mirrored blocks.  Rank 0 collects the row
+    blocks and compares them, bit for bit, with the matrix one rank computes alone (tools/sharded_check.py) on the family,
+    one-component and one-family collections; 701 signatures: the last row block is short."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join("tools", "sharded_check.py"), "701"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "sharded check ok" in r.stdout and "DIFFERENT" not in r.stdout
+    assert r.stdout.count("equal") == 12

@@ -7,15 +7,19 @@ from __graft_entry__ import load_package
 pkg = load_package()
 from sourmash_rust_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-mode = sys.argv[2] if len(sys.argv) > 2 else "families"      # families | one_component | one_family | all_tiles | nosym
-sigs = synth.family_signatures(0, n, num=2000, seed=3, n_families=1 if mode == "one_family" else 50)
+mode = sys.argv[2] if len(sys.argv) > 2 else "families"      # families | one_component | one_family | all_tiles | nosym | components
+dense = mode in ("one_family", "components") or (len(sys.argv) > 4 and sys.argv[4] == "dense")
+sigs = synth.family_signatures(0, n, num=2000, seed=3, n_families=1 if dense else 50)
 if mode == "one_component":
     sigs[:, 0] = 1                                            # a contaminant hash shared by every signature
 tune = {"all_tiles": dict(route="tiled", visit_all_tiles=True), "nosym": dict(route="tiled", visit_all_tiles=True, use_symmetry=False)}.get(mode, {})
 t = torch.from_numpy(sigs.view(np.int64)).cuda()
 off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+if mode == "components":
+    tune = dict(route="components")
 with pkg.matrix.tuning(**tune):
-    for it in range(12):
+    for it in range(iters):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard",))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
