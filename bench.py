@@ -259,6 +259,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.smh_profile_enable(0)
+    # N > 1: the ranks' partial sketches united into ONE sketch on the device (one all-gather of the padded hash arrays +
+    # rank-arithmetic unions, distributed.union_across_ranks) -- reported on its own, never part of `value`
+    union = None
+    if world > 1:
+        from sourmash_rust_amd import distributed as D
+        barrier()
+        t0 = time.perf_counter()
+        uni = D.union_across_ranks(mh)
+        barrier()
+        union_s = max_over_ranks(time.perf_counter() - t0)
+        union = {"union_ms": union_s * 1e3, "hashes": len(uni), "parts": world,
+                 "what": "the %d ranks' partial sketches -> one sketch on every rank, in HBM (all-gather of the hash arrays over RCCL, "
+                         "then per part a union by rank arithmetic and two scatters; KmerMinHash::merge semantics, "
+                         "reference src/lib.rs:307-403).  Not part of `value`" % world}
+        del uni
     retained = len(mh)          # the sketch is still in HBM here (DeviceSketch); bringing it to the
     t1 = time.perf_counter()    # host is a separate, untimed step whose cost is reported below
     host_mins = mh.mins_np()
@@ -535,6 +550,7 @@ def main():
                                  "valu_bound prices the kernel against the guide's VALU issue peak"},
             "cpu_baseline": cpu,
             "host_input": host_input,
+            "union_across_ranks": union,
             "compare": compare,
         }
         print(json.dumps(line))

@@ -68,6 +68,18 @@ int smh_check_compatible(const KmerMinHash *ptr, const KmerMinHash *other);
 int smh_intersection(const KmerMinHash *ptr, const KmerMinHash *other, uint64_t **common_out, uint64_t *n_common,
                      uint64_t *union_size);
 
+/* The union of partial SCALED sketches without leaving HBM -- what folds the per-GPU partial sketches of one input into one
+ * signature (KmerMinHash::merge, reference src/lib.rs:307-403, for scaled sketches: set union, abundances add).
+ * smh_sketch_export_dev copies the sketch's ascending hashes (and, when it tracks them and abunds_dev is not NULL, their
+ * abundances) into the caller's device buffers of `capacity` entries; *n_out = the number of hashes (call with capacity 0 to
+ * ask).  smh_sketch_absorb_dev unites `ptr` with n_parts sorted, distinct parts lying in ONE device buffer (part k =
+ * mins_dev[part_starts[k] .. + part_lens[k]), e.g. the output of an all-gather of padded exports): each part is merged by rank
+ * arithmetic and two scatters, no sort, no host copy.  A sketch that tracks abundances needs abunds_dev. */
+int smh_sketch_export_dev(KmerMinHash *ptr, uint64_t *mins_dev, uint64_t *abunds_dev, uint64_t capacity, uint64_t *n_out,
+                          void *stream);
+int smh_sketch_absorb_dev(KmerMinHash *ptr, const uint64_t *mins_dev, const uint64_t *abunds_dev, const uint64_t *part_starts,
+                          const uint64_t *part_lens, uint32_t n_parts, void *stream);
+
 /* murmur64 of n byte strings (offsets: n+1 host entries) on the device
  * (reference src/lib.rs:33-35 _hash_murmur) */
 int smh_hash_words(const char *bytes, const uint64_t *offsets, uint32_t n, uint64_t seed,

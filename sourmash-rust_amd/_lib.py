@@ -99,6 +99,8 @@ _SIGS = {
     "smh_add_many_with_abund": (C.c_int, [C.c_void_p, u64p, u64p, C.c_uint64]),
     "smh_check_compatible": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smh_intersection": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(u64p), u64p, u64p]),
+    "smh_sketch_export_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p]),
+    "smh_sketch_absorb_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64p, u64p, C.c_uint32, C.c_void_p]),
     "smh_hash_words": (C.c_int, [C.c_char_p, u64p, C.c_uint32, C.c_uint64, u64p]),
     "smh_compare_block": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p), C.c_uint32, f64p, u64p, u64p, u64p, f64p]),
     "smh_compare_block_dev": (C.c_int, [C.c_void_p, u64p, C.c_uint32, C.c_void_p, u64p, C.c_uint32, C.c_uint32,

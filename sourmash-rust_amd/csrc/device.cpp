@@ -210,6 +210,11 @@ void Device::drain() {
   pending_.clear();
 }
 
+void Device::count(const char* name) {
+  std::lock_guard<std::recursive_mutex> lock(mu_);
+  times_[name].launches += 1;
+}
+
 KernelTimes Device::prof_get(const std::string& name) {
   drain();
   auto it = times_.find(name);

@@ -90,6 +90,7 @@ class Device {
   bool profiling() const { return profiling_; }
   void prof_begin(hipStream_t s);
   void prof_end(const char* name, hipStream_t s);
+  void count(const char* name);                   // an event counter under the same names (launches += 1, always on)
   KernelTimes prof_get(const std::string& name);  // synchronises pending events
   void prof_reset();
 

@@ -739,6 +739,44 @@ int smh_index_compare(SmhIndex* rows, SmhIndex* cols, double* jaccard, uint64_t*
   });
 }
 
+// ---- a scaled sketch's state as device arrays: the cross-rank union of partial sketches ----
+int smh_sketch_export_dev(KmerMinHash* ptr, uint64_t* mins_dev, uint64_t* abunds_dev, uint64_t capacity, uint64_t* n_out, void* stream) {
+  return pad_code([&] {
+    require(ptr, "ptr"); require(n_out, "n_out");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    ptr->to_device_state();
+    const uint64_t n = ptr->dev ? ptr->dev->n : 0;
+    *n_out = n;
+    if (n == 0 || capacity < n || !mins_dev) return;
+    smh::DeviceSketch& S = *ptr->dev;
+    HIP_CHECK(hipMemcpyAsync(mins_dev, S.uniq.ptr, n * 8, hipMemcpyDeviceToDevice, s));
+    if (abunds_dev && ptr->has_abunds) {
+      if (S.has_counts) HIP_CHECK(hipMemcpyAsync(abunds_dev, S.counts.ptr, n * 8, hipMemcpyDeviceToDevice, s));
+      else smh::starts_to_counts(S.starts.as<uint32_t>(), (uint32_t)n, (uint32_t)S.total, abunds_dev, s);
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+int smh_sketch_absorb_dev(KmerMinHash* ptr, const uint64_t* mins_dev, const uint64_t* abunds_dev, const uint64_t* part_starts,
+                          const uint64_t* part_lens, uint32_t n_parts, void* stream) {
+  return pad_code([&] {
+    require(ptr, "ptr");
+    if (n_parts == 0) return;
+    require(mins_dev, "mins_dev"); require(part_starts, "part_starts"); require(part_lens, "part_lens");
+    if (!(ptr->num == 0 && ptr->max_hash > 0)) smh::throw_internal("smh_sketch_absorb_dev: only scaled sketches (num == 0, max_hash > 0)");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    ptr->to_device_state();
+    for (uint32_t k = 0; k < n_parts; k++)
+      smh::Engine::get().union_arrays_into_device_sketch(*ptr, mins_dev + part_starts[k], abunds_dev ? abunds_dev + part_starts[k] : nullptr,
+                                                         part_lens[k], s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
 // ---- SmhCollection: the dictionary of one collection (all-vs-all, shareable among ranks) ----
 struct SmhCollection { smh::CollectionDict* d = nullptr; };
 

@@ -136,8 +136,8 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
 // hashes D also holds) with the fold D of one more batch (ascending distinct hashes + optional run starts): out / out_cnt
 // (room for n_s + n_d entries) receive the merged sketch, *n_new_dev the number of hashes that were new (result size =
 // n_s + that).  tmp: (2 n_d + n_s + 1) u32 of work space.  No sort, no host round trip.
-void sorted_union_async(const uint64_t* S, uint64_t* S_cnt, uint32_t n_s, const uint64_t* D, const uint32_t* D_starts, uint32_t n_d,
-                        uint32_t d_total, uint64_t* out, uint64_t* out_cnt, uint32_t* n_new_dev, DeviceBuffer& tmp, DeviceBuffer& scratch,
+void sorted_union_async(const uint64_t* S, uint64_t* S_cnt, uint32_t n_s, const uint64_t* D, const uint32_t* D_starts,
+                        const uint64_t* D_cnt /* counts of D: these, or run starts, when S_cnt is given */, uint32_t n_d, uint32_t d_total, uint64_t* out, uint64_t* out_cnt, uint32_t* n_new_dev, DeviceBuffer& tmp, DeviceBuffer& scratch,
                         hipStream_t s);
 // counts[i] = starts[i+1] - starts[i] (the last run ends at total)
 void starts_to_counts(const uint32_t* starts, uint32_t n, uint32_t total, uint64_t* counts, hipStream_t s);

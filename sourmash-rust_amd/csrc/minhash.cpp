@@ -59,16 +59,20 @@ void KmerMinHash::materialize() const {
   std::vector<uint64_t>& hm = mins.w();
   hm.resize(n);
   if (n) HIP_CHECK(hipMemcpyAsync(hm.data(), dev->uniq.ptr, n * 8, hipMemcpyDeviceToHost, s));
+  d.count("sketch_to_host");   // (evidence for the tests: a sketch that accumulates in HBM must not pass here between batches)
   std::vector<uint32_t> st;
+  if (has_abunds) abunds.resize(n);
   if (has_abunds && n) {
-    st.resize(n);
-    HIP_CHECK(hipMemcpyAsync(st.data(), dev->starts.ptr, n * 4, hipMemcpyDeviceToHost, s));
+    if (dev->has_counts) {
+      HIP_CHECK(hipMemcpyAsync(abunds.data(), dev->counts.ptr, n * 8, hipMemcpyDeviceToHost, s));
+    } else {
+      st.resize(n);
+      HIP_CHECK(hipMemcpyAsync(st.data(), dev->starts.ptr, n * 4, hipMemcpyDeviceToHost, s));
+    }
   }
   HIP_CHECK(hipStreamSynchronize(s));
-  if (has_abunds) {
-    abunds.resize(n);
+  if (has_abunds && !dev->has_counts)
     for (size_t k = 0; k < n; k++) abunds[k] = (k + 1 < n ? st[k + 1] : (uint32_t)dev->total) - st[k];
-  }
   // the device copy stays on as the mirror of the host vector: a compare right after needs no upload
   auto m = std::make_shared<DeviceMirror>();
   std::swap(m->ptr, dev->uniq.ptr);
@@ -572,7 +576,12 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
     const uint64_t CH = span_ld > 4.0e12L ? (uint64_t)4e12 : (span_ld < 16777216.0L ? (1ull << 24) : (uint64_t)span_ld);
     for (uint64_t lo = 0; lo < P; lo += CH) {
       const uint64_t hi = std::min(P, lo + CH);
-      const bool whole_into_empty = mh.mins.empty() && !mh.dev && lo == 0 && hi == P;
+      // the state is in HBM, or there is none yet: it stays (or starts) there -- the batch's fold is united with it on
+      // the device and nothing crosses the link until an accessor asks.  A state that an accessor has already brought to
+      // the host is merged there (apply_scaled).
+      const bool empty = mh.mins.empty() && !mh.dev;
+      const bool in_hbm = empty || mh.dev;
+      const bool whole_into_empty = empty && lo == 0 && hi == P;
       uint64_t n = 0;
       bool hashed = false;
       if (whole_into_empty && (long double)P * frac < 0.7L * kSmallFoldMax) {
@@ -587,12 +596,13 @@ void ingest(KmerMinHash& mh, HashSource& src, hipStream_t s) {
       }
       if (!hashed) n = E.run_chunk(&src, lo, hi, mh.max_hash, false, s);
       Delta d;
-      if (whole_into_empty && n > 0) {
-        // empty sketch, whole batch in one chunk: the sorted distinct hashes ARE the new state
+      if (in_hbm) {
+        if (n == 0) continue;
         auto ds = std::make_shared<DeviceSketch>();
         E.reduce_chunk(n, 0, false, false, s, &d, ds.get(), mh.max_hash);
-        mh.dev = ds;
-        return;
+        if (!mh.dev) mh.dev = ds;          // empty sketch: the sorted distinct hashes ARE the new state
+        else E.union_into_device_sketch(mh, *ds, s);
+        continue;
       }
       E.reduce_chunk(n, 0, false, false, s, &d, nullptr, mh.max_hash);
       apply_scaled(mh, d);
@@ -908,7 +918,10 @@ void KmerMinHash::add_sequences_device(const uint8_t* d_seq, uint64_t total_len,
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
   Engine& E = Engine::get();
   hipStream_t s = stream ? stream : dev.stream();
-  materialize();   // drains queued small sequences first: stream order is part of the semantics
+  // drains queued small sequences first: stream order is part of the semantics.  A scaled sketch that lives in HBM stays
+  // there (ingest() unites the batch with it on the device); any other state is handled on the host.
+  flush_pending();
+  if (!(num == 0 && max_hash > 0)) materialize();
 
   const uint64_t* d_starts = nullptr;
   if (nrec > 1) {
@@ -967,7 +980,8 @@ void KmerMinHash::add_sequences_host(const uint8_t* h_seq, uint64_t total, const
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
   Engine& E = Engine::get();
   hipStream_t s = dev.stream();
-  materialize();
+  flush_pending();
+  if (!(num == 0 && max_hash > 0)) materialize();
   E.seqbuf.ensure(total + 64);
   uint8_t* d_seq = E.seqbuf.as<uint8_t>();
 
@@ -1030,11 +1044,12 @@ void KmerMinHash::add_sequences_host(const uint8_t* h_seq, uint64_t total, const
     for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (n > cap) n = E.run_chunk(&src, 0, P, max_hash, false, s);   // rare: hash again into an exact-size buffer
     Delta d;
-    if (mins.empty() && !this->dev && n > 0) {
+    if ((mins.empty() || this->dev) && n > 0) {
       auto ds = std::make_shared<DeviceSketch>();
       E.reduce_chunk(n, 0, false, false, s, &d, ds.get(), max_hash);
-      this->dev = ds;
-    } else {
+      if (!this->dev) this->dev = ds;
+      else E.union_into_device_sketch(*this, *ds, s);
+    } else if (n > 0) {
       E.reduce_chunk(n, 0, false, false, s, &d, nullptr, max_hash);
       apply_scaled(*this, d);
     }
@@ -1518,11 +1533,16 @@ void Engine::compare_host(const std::vector<const KmerMinHash*>& rows, const std
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
-// The device copy of mh.mins: reused while the vector's generation is the one the copy was made at
-// (TrackedMins: every mutation route bumps it -- exact, O(1), nothing is read), re-created (never
-// overwritten: a published mirror is immutable) otherwise.
-const uint64_t* Engine::mirror_of(const KmerMinHash& mh, hipStream_t s) {
-  mh.materialize();
+// The sketch's hashes in device memory.  A sketch whose state lives in HBM is compared where it is (nothing is brought to
+// the host); otherwise the device copy of mh.mins: reused while the vector's generation is the one the copy was made at
+// (TrackedMins: every mutation route bumps it -- exact, O(1), nothing is read), re-created (never overwritten: a published
+// mirror is immutable) otherwise.
+const uint64_t* Engine::device_mins(const KmerMinHash& mh, size_t* n_out, hipStream_t s) {
+  mh.flush_pending();
+  if (mh.dev) {
+    *n_out = (size_t)mh.dev->n;
+    return mh.dev->uniq.as<uint64_t>();
+  }
   const size_t n = mh.mins.size();
   if (!mh.mirror || mh.mirror->gen != mh.mins.generation()) {
     auto m = std::make_shared<DeviceMirror>();
@@ -1532,6 +1552,7 @@ const uint64_t* Engine::mirror_of(const KmerMinHash& mh, hipStream_t s) {
     m->gen = mh.mins.generation();
     mh.mirror = m;
   }
+  *n_out = n;
   return reinterpret_cast<const uint64_t*>(mh.mirror->ptr);
 }
 
@@ -1539,9 +1560,11 @@ void Engine::compare_pair(const KmerMinHash& a, const KmerMinHash& b, uint32_t n
   Device& dev = Device::get();
   std::lock_guard<std::recursive_mutex> lock(dev.mutex());
   hipStream_t s = dev.stream();
-  const uint64_t* A = mirror_of(a, s);
-  const uint64_t* B = mirror_of(b, s);
-  const uint32_t la = (uint32_t)a.mins.size(), lb = (uint32_t)b.mins.size();
+  size_t na = 0, nb = 0;
+  const uint64_t* A = device_mins(a, &na, s);
+  const uint64_t* B = device_mins(b, &nb, s);
+  if (na >= (1ull << 32) || nb >= (1ull << 32)) throw_internal("compare: a sketch of more than 2^32 hashes");
+  const uint32_t la = (uint32_t)na, lb = (uint32_t)nb;
   pair_out.ensure(sizeof(PairOut));
   pin_pair.ensure(sizeof(PairOut));
   launch_compare_pair(A, la, B, lb, num, pair_out.as<PairOut>(), dev, s);
@@ -1554,6 +1577,90 @@ void Engine::compare_pair(const KmerMinHash& a, const KmerMinHash& b, uint32_t n
   out->common = cut ? h->common : h->tot_c;
   out->jaccard = (double)out->common / (double)(out->size > 1 ? out->size : 1);
   out->containment = (double)h->tot_c / (double)la;
+}
+
+// KmerMinHash::add_hash over one more batch (reference src/lib.rs:192-245) for a scaled sketch whose state lives in HBM:
+// the batch's sorted distinct hashes with their counts (run starts of the fold, or plain u64 counts).  Present hashes have
+// their counts raised, new ones are inserted.
+static void union_core(KmerMinHash& mh, const uint64_t* d_mins, const uint32_t* d_starts, const uint64_t* d_counts, uint64_t n_delta,
+                       uint64_t delta_total, Engine& E, hipStream_t s) {
+  Device& dev = Device::get();
+  DeviceSketch& S = *mh.dev;
+  if (n_delta == 0) return;
+  if (S.n + n_delta >= (1ull << 31) || delta_total >= (1ull << 32)) throw_internal("sketch union: more than 2^31 hashes");
+  const uint32_t n_s = (uint32_t)S.n, n_d = (uint32_t)n_delta;
+  const bool track = mh.has_abunds;
+  if (track && !S.has_counts) {   // first union: run starts of the first batch -> counts
+    S.counts.ensure((size_t)std::max<uint32_t>(n_s, 1) * 8);
+    starts_to_counts(S.starts.as<uint32_t>(), n_s, (uint32_t)S.total, S.counts.as<uint64_t>(), s);
+    S.has_counts = true; S.has_runs = false;
+  }
+  DeviceBuffer nu, nc;
+  const size_t cap = (size_t)n_s + n_d;
+  nu.ensure(cap * 8);
+  if (track) nc.ensure(cap * 8);
+  E.misc.ensure(16);
+  sorted_union_async(S.uniq.as<uint64_t>(), track ? S.counts.as<uint64_t>() : nullptr, n_s, d_mins, track ? d_starts : nullptr,
+                     track ? d_counts : nullptr, n_d, (uint32_t)delta_total, nu.as<uint64_t>(), track ? nc.as<uint64_t>() : nullptr,
+                     E.misc.as<uint32_t>(), E.union_tmp, dev.scratch, s);
+  uint32_t n_new = 0;
+  HIP_CHECK(hipMemcpyAsync(&n_new, E.misc.ptr, 4, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  std::swap(S.uniq.ptr, nu.ptr); std::swap(S.uniq.bytes, nu.bytes);
+  if (track) { std::swap(S.counts.ptr, nc.ptr); std::swap(S.counts.bytes, nc.bytes); }
+  S.n = (uint64_t)n_s + n_new;
+  S.total += delta_total;
+  S.has_runs = false;
+  dev.count("sketch_union_on_device");
+}
+
+void Engine::union_into_device_sketch(KmerMinHash& mh, DeviceSketch& delta, hipStream_t s) {
+  union_core(mh, delta.uniq.as<uint64_t>(), delta.has_counts ? nullptr : delta.starts.as<uint32_t>(),
+             delta.has_counts ? delta.counts.as<uint64_t>() : nullptr, delta.n, delta.total, *this, s);
+}
+
+void Engine::union_arrays_into_device_sketch(KmerMinHash& mh, const uint64_t* d_mins, const uint64_t* d_counts, uint64_t n, hipStream_t s) {
+  if (n == 0) return;
+  if (mh.has_abunds && !d_counts) throw_internal("sketch union: the part carries no abundances");
+  if (!mh.dev) {                       // an empty sketch: the part IS the new state
+    auto ds = std::make_shared<DeviceSketch>();
+    ds->uniq.ensure(n * 8);
+    HIP_CHECK(hipMemcpyAsync(ds->uniq.ptr, d_mins, n * 8, hipMemcpyDeviceToDevice, s));
+    if (mh.has_abunds) {
+      ds->counts.ensure(n * 8);
+      HIP_CHECK(hipMemcpyAsync(ds->counts.ptr, d_counts, n * 8, hipMemcpyDeviceToDevice, s));
+      ds->has_counts = true;
+    }
+    ds->n = n; ds->total = n;
+    HIP_CHECK(hipStreamSynchronize(s));
+    mh.dev = ds;
+    return;
+  }
+  union_core(mh, d_mins, nullptr, d_counts, n, n, *this, s);
+}
+
+// scaled sketches: a host-resident state goes (back) to HBM as ascending hashes + u64 counts
+void KmerMinHash::to_device_state() {
+  flush_pending();
+  if (dev || mins.empty()) return;
+  if (!(num == 0 && max_hash > 0)) throw_internal("only a scaled sketch keeps its state in HBM");
+  if (has_abunds && abunds.size() != mins.size()) throw_internal("sketch with mismatched abundance vector");
+  Device& d = Device::get();
+  std::lock_guard<std::recursive_mutex> lock(d.mutex());
+  hipStream_t s = d.stream();
+  auto ds = std::make_shared<DeviceSketch>();
+  const size_t n = mins.size();
+  ds->uniq.ensure(n * 8);
+  HIP_CHECK(hipMemcpyAsync(ds->uniq.ptr, mins.data(), n * 8, hipMemcpyHostToDevice, s));
+  if (has_abunds) {
+    ds->counts.ensure(n * 8);
+    HIP_CHECK(hipMemcpyAsync(ds->counts.ptr, abunds.data(), n * 8, hipMemcpyHostToDevice, s));
+    ds->has_counts = true;
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  ds->n = n; ds->total = n;
+  dev = ds;
+  mins.w().clear(); abunds.clear(); mirror.reset();
 }
 
 uint64_t KmerMinHash::count_common(const KmerMinHash& other) const {

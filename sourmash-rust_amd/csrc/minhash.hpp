@@ -32,10 +32,12 @@ struct Delta {
 // filled by materialize().  Keeps a 10^7-hash scaled sketch out of PCIe unless it is wanted.
 struct DeviceSketch {
   DeviceBuffer uniq;    // n ascending distinct u64
-  DeviceBuffer starts;  // n u32 run starts (abundance k = starts[k+1]-starts[k], last ends at total)
+  DeviceBuffer starts;  // has_runs: n u32 run starts (abundance k = starts[k+1]-starts[k], last ends at total)
+  DeviceBuffer counts;  // has_counts: n u64 abundances (a sketch that has absorbed more than one batch)
   uint64_t n = 0;
   uint64_t total = 0;
   bool has_runs = false;
+  bool has_counts = false;
 };
 
 // The `mins` vector with a generation counter: reads go through the const forwarding methods, every
@@ -104,6 +106,7 @@ struct KmerMinHash {
   KmerMinHash(const KmerMinHash& o);             // Clone: brings a device-resident state to the host first
   KmerMinHash& operator=(const KmerMinHash& o);
   void materialize() const;                      // device-resident state -> mins / abunds
+  void to_device_state();                        // scaled sketches: host-resident state -> HBM (uniq + u64 counts)
 
   void check_compatible(const KmerMinHash& other) const;                 // 176-190
   void add_hash(uint64_t h);                                             // 192-245
@@ -168,7 +171,12 @@ class Engine {
   // one ordered pair (self = a) on mirrored device copies: what the pairwise reference API needs
   struct PairResult { uint64_t common, size, count_common; double jaccard, containment; };
   void compare_pair(const KmerMinHash& a, const KmerMinHash& b, uint32_t num, PairResult* out);
-  const uint64_t* mirror_of(const KmerMinHash& mh, hipStream_t s);
+  // the sketch's hashes in device memory: the device-resident state itself, or the mirror of the host vector
+  const uint64_t* device_mins(const KmerMinHash& mh, size_t* n, hipStream_t s);
+  // a device-resident scaled sketch absorbs the fold of one more batch without leaving HBM (sort.hip sorted_union_async)
+  void union_into_device_sketch(KmerMinHash& mh, DeviceSketch& delta, hipStream_t s);
+  // the same with the delta given as plain device arrays (ascending distinct hashes, u64 counts or null = 1 each)
+  void union_arrays_into_device_sketch(KmerMinHash& mh, const uint64_t* d_mins, const uint64_t* d_counts, uint64_t n, hipStream_t s);
 
   // block compare of host-resident sketches (uploads them); outputs are row-major rows x cols
   void compare_host(const std::vector<const KmerMinHash*>& rows, const std::vector<const KmerMinHash*>& cols,
@@ -182,7 +190,7 @@ class Engine {
   void pack_sketches(const std::vector<const KmerMinHash*>& v, DeviceBuffer& data, DeviceBuffer& offs, SketchSet* out,
                      uint32_t* maxlen, std::vector<uint64_t>* h_off, hipStream_t s);
 
-  DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, uniq2, starts, red_b, misc, seqbuf, offbuf, vendbuf, vendbuf2, grpbuf;
+  DeviceBuffer cand_hash[2], cand_pos[2], counter, uniq, uniq2, starts, red_b, misc, seqbuf, offbuf, vendbuf, vendbuf2, grpbuf, union_tmp;
   PinnedBuffer pin_a, pin_b, pin_pair;
   DeviceBuffer pair_out;
   DeviceBuffer resbuf, segbuf, badbuf, cmp_a, cmp_b, cmp_oa, cmp_ob, cmp_out;

@@ -752,7 +752,8 @@ void exclusive_scan_u32_dev(uint32_t* d, size_t m, uint32_t* total, DeviceBuffer
 // scan (newrank_j) and marked at lb_j, a scan of the marks tells every S[i] how many new hashes precede it.  Two scatters
 // write the result -- no sort, every array is read and written once.
 __global__ __launch_bounds__(256) void k_union_probe(const uint64_t* __restrict__ S, uint64_t* __restrict__ S_cnt, uint32_t n_s,
-                                                     const uint64_t* __restrict__ D, const uint32_t* __restrict__ D_starts, uint32_t n_d,
+                                                     const uint64_t* __restrict__ D, const uint32_t* __restrict__ D_starts,
+                                                     const uint64_t* __restrict__ D_cnt, uint32_t n_d,
                                                      uint32_t d_total, uint32_t* __restrict__ lb_out, uint32_t* __restrict__ isnew,
                                                      uint32_t* __restrict__ marks) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -765,7 +766,8 @@ __global__ __launch_bounds__(256) void k_union_probe(const uint64_t* __restrict_
   }
   const bool present = lo < n_s && S[lo] == h;
   if (present) {
-    if (S_cnt) S_cnt[lo] += (uint64_t)((j + 1 < n_d ? D_starts[j + 1] : d_total) - D_starts[j]);   // one D element per S element at most
+    if (S_cnt)   // one D element per S element at most: no atomic
+      S_cnt[lo] += D_cnt ? D_cnt[j] : (uint64_t)((j + 1 < n_d ? D_starts[j + 1] : d_total) - D_starts[j]);
   } else {
     atomicAdd(&marks[lo], 1u);
   }
@@ -781,8 +783,8 @@ __global__ __launch_bounds__(256) void k_union_scatter_old(const uint64_t* __res
   out[at] = S[i];
   if (out_cnt) out_cnt[at] = S_cnt[i];
 }
-__global__ __launch_bounds__(256) void k_union_scatter_new(const uint64_t* __restrict__ D, const uint32_t* __restrict__ D_starts, uint32_t n_d,
-                                                           uint32_t d_total, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ newrank,
+__global__ __launch_bounds__(256) void k_union_scatter_new(const uint64_t* __restrict__ D, const uint32_t* __restrict__ D_starts,
+                                                           const uint64_t* __restrict__ D_cnt, uint32_t n_d, uint32_t d_total, const uint32_t* __restrict__ lb, const uint32_t* __restrict__ newrank,
                                                            uint64_t* __restrict__ out, uint64_t* __restrict__ out_cnt) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_d) return;
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(256) void k_union_scatter_new(const uint64_t* __res
   if (!(v & 0x80000000u)) return;
   const uint32_t at = (v & 0x7fffffffu) + newrank[j];
   out[at] = D[j];
-  if (out_cnt) out_cnt[at] = (uint64_t)((j + 1 < n_d ? D_starts[j + 1] : d_total) - D_starts[j]);
+  if (out_cnt) out_cnt[at] = D_cnt ? D_cnt[j] : (uint64_t)((j + 1 < n_d ? D_starts[j + 1] : d_total) - D_starts[j]);
 }
 __global__ __launch_bounds__(256) void k_starts_to_counts(const uint32_t* __restrict__ starts, uint32_t n, uint32_t total,
                                                           uint64_t* __restrict__ counts) {
@@ -802,8 +804,8 @@ void starts_to_counts(const uint32_t* starts, uint32_t n, uint32_t total, uint64
   hipLaunchKernelGGL(k_starts_to_counts, dim3((n + 255) / 256), dim3(256), 0, s, starts, n, total, counts);
   HIP_CHECK(hipGetLastError());
 }
-void sorted_union_async(const uint64_t* S, uint64_t* S_cnt, uint32_t n_s, const uint64_t* D, const uint32_t* D_starts, uint32_t n_d,
-                        uint32_t d_total, uint64_t* out, uint64_t* out_cnt, uint32_t* n_new_dev, DeviceBuffer& tmp, DeviceBuffer& scratch,
+void sorted_union_async(const uint64_t* S, uint64_t* S_cnt, uint32_t n_s, const uint64_t* D, const uint32_t* D_starts,
+                        const uint64_t* D_cnt, uint32_t n_d, uint32_t d_total, uint64_t* out, uint64_t* out_cnt, uint32_t* n_new_dev, DeviceBuffer& tmp, DeviceBuffer& scratch,
                         hipStream_t s) {
   if (n_d == 0) { HIP_CHECK(hipMemsetAsync(n_new_dev, 0, 4, s)); }
   tmp.ensure(((size_t)2 * n_d + n_s + 1) * 4 + 64);
@@ -812,13 +814,13 @@ void sorted_union_async(const uint64_t* S, uint64_t* S_cnt, uint32_t n_s, const 
   uint32_t* marks = newrank + n_d;
   HIP_CHECK(hipMemsetAsync(marks, 0, ((size_t)n_s + 1) * 4, s));
   if (n_d) {
-    hipLaunchKernelGGL(k_union_probe, dim3((n_d + 255) / 256), dim3(256), 0, s, S, S_cnt, n_s, D, D_starts, n_d, d_total, lb, newrank, marks);
+    hipLaunchKernelGGL(k_union_probe, dim3((n_d + 255) / 256), dim3(256), 0, s, S, S_cnt, n_s, D, D_starts, D_cnt, n_d, d_total, lb, newrank, marks);
     HIP_CHECK(hipGetLastError());
     exclusive_scan_u32_dev(newrank, n_d, n_new_dev, scratch, s);
   }
   exclusive_scan_u32_dev(marks, (size_t)n_s + 1, nullptr, scratch, s);
   if (n_s) hipLaunchKernelGGL(k_union_scatter_old, dim3((n_s + 255) / 256), dim3(256), 0, s, S, S_cnt, n_s, marks, out, out_cnt);
-  if (n_d) hipLaunchKernelGGL(k_union_scatter_new, dim3((n_d + 255) / 256), dim3(256), 0, s, D, D_starts, n_d, d_total, lb, newrank, out, out_cnt);
+  if (n_d) hipLaunchKernelGGL(k_union_scatter_new, dim3((n_d + 255) / 256), dim3(256), 0, s, D, D_starts, D_cnt, n_d, d_total, lb, newrank, out, out_cnt);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -283,6 +283,45 @@ def shard_records(n_records, world, rank):
     return lo, hi
 
 
+def union_across_ranks(mh, group=None, parts=None):
+    """The ranks' partial SCALED sketches of one input -> one sketch, on every rank, without leaving HBM: all-gather of the
+    sizes, ONE all-gather of the padded hash arrays (and one of the abundances), then the parts are united on the device
+    (smh_sketch_absorb_dev: rank arithmetic + scatters per part, no sort, no host copy).  KmerMinHash::merge semantics for
+    scaled sketches (reference src/lib.rs:307-403): set union, abundances add -- exact.
+    `parts` (tests): a list of sketches standing in for the other ranks' (no process group needed)."""
+    import torch
+    from .minhash import KmerMinHash
+    assert mh.num == 0 and mh.max_hash > 0, "the device union is for scaled sketches"
+    comm = _Comm(group)
+    track = mh.track_abundance
+    locals_ = parts if parts is not None else [mh]
+    sizes_local = [p.export_dev() for p in locals_]
+    if parts is None and comm.world > 1:
+        t = torch.tensor([sizes_local[0]], dtype=torch.int64, device="cuda")
+        sizes = [int(x) for x in comm.all_gather(t).cpu().tolist()]
+    else:
+        sizes = sizes_local
+    cap = max(max(sizes), 1)
+
+    def padded(p, want_ab):
+        m = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        a = torch.zeros(cap, dtype=torch.int64, device="cuda") if want_ab else None
+        p.export_dev(m, a)
+        return m, a
+
+    if parts is None:
+        m, a = padded(mh, track)
+        gm = comm.all_gather(m)
+        ga = comm.all_gather(a) if track else None
+    else:
+        pairs = [padded(p, track) for p in parts]
+        gm = torch.cat([x[0] for x in pairs])
+        ga = torch.cat([x[1] for x in pairs]) if track else None
+    out = KmerMinHash(0, mh.ksize, mh.is_protein, mh.seed, mh.max_hash, track)
+    out.absorb_dev(gm, ga, [r * cap for r in range(len(sizes))], sizes)
+    return out
+
+
 def merge_sketch_across_ranks(mins, abunds=None, group=None):
     """Union of the ranks' partial sketches (ascending distinct uint64 `mins`, optional counts):
     all-gather of the lengths, then of the padded arrays; returns the concatenated per-rank lists

@@ -140,6 +140,24 @@ class KmerMinHash:
         call(L.smh_add_sequences_grouped_dev, arr, len(sketches), C.c_void_p(dev_ptr), total_len, off.ctypes.data_as(u64p),
              grp.ctypes.data_as(C.POINTER(C.c_uint32)), off.size - 1, bool(force), C.c_void_p(stream or 0))
 
+    # --- a scaled sketch's state as device arrays (additive ABI; the cross-rank union, distributed.union_across_ranks)
+    def export_dev(self, mins_t=None, abunds_t=None, stream=None):
+        """copies the ascending hashes (and abundances) into CUDA int64 tensors; returns the number of hashes
+        (call without tensors to ask for the size)"""
+        n = C.c_uint64()
+        cap = mins_t.numel() if mins_t is not None else 0
+        call(self._L.smh_sketch_export_dev, self._p, C.c_void_p(mins_t.data_ptr() if mins_t is not None else 0),
+             C.c_void_p(abunds_t.data_ptr() if abunds_t is not None else 0), cap, C.byref(n), C.c_void_p(stream or 0))
+        return n.value
+
+    def absorb_dev(self, mins_t, abunds_t, part_starts, part_lens, stream=None):
+        """unites this scaled sketch with sorted distinct parts lying in one CUDA buffer (see smh_sketch_absorb_dev)"""
+        st = np.ascontiguousarray(part_starts, dtype=np.uint64)
+        ln = np.ascontiguousarray(part_lens, dtype=np.uint64)
+        call(self._L.smh_sketch_absorb_dev, self._p, C.c_void_p(mins_t.data_ptr()),
+             C.c_void_p(abunds_t.data_ptr() if abunds_t is not None else 0), st.ctypes.data_as(u64p), ln.ctypes.data_as(u64p),
+             st.size, C.c_void_p(stream or 0))
+
     def merge(self, other): call(self._L.kmerminhash_merge, self._p, other._p)
     def add_from(self, other): call(self._L.kmerminhash_add_from, self._p, other._p)
 

@@ -65,8 +65,13 @@ def test_sharded_matrix_over_a_real_process_group(world, pkg):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join("tools", "sharded_check.py"), "701"]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join("tools", "sharded_check.py"), "701",
+           "1.0" if world == 2 else "0"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sharded check ok" in r.stdout and "DIFFERENT" not in r.stdout
-    assert r.stdout.count("equal") == 12
+    assert r.stdout.count("equal") == (13 if world == 2 else 12)
+    if world == 2:
+        # ... and the sketch side: 1 GB per rank through the protein arm with abundances, the partial sketches united across
+        # the ranks on the device (one all-gather of the padded arrays) == the sketch of the 2 GB on one rank
+        assert "union of 2 ranks x 1.0 GB (protein, abundances)" in r.stdout and "nothing copied to the host" in r.stdout

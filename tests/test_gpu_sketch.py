@@ -797,3 +797,122 @@ def test_a_batch_of_many_short_records(prot, pkg, coracle):
         for r in range(nrec):
             o.add_sequence(raw[int(off[r]):int(off[r + 1])], True)
         same_state(g, o)
+
+
+def _count(pkg, name):
+    import ctypes as C
+    ms, k = C.c_double(), C.c_uint64()
+    pkg.lib().smh_profile_get(name.encode(), C.byref(ms), C.byref(k))
+    return k.value
+
+
+@pytest.mark.parametrize("protein,track", [(False, True), (False, False), (True, True)])
+def test_scaled_sketch_accumulates_in_hbm_small(protein, track, pkg, coracle):
+    """Many add_sequence batches into ONE scaled sketch (the reference's normal use, src/lib.rs:252-305): after the first
+    batch the state lives in HBM and every later batch is united with it THERE (sort.hip sorted_union_async) -- equal to the
+    oracle fed the same records in the same order, abundances included, with batches that repeat earlier k-mers, an empty
+    batch (records shorter than k), a batch that adds nothing new, and the legacy one-string calls in between."""
+    mx = (1 << 64) // 50
+    ks = 27 if protein else 21
+    g = pkg.KmerMinHash(0, ks, protein, 42, mx, track)
+    o = coracle.MinHash(0, ks, protein, 42, mx, track)
+    L = pkg.lib()
+    L.smh_profile_reset()
+    recs = [bytes(coracle.synth_dna(i * 40000, 40000, 9, 0)) for i in range(12)]
+    batches = [recs[0:3], recs[3:4], [b"ACGT"], recs[2:6], recs[6:12], recs[0:1], recs[11:12]]
+    for bi, batch in enumerate(batches):
+        g.add_sequences(batch, True)
+        for r in batch:
+            o.add_sequence(r, True)
+        if bi == 3:                      # the one-string ABI in between (queued, drained by the next batch)
+            g.add_sequence(recs[7][:5000], True); o.add_sequence(recs[7][:5000], True)
+        assert len(g) == len(o.mins)
+    assert _count(pkg, "sketch_to_host") == 0, "the sketch left HBM between batches"
+    assert _count(pkg, "sketch_union_on_device") >= 5
+    h = pkg.KmerMinHash(0, ks, protein, 42, mx, track)
+    h.add_sequences(recs, True)
+    assert g.compare(h) == 1.0 and g.count_common(h) == len(o.mins)          # compared where they are: still nothing copied
+    assert _count(pkg, "sketch_to_host") == 0
+    same_state(g, o)
+    assert _count(pkg, "sketch_to_host") == 1
+    g.add_sequences(recs[4:5], True); o.add_sequence(recs[4], True)           # a host-resident state keeps working (host merge)
+    same_state(g, o)
+
+
+def test_ten_batches_of_one_gb_into_one_sketch(pkg, coracle):
+    """10 x 1 GB (1 000 records x 1 MB each) into ONE scaled sketch with abundances == the sketch of the 10 GB in one
+    call; nothing is copied to the host before an accessor asks (profile counter), a compare against the one-shot sketch
+    does not materialise either of them, sampled records sketched by the C oracle are contained in it, and a later batch
+    costs about what the first one did (the union is rank arithmetic + two scatters, not a sort of the whole state)."""
+    import ctypes as C
+    import time
+    import torch
+    nrec, rlen, mx = 10000, 1_000_000, 18446744073709552
+    total = nrec * rlen
+    buf = torch.empty(total, dtype=torch.uint8, device="cuda")
+    L = pkg.lib()
+    assert L.smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), 0, total, 2, 0, C.c_void_p(0)) == 0
+    torch.cuda.synchronize()
+    off = np.arange(nrec + 1, dtype=np.uint64) * np.uint64(rlen)
+
+    def add(mh, r0, r1):
+        mh.add_sequences_dev(buf.data_ptr() + r0 * rlen, (r1 - r0) * rlen, off[r0:r1 + 1] - off[r0], True)
+
+    for track in (True, False):
+        whole = pkg.KmerMinHash(0, 31, False, 42, mx, track)
+        add(whole, 0, nrec)
+        for rep in range(2):             # the second pass is the timed one (buffers come from the pool by then)
+            acc = pkg.KmerMinHash(0, 31, False, 42, mx, track)
+            L.smh_profile_reset()
+            times = []
+            for b in range(10):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                add(acc, b * 1000, (b + 1) * 1000)
+                n_now = len(acc)
+                times.append(time.perf_counter() - t0)
+        assert _count(pkg, "sketch_to_host") == 0 and _count(pkg, "sketch_union_on_device") == 9
+        assert n_now == len(whole) and acc.compare(whole) == 1.0 and acc.count_common(whole) == n_now
+        assert _count(pkg, "sketch_to_host") == 0
+        print("track=%s batch ms: %s" % (track, " ".join("%.2f" % (t * 1e3) for t in times)))
+        assert max(times[1:]) <= 1.5 * times[0], times
+        assert (acc.mins_np() == whole.mins_np()).all()
+        if track:
+            assert (acc.abunds_np() == whole.abunds_np()).all()
+            wm = dict(zip(acc.mins_np().tolist(), acc.abunds_np().tolist()))
+            for r in (0, 5500, nrec - 1):
+                o = coracle.MinHash(0, 31, False, 42, mx, True)
+                o.add_sequence(bytes(coracle.synth_dna(r * rlen, rlen, 2, 0)), True)
+                assert all(wm.get(h, 0) >= c for h, c in zip(o.mins, o.abunds))
+
+
+@pytest.mark.parametrize("protein,track", [(False, True), (True, True), (False, False)])
+def test_union_of_partial_sketches_on_the_device(protein, track, pkg, coracle):
+    """Row e2 of SURVEY.md 8e: the per-rank partial sketches of one input folded into one sketch without leaving HBM
+    (smh_sketch_export_dev / smh_sketch_absorb_dev; distributed.union_across_ranks with the other ranks' sketches passed in).
+    Scaled sketches: the union is exact, abundances add (KmerMinHash::merge, reference src/lib.rs:307-403) -- against the
+    oracle fed all records, with overlapping shards (the same k-mers on several ranks), an EMPTY rank and a rank whose
+    state had already been brought to the host."""
+    from sourmash_rust_amd import distributed as D
+    mx = (1 << 64) // 40
+    ks = 27 if protein else 21
+    recs = [bytes(coracle.synth_dna(i * 30000, 30000, 13, 0)) for i in range(10)]
+    shards = [recs[0:4], recs[3:7], [], recs[6:10], recs[0:1]]
+    parts = []
+    o = coracle.MinHash(0, ks, protein, 42, mx, track)
+    for sh in shards:
+        p = pkg.KmerMinHash(0, ks, protein, 42, mx, track)
+        if sh:
+            p.add_sequences(sh, True)
+        for r in sh:
+            o.add_sequence(r, True)
+        parts.append(p)
+    _ = parts[3].mins                         # this rank's sketch was looked at: its state is on the host now
+    pkg.lib().smh_profile_reset()
+    uni = D.union_across_ranks(parts[0], parts=parts)
+    assert _count(pkg, "sketch_to_host") == 0
+    same_state(uni, o)
+    for p, sh in zip(parts, shards):          # the parts themselves are unchanged
+        q = coracle.MinHash(0, ks, protein, 42, mx, track)
+        for r in sh:
+            q.add_sequence(r, True)
+        same_state(p, q)

@@ -48,6 +48,37 @@ def main():
                 same = bool((got == single).all())
                 print("%s %s world %d: %s" % (kind, name, world, "equal" if same else "DIFFERENT"), flush=True)
                 ok = ok and same
+    # ---- the sketch side: every rank sketches its share of ONE input (protein arm, abundances), then the partial sketches
+    # are united across ranks on the device (distributed.union_across_ranks); rank 0 compares with the sketch of everything
+    gb = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+    if gb > 0:
+        import ctypes as C
+        rlen, mx = 1_000_000, 18446744073709552
+        nrec = int(gb * 1000)
+        L = pkg.lib()
+
+        def sketch(first, count):
+            buf = torch.empty(count * rlen, dtype=torch.uint8, device="cuda")
+            assert L.smh_synth_dna_dev(C.c_void_p(buf.data_ptr()), first * rlen, count * rlen, 5, 0, C.c_void_p(0)) == 0
+            torch.cuda.synchronize()
+            mh = pkg.KmerMinHash(0, 27, True, 42, mx, True)
+            mh.add_sequences_dev(buf.data_ptr(), count * rlen, np.arange(count + 1, dtype=np.uint64) * np.uint64(rlen), True)
+            return mh
+
+        mine = sketch(rank * nrec, nrec)
+        L.smh_profile_reset()
+        uni = D.union_across_ranks(mine)
+        ms, k = C.c_double(), C.c_uint64()
+        L.smh_profile_get(b"sketch_to_host", C.byref(ms), C.byref(k))
+        none_copied = k.value == 0
+        n_uni = len(uni)
+        if rank == 0:
+            whole = sketch(0, world * nrec)
+            same = n_uni == len(whole) and uni.compare(whole) == 1.0 and (uni.mins_np() == whole.mins_np()).all() \
+                and (uni.abunds_np() == whole.abunds_np()).all()
+            print("union of %d ranks x %.1f GB (protein, abundances): %d hashes, %s, %s" %
+                  (world, gb, n_uni, "equal" if same else "DIFFERENT", "nothing copied to the host" if none_copied else "COPIED TO HOST"), flush=True)
+            ok = ok and same and none_copied
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
