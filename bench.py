@@ -414,11 +414,21 @@ def main():
                         "effective_bytes": walked * ((NUM + NUM) * 8 + 8),
                         "effective_TBps": walked * ((NUM + NUM) * 8 + 8) / (kms * 1e-3) / 1e12,
                         "compulsory_hbm_bytes": sizes[0] * NUM * 8 + D.shard_range(sizes[0], world, 0)[2] * sizes[0] * 8,
-                        "valu_insts_per_walked_pair": pmc.get("valu_insts_per_walked_pair") if pmc else None,
+                        "valu_bound": None,
                         "note": "integer compare/indexing, no MFMA.  'effective' = SURVEY.md 8d's (|A|+|B|)*8+8 B per walked pair, "
                                 "served from LDS/L2 (may exceed the HBM peak: it is not HBM traffic); 'achieved' = actual ds_read "
                                 "bytes against the guide's ds_read_b32 aggregate (~75 TB/s); compulsory HBM traffic is "
                                 "N*16 KB in + rows*N*8 B out"}
+        if cmp_roof and pmc and pmc.get("valu_wave_insts_per_64_pairs"):
+            # the binding resource (like the sketch kernel's): VALU issue.  Wave instructions per 64 walked pairs from the
+            # committed PMC pass, priced at the guide's 2 cycles per wave64 instruction and at the 4 cycles the counters show
+            # (SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs = the kernel's duration)
+            vi = pmc["valu_wave_insts_per_64_pairs"]
+            floor2 = cmp_roof["pairs_walked"] / 64.0 * vi * VALU_CYCLES / (SIMDS * MAX_CLOCK_HZ) * 1e3
+            cmp_roof["valu_bound"] = {"valu_wave_insts_per_64_pairs": vi, "floor_ms_at_2_cycles": floor2,
+                                      "frac_at_2_cycles": floor2 / cmp_roof["kernel_ms_avg"],
+                                      "floor_ms_at_4_cycles": 2 * floor2, "frac_at_4_cycles": 2 * floor2 / cmp_roof["kernel_ms_avg"],
+                                      "per_merge_step": "16.6 VALU + 5.1 SALU + 1.8 branch + 2.9 LDS wave-instructions (profiles/r03_pmc_compare_tiled.json)"}
         compare = {"metric": "signature pairs compared/sec (ordered pairs delivered, num=%d)" % NUM, "value": head["families"]["pairs_per_s"],
                    "unit": "pairs/s", "n_signatures": sizes[0], "seconds": head["families"]["seconds"],
                    "scaling": "strong: N = %d signatures at every world size (the %d x %d matrix of BASELINE configs[3])" % (sizes[0], sizes[0], sizes[0]),

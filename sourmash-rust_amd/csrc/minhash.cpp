@@ -36,7 +36,7 @@ KmerMinHash::KmerMinHash(const KmerMinHash& o)
 KmerMinHash& KmerMinHash::operator=(const KmerMinHash& o) {
   if (this == &o) return *this;
   o.materialize();
-  pend_seq.clear(); pend_off.clear();
+  pend_seq.clear(); pend_off.clear(); pend_words.clear(); pend_woff.clear();
   num = o.num; ksize = o.ksize; is_protein = o.is_protein; seed = o.seed; max_hash = o.max_hash;
   has_abunds = o.has_abunds; mins = o.mins; abunds = o.abunds; dev.reset(); mirror.reset();
   return *this;
@@ -1321,6 +1321,7 @@ constexpr size_t kLazyFlushBytes = 8u << 20;  // queued bytes that trigger a bat
 }  // namespace
 
 void KmerMinHash::flush_pending() const {
+  if (pend_woff.size() > 1) flush_words();
   if (pend_off.size() <= 1) { pend_seq.clear(); pend_off.clear(); return; }
   // move the queue out first: add_sequences_device() calls back into materialize()
   std::vector<uint8_t> seqs;
@@ -1343,6 +1344,7 @@ void KmerMinHash::add_sequence(const uint8_t* seq, size_t len, bool force) {
   if (!is_protein && ksize == 0) throw_panic("window size must be non-zero");
   if (is_protein && ksize / 3 == 0) throw_panic("window size must be non-zero");
   Device& dev = Device::get();   // raises here, not at the deferred batch, when there is no GPU
+  if (pend_woff.size() > 1) flush_words();   // queued words came first
   bool direct = len >= kLazyMaxRecord || pend_off.size() >= (1u << 20);
   size_t use = len;
   bool have_err = false;
@@ -1409,11 +1411,29 @@ void Engine::hash_words(const uint8_t* bytes, const uint64_t* offsets, uint32_t 
   HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// reference src/lib.rs:247-250: add_hash(_hash_murmur(word, seed)).  The hash is computed on the device; a call per word
+// would be a launch and a synchronisation per word (the reference's own protein arm calls add_word per window), so the
+// words are queued and hashed together (flush_words).
 void KmerMinHash::add_word(const uint8_t* w, size_t len) {
-  const uint64_t off[2] = {0, (uint64_t)len};
-  uint64_t h = 0;
-  Engine::get().hash_words(w, off, 1, seed, &h);
-  add_hash(h);
+  (void)Device::get();             // raises here, not at the deferred batch, when there is no GPU
+  if (pend_off.size() > 1) flush_pending();   // queued sequences came first
+  if (pend_woff.empty()) pend_woff.push_back(0);
+  pend_words.insert(pend_words.end(), w, w + len);
+  pend_woff.push_back(pend_words.size());
+  if (pend_woff.size() > (1u << 16) || pend_words.size() > (8u << 20)) flush_words();
+}
+
+void KmerMinHash::flush_words() const {
+  if (pend_woff.size() <= 1) { pend_words.clear(); pend_woff.clear(); return; }
+  std::vector<uint8_t> bytes;
+  std::vector<uint64_t> offs;
+  bytes.swap(pend_words);          // moved out first: add_many() below observes the sketch (and would come back here)
+  offs.swap(pend_woff);
+  const uint32_t n = (uint32_t)(offs.size() - 1);
+  std::vector<uint64_t> hashes(n);
+  const uint8_t dummy = 0;
+  Engine::get().hash_words(bytes.empty() ? &dummy : bytes.data(), offs.data(), n, seed, hashes.data());
+  const_cast<KmerMinHash*>(this)->add_many(hashes.data(), n);   // add_hash in call order (bulk: the device fold, same result)
 }
 
 // ------------------------------------------------------------------------------------

@@ -99,7 +99,13 @@ struct KmerMinHash {
   // launch per call, without the per-launch latency.  Errors are still raised by the call itself.
   mutable std::vector<uint8_t> pend_seq;
   mutable std::vector<uint64_t> pend_off;
+  // add_word calls are queued the same way: the words are hashed by ONE device launch when the state is next observed
+  // (or 64 K words are waiting) and then go through add_hash in the order they came.  The two queues never hold work at
+  // the same time (whichever call comes next drains the other first), so the stream order of the calls is kept.
+  mutable std::vector<uint8_t> pend_words;
+  mutable std::vector<uint64_t> pend_woff;
   void flush_pending() const;
+  void flush_words() const;
 
   KmerMinHash() { mins.w().reserve(1000); }  // Default, src/lib.rs:48-60
   KmerMinHash(uint32_t n, uint32_t k, bool prot, uint64_t seed_, uint64_t mx, bool track);  // 142-174

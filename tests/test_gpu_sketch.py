@@ -916,3 +916,43 @@ def test_union_of_partial_sketches_on_the_device(protein, track, pkg, coracle):
         for r in sh:
             q.add_sequence(r, True)
         same_state(p, q)
+
+
+@pytest.mark.parametrize("params", [(0, 9, False, 42, 1 << 61, True), (300, 9, False, 42, 0, True), (50, 6, False, 7, 0, False)])
+def test_add_word_calls_are_queued_and_keep_their_order(params, pkg, coracle):
+    """kmerminhash_add_word (reference src/ffi.rs:82-95, src/lib.rs:247-250) through the legacy one-word-per-call ABI: the
+    words are hashed by one device launch when the sketch is next observed, then go through add_hash in call order --
+    interleaved with add_hash, add_sequence and accessors, in scaled and in bottom-num mode (where the abundance of the
+    last element depends on the order, quirk Q3), with repeated words and the empty word."""
+    import time
+    rng = random.Random(5)
+    g, o = pkg.KmerMinHash(*params), coracle.MinHash(*params)
+    alphabet = [bytes(rng.choice(b"ACGT") for _ in range(params[1])) for _ in range(400)] + [b""]
+    for step in range(3000):
+        r = rng.random()
+        if r < 0.90:
+            w = rng.choice(alphabet)
+            g.add_word(w); o.add_word(w)
+        elif r < 0.95:
+            h = rng.getrandbits(60)
+            g.add_hash(h); o.add_hash(h)
+        elif r < 0.98:
+            s = bytes(rng.choice(b"ACGT") for _ in range(60))
+            g.add_sequence(s, True); o.add_sequence(s, True)
+        else:
+            assert len(g) == len(o.mins)
+    same_state(g, o)
+    # 100 000 calls: one launch per 64 K words instead of one per word
+    g2 = pkg.KmerMinHash(0, 9, False, 42, 1 << 62, True)
+    words = [rng.choice(alphabet[:-1]) for _ in range(100000)]
+    t0 = time.perf_counter()
+    for w in words:
+        g2.add_word(w)
+    n = len(g2)
+    dt = time.perf_counter() - t0
+    o2 = coracle.MinHash(0, 9, False, 42, 1 << 62, True)
+    for w in set(words):
+        o2.add_word(w)
+    assert n == len(o2.mins) and g2.mins == o2.mins and sum(g2.abunds) == sum(1 for w in words if coracle.hash_murmur(w, 42) <= (1 << 62))
+    print("100 000 add_word calls: %.3f s" % dt)
+    assert dt < 1.0
