@@ -8,12 +8,16 @@ import pytest
 from conftest import ROOT
 
 
+# (tests/test_sanitizers.py links the clients against the ASan/UBSan build of the library, whose runtime is preloaded)
+EXTRA_LD = os.environ.get("SMH_TEST_EXTRA_LDFLAGS", "").split()
+
+
 def test_c_client_builds_and_runs(pkg, tmp_path):
     libdir = os.path.dirname(pkg.SO_PATH)
     exe = str(tmp_path / "c_abi_client")
     subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c_abi_client.c"), "-o", exe,
-                           "-L", libdir, "-lsourmash_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", libdir, "-lsourmash_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"] + EXTRA_LD)
     out = subprocess.check_output([exe], text=True, stderr=subprocess.STDOUT)
     assert "c abi client ok" in out
 
@@ -23,7 +27,7 @@ def _build_and_run(pkg, tmp_path, name):
     exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c11", "-D_GNU_SOURCE", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", name + ".c"), "-o", exe,
-                           "-L", libdir, "-lsourmash_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", libdir, "-lsourmash_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"] + EXTRA_LD)
     return subprocess.check_output([exe], text=True, stderr=subprocess.STDOUT)
 
 
