@@ -378,7 +378,12 @@ __global__ __launch_bounds__(256) void k_compare_comp(SketchSet rows, SketchSet 
 // union and common counts across ranges; the union walk stops counting at n = the row's num.
 // A tile whose segments do not fit LDS for some range merges that range straight from global memory.
 constexpr int kTB = 64;          // columns per tile (= lanes of a wave); rows per tile = WPB * RPW
-constexpr uint32_t kSent = 0xffffffffu;
+// Sentinels behind every staged segment, above every rank (a block holds fewer than 2^31 - 2 hashes) and positive as ints.
+// A row's differs from a column's, so that when BOTH sides of a pair are exhausted the walk sees A < B: it keeps stepping
+// over A's padding without finding a match or moving B (the walks look for the end only every 4 steps).
+constexpr uint32_t kSentA = 0x7ffffffeu, kSent = 0x7fffffffu;
+constexpr uint32_t kPad = 4;
+using LdsU32 = const __attribute__((address_space(3))) uint32_t*;
 
 // What the device-side plan of a block compare decides (see "device-side plan" below); the kernels
 // read it, the host reads it back once, at the end of the call.
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       }
       lenA[tid] = hi - lo; gA[tid] = g;
       // exclusive scan of (len + 1 sentinel slot) over the tile's rows, by wave 0
-      uint32_t v = tid < kTR ? hi - lo + 1 : 0, incl = v;
+      uint32_t v = tid < kTR ? hi - lo + kPad : 0, incl = v;
       for (int off = 1; off < 64; off <<= 1) {
         uint32_t o = __shfl_up(incl, off);
         if (lane >= off) incl += o;
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       lenB[tid - 64] = hi - lo; gB[tid - 64] = g;
       uint32_t mx = hi - lo;
       for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
-      if (tid == 64) ctl[1] = ((mx + 1) * kTB > a.capBt) ? 1u : 0u;
+      if (tid == 64) ctl[1] = ((mx + kPad) * kTB > a.capBt) ? 1u : 0u;
     }
     __syncthreads();
     overflow = (ctl[0] | ctl[1]) != 0;
@@ -551,11 +556,11 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
         const int t = w * kRowsPerWave + q;
         const uint32_t la = lenA[t], oa = offA[t], g = gA[t];
         for (uint32_t e = lane; e < la; e += 64) poolA[oa + e] = a.rrank[g + e];
-        if (lane == 0) poolA[oa + la] = kSent;
+        if (lane < (int)kPad) poolA[oa + la + lane] = kSentA;
       }
       {
         const uint32_t lb = lenB[lane], g = gB[lane];
-        for (uint32_t e = w; e <= lb; e += WPB) Bt[e * kTB + lane] = e < lb ? a.crank[g + e] : kSent;
+        for (uint32_t e = w; e < lb + kPad; e += WPB) Bt[e * kTB + lane] = e < lb ? a.crank[g + e] : kSent;
       }
       __syncthreads();
       // ---- merge: one pair per lane per row
@@ -567,21 +572,60 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
         const uint32_t n = nrowL[t];
         if (!WantCC && ucount[q] >= n) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
         const uint32_t* A = poolA + offA[t];
-        uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
-        uint32_t av = A[0], bv = Bt[lane];
-        while (!(av == kSent && bv == kSent)) {
-          const bool eq = av == bv;
-          cm += (eq && u < n) ? 1u : 0u;
-          if (WantCC) c2 += eq ? 1u : 0u;
-          u += 1;
-          const bool adva = av <= bv, advb = bv <= av;
-          pa += adva ? 1u : 0u;
-          pb += advb ? 1u : 0u;
-          av = A[pa];
-          bv = Bt[pb * kTB + lane];
+        const uint32_t u0 = ucount[q];
+        // No lane's cut can fall inside this range (even with no match at all the union stays within n), or every lane is
+        // past it already (count_common wanted): only the NUMBER of matches of the range matters, and the walk needs no
+        // counters at all -- a step advances A, B or both, so A's and B's final positions say how many steps were matches.
+        // Addresses advance by a constant per step (folded into the reads' immediate offsets) minus what the compares
+        // take back, all in two-operand full-rate instructions; the end (both at a sentinel) is looked for every 4 steps.
+        uint32_t sa = (uint32_t)(uintptr_t)A, sb = (uint32_t)(uintptr_t)(Bt + lane);   // LDS byte addresses
+        const uint32_t sa0 = sa;
+        uint32_t av = *(LdsU32)(uintptr_t)sa, bv = *(LdsU32)(uintptr_t)sb;
+        uint32_t iters = 0;
+        if (__all((u0 + la + lb <= n) || (WantCC && u0 >= n))) {
+          while ((av & bv) != kSentA) {
+#pragma unroll
+            for (uint32_t j = 1; j <= 4; j++) {
+              const uint32_t g = (bv - av) >> 31;      // 1: bv < av, only B's element is consumed (ranks are < 2^31)
+              const uint32_t l = (av - bv) >> 31;      // 1: av < bv, only A's
+              sa -= g << 2;
+              sb -= l << 8;
+              av = *(LdsU32)(uintptr_t)(sa + 4u * j);
+              bv = *(LdsU32)(uintptr_t)(sb + (4u * kTB) * j);
+            }
+            sa += 16u; sb += 16u * kTB;
+            iters += 1;
+          }
+          // A fell behind the unconditional 4 bytes per step once for every B-only step; B's elements are B-only or matches
+          const uint32_t m = lb - ((sa0 + 16u * iters - sa) >> 2);
+          ucount[q] = u0 + la + lb - m;
+          if (u0 + la + lb <= n) common[q] += m;
+          if (WantCC) cc[q] += m;
+          continue;
         }
-        ucount[q] = u; common[q] = cm;
-        if (WantCC) cc[q] += c2;
+        // The cut may fall inside this range for some lane: the same walk with the matches counted while the union is
+        // short of n (r = u - n is negative until then), still in two-operand arithmetic on VGPRs only.
+        int32_t r = (int32_t)(u0 - n);
+        uint32_t cmv = 0, ccv = 0;
+        while ((av & bv) != kSentA) {
+#pragma unroll
+          for (uint32_t j = 1; j <= 4; j++) {
+            const uint32_t t1 = bv - av, t2 = av - bv;
+            const uint32_t eq = ((t1 | t2) >> 31) ^ 1u;     // neither is smaller
+            cmv += eq & ((uint32_t)r >> 31);
+            if (WantCC) ccv += eq;
+            r += 1;
+            sa -= (t1 >> 31) << 2;
+            sb -= (t2 >> 31) << 8;
+            av = *(LdsU32)(uintptr_t)(sa + 4u * j);
+            bv = *(LdsU32)(uintptr_t)(sb + (4u * kTB) * j);
+          }
+          sa += 16u; sb += 16u * kTB;
+        }
+        // a lane that did not reach its cut has counted every match; one that did only needs ucount >= n from here on
+        ucount[q] = u0 + la + lb - (WantCC ? ccv : cmv);
+        common[q] += cmv;
+        if (WantCC) cc[q] += ccv;
       }
     } else {
       // ---- rare: this range does not fit LDS for this tile; merge from global memory
@@ -1264,7 +1308,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   const uint64_t base = offsets_host[0];
   D.hashes = hashes_dev + base; D.n = n; D.world = world; D.rank = rank;
   D.total = offsets_host[n] - base;
-  if (D.total >= (1ull << 31)) throw_internal("compare block: more than 2^31 hashes");
+  if (D.total >= (1ull << 31) - 2) throw_internal("compare block: more than 2^31 hashes");   // (ranks stay below the sentinels)
   for (uint32_t i = 0; i < n; i++) D.max_len = std::max<uint32_t>(D.max_len, (uint32_t)(offsets_host[i + 1] - offsets_host[i]));
   // offsets relative to the first element (a copy the dictionary owns: the caller's array may be reused)
   D.off.ensure((size_t)(n + 1) * 8);

@@ -18,9 +18,22 @@ off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 if mode == "components":
     tune = dict(route="components")
+import ctypes as C
+L = pkg.lib()
+times = []
 with pkg.matrix.tuning(**tune):
     for it in range(iters):
+        if it == 2:
+            L.smh_profile_reset(); L.smh_profile_enable(1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = pkg.matrix.compare_block_dev(t, off, t, off, 2000, want=("jaccard",))
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("n=%d %s: %.3f ms per matrix (%.1f M pairs/s) %s" % (n, mode, dt * 1e3, n * n / dt / 1e6, pkg.matrix.last_stats()))
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+L.smh_profile_enable(0)
+kern = {}
+for name in ("compare_tiled", "compare_comp", "compare_fill"):
+    ms, k = C.c_double(), C.c_uint64()
+    L.smh_profile_get(name.encode(), C.byref(ms), C.byref(k))
+    if k.value:
+        kern[name] = round(ms.value / k.value, 4)
+dt = sorted(times[2:] or times)[len(times[2:] or times) // 2]
+print("n=%d %s: median %.3f ms per matrix (min %.3f; %.1f M pairs/s) kernels ms %s %s" % (n, mode, dt * 1e3, min(times) * 1e3, n * n / dt / 1e6, kern, pkg.matrix.last_stats()))
