@@ -844,12 +844,9 @@ struct SliceHeader {
   uint32_t n_elems, nruns, nfreq, pad;
   uint64_t freq_hash[64];
 };
+struct DictState;
 __global__ __launch_bounds__(64) void k_slice_header(const RangeState* __restrict__ rs, const uint64_t* __restrict__ uniq, uint32_t n,
-                                                     SliceHeader* __restrict__ h) {
-  const uint32_t k = threadIdx.x;
-  if (k == 0) { h->n_elems = n; h->nruns = rs->nruns; h->nfreq = rs->nfreq; h->pad = 0; }
-  h->freq_hash[k] = k < rs->nfreq ? uniq[rs->freq_run[k]] : 0ull;
-}
+                                                     SliceHeader* __restrict__ h, DictState* single_owner);
 // What everybody derives from the gathered headers: the rank offset of every slice, the frequent hashes (ascending)
 struct DictState {
   uint32_t nruns;              // distinct hashes of the collection
@@ -859,6 +856,19 @@ struct DictState {
   uint32_t rbase[64];          // dense rank of the first hash of slice g
   uint64_t freq_hash[64];
 };
+// (ds: a single owner's header IS the collection's state -- one launch less)
+__global__ __launch_bounds__(64) void k_slice_header(const RangeState* __restrict__ rs, const uint64_t* __restrict__ uniq, uint32_t n,
+                                                     SliceHeader* __restrict__ h, DictState* ds) {
+  const uint32_t k = threadIdx.x;
+  const uint64_t f = k < rs->nfreq ? uniq[rs->freq_run[k]] : 0ull;
+  if (k == 0) { h->n_elems = n; h->nruns = rs->nruns; h->nfreq = rs->nfreq; h->pad = 0; }
+  h->freq_hash[k] = f;
+  if (ds) {
+    if (k == 0) { ds->nruns = rs->nruns; ds->nfreq = rs->nfreq; ds->part_built = 0; ds->pad = 0; }
+    ds->rbase[k] = 0;
+    ds->freq_hash[k] = f;
+  }
+}
 __global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint32_t G, DictState* __restrict__ ds) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t base = 0, nf = 0;
@@ -947,6 +957,38 @@ __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ ke
   }
   uf_union(parent, a, b);
 }
+// The first sample of the neighbour pairs for a collection of at most kUfLdsNodes sketches: ONE workgroup, the forest in
+// LDS.  The unions of related sketches all meet at the same few parent words; in LDS that contention costs nanoseconds,
+// through the L2 (agent-scope atomics) microseconds each (1000 sketches of one family: 93 us for 7 800 sampled pairs).
+constexpr uint32_t kUfLdsNodes = 16384;
+template <int Shift>
+__global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
+                                                      const uint32_t* __restrict__ node, uint64_t n, uint32_t nsk, uint32_t* parent,
+                                                      const uint32_t* __restrict__ runid, const uint8_t* __restrict__ isfreq) {
+  extern __shared__ uint32_t lpar[];
+  for (uint32_t i = threadIdx.x; i < nsk; i += 1024) lpar[i] = i;
+  __syncthreads();
+  for (uint64_t t = threadIdx.x + 1; (t << Shift) < n; t += 1024) {
+    const uint64_t i = t << Shift;
+    if (keys[i] != keys[i - 1]) continue;
+    if (isfreq && isfreq[runid[i]]) continue;
+    uint32_t x = node[origin[i]], y = node[origin[i - 1]];
+    while (true) {
+      // (relaxed workgroup-scope loads: other lanes are changing the forest)
+      while (true) { const uint32_t p = __hip_atomic_load(&lpar[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p == x) break; x = p; }
+      while (true) { const uint32_t p = __hip_atomic_load(&lpar[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p == y) break; y = p; }
+      if (x == y) break;
+      if (x > y) { const uint32_t s = x; x = y; y = s; }
+      if (atomicCAS(&lpar[y], y, x) == y) break;      // the larger root goes under the smaller
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nsk; i += 1024) {   // flattened: every sketch points at its root
+    uint32_t x = i;
+    while (true) { const uint32_t p = lpar[x]; if (p == x) break; x = p; }
+    parent[i] = x;
+  }
+}
 // the slices' forests (root of every sketch within slice g) united into one
 __global__ __launch_bounds__(256) void k_uf_merge(const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint64_t roots_at,
                                                   uint32_t G, uint32_t nsk, uint32_t* parent) {
@@ -973,10 +1015,21 @@ __global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, 
 __global__ __launch_bounds__(256) void k_freq_mark(const uint32_t* __restrict__ starts, uint32_t n, uint32_t threshold,
                                                    RangeState* st) {
   const uint32_t nruns = st->nruns;
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += gridDim.x * blockDim.x) {
-    const uint32_t len = (r + 1 < nruns ? starts[r + 1] : n) - starts[r];
-    if (len > threshold) {
-      const uint32_t k = atomicAdd(&st->nfreq_seen, 1u);
+  const int lane = threadIdx.x & 63;
+  for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < nruns; r0 += gridDim.x * blockDim.x) {
+    const uint32_t r = r0 + threadIdx.x;
+    const bool hit = r < nruns && ((r + 1 < nruns ? starts[r + 1] : n) - starts[r]) > threshold;
+    // one atomic per wave: in a dense family thousands of runs are long, and they would all queue at one counter word
+    const uint64_t m = __ballot(hit);
+    if (m == 0) continue;
+    // more than kMaxFreq already: nothing will be set aside, the exact count is of no interest (a plain L2 read, unlike
+    // the read-modify-writes, which are served one at a time: 4 000 long runs of a dense family cost 20 us there)
+    if (__hip_atomic_load(&st->nfreq_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kMaxFreq) continue;
+    uint32_t base = 0;
+    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&st->nfreq_seen, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m));
+    if (hit) {
+      const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (k < kMaxFreq) st->freq_run[k] = r;
     }
   }
@@ -992,24 +1045,30 @@ __global__ __launch_bounds__(64) void k_freq_finalize(RangeState* st, uint8_t* _
   if (lane < seen) { st->freq_run[rank] = mine; isfreq[mine] = (uint8_t)(rank + 1); }
   if (lane == 0) st->nfreq = seen;
 }
-// mask / position records of every sketch: which of the frequent hashes it holds, and where (binary search per pair)
+// mask / position records of every sketch: which of the frequent hashes it holds, and where (a binary search per hash)
 __global__ __launch_bounds__(256) void k_freq_records(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
                                                       const DictState* __restrict__ ds, unsigned long long* __restrict__ mask,
                                                       uint32_t* __restrict__ pos) {
-  const uint32_t b = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= ds->nfreq || s >= nsk) return;
-  const uint64_t f = ds->freq_hash[b];
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsk) return;
+  const uint32_t nfreq = ds->nfreq;
   const uint64_t* v = hashes + off[s];
   const uint32_t len = (uint32_t)(off[s + 1] - off[s]);
-  uint32_t lo = 0, hi = len;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (v[mid] < f) lo = mid + 1; else hi = mid;
+  unsigned long long m = 0;
+  uint32_t lo = 0;                     // the frequent hashes ascend: each search starts where the last one ended
+  for (uint32_t b = 0; b < nfreq; b++) {
+    const uint64_t f = ds->freq_hash[b];
+    uint32_t hi = len;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (v[mid] < f) lo = mid + 1; else hi = mid;
+    }
+    if (lo < len && v[lo] == f) {
+      m |= 1ull << b;
+      pos[(size_t)s * kMaxFreq + b] = lo;
+    }
   }
-  if (lo < len && v[lo] == f) {
-    atomicOr(&mask[s], 1ull << b);
-    pos[(size_t)s * kMaxFreq + b] = lo;
-  }
+  mask[s] = m;
 }
 
 // every pair as if it shared nothing but frequent hashes (none, usually); the compare kernels then
@@ -1404,9 +1463,15 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   uint32_t* roots = reinterpret_cast<uint32_t*>(share + D.roots_at);
   hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
   if (nm) {
-    // 1/256 sample straight to the atomic path, then 1/16 and everything through the cached filter
-    hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
-                       (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+    // a 1/256 sample first -- in LDS by one workgroup when the collection is small (k_uf_runs_lds), else straight to
+    // the atomic path -- then 1/16 and everything through the cached filter, which sends on only the pairs that are not
+    // connected yet
+    if (n <= kUfLdsNodes && nm <= (1u << 22))      // (one workgroup: beyond ~16 K sampled pairs the many-workgroup path wins)
+      hipLaunchKernelGGL((k_uf_runs_lds<8>), dim3(1), dim3(1024), (size_t)n * 4, s, sk, so, T.node.as<uint32_t>(), (uint64_t)nm, n,
+                         T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+    else
+      hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+                         (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
     hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                        (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
     hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
@@ -1414,7 +1479,9 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   }
   hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, roots);
   // ---- what the slice publishes: header, roots (written above), range boundaries, local ranks in slice order
-  hipLaunchKernelGGL(k_slice_header, dim3(1), dim3(64), 0, s, rs, T.uniq.as<uint64_t>(), nm, reinterpret_cast<SliceHeader*>(share));
+  D.dstate.ensure(sizeof(DictState));
+  hipLaunchKernelGGL(k_slice_header, dim3(1), dim3(64), 0, s, rs, T.uniq.as<uint64_t>(), nm, reinterpret_cast<SliceHeader*>(share),
+                     G == 1 ? D.dstate.as<DictState>() : (DictState*)nullptr);
   hipLaunchKernelGGL(k_hbounds, dim3((D.Rg + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), T.uniq.as<uint64_t>(), rs, nm, D.Rg,
                      D.splitters.as<uint64_t>() + rank, reinterpret_cast<uint64_t*>(share + D.hbound_at));   // (slice's lower end: by pointer)
   if (nm)
@@ -1445,7 +1512,7 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
   const uint64_t* off = D.off.as<uint64_t>();
   D.dstate.ensure(sizeof(DictState));
   DictState* ds = D.dstate.as<DictState>();
-  hipLaunchKernelGGL(k_dict_state, dim3(1), dim3(1), 0, s, gathered, D.share_bytes, G, ds);
+  if (G > 1) hipLaunchKernelGGL(k_dict_state, dim3(1), dim3(1), 0, s, gathered, D.share_bytes, G, ds);   // (one owner: k_slice_header did it)
   if (G == 1) {
     // one owner: its share already IS the dictionary (slice order == collection order, one forest, one boundary list)
     D.rank_ptr = reinterpret_cast<const uint32_t*>(gathered + D.ranks_at);
@@ -1474,8 +1541,7 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
   // frequent hashes: the per-sketch records (which of them it holds, and where)
   if (D.split) {
     D.fmask.ensure((size_t)n * 8); D.fpos.ensure((size_t)n * kMaxFreq * 4);
-    HIP_CHECK(hipMemsetAsync(D.fmask.ptr, 0, (size_t)n * 8, s));
-    hipLaunchKernelGGL(k_freq_records, dim3((n + 255) / 256, kMaxFreq), dim3(256), 0, s, D.hashes, off, n, ds,
+    hipLaunchKernelGGL(k_freq_records, dim3((n + 255) / 256), dim3(256), 0, s, D.hashes, off, n, ds,
                        D.fmask.as<unsigned long long>(), D.fpos.as<uint32_t>());
   }
   D.part.ensure((size_t)n * (D.R + 1) * 4);    // filled by the first block compare that may take the tiled route
