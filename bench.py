@@ -428,7 +428,7 @@ def main():
             cmp_roof["valu_bound"] = {"valu_wave_insts_per_64_pairs": vi, "floor_ms_at_2_cycles": floor2,
                                       "frac_at_2_cycles": floor2 / cmp_roof["kernel_ms_avg"],
                                       "floor_ms_at_4_cycles": 2 * floor2, "frac_at_4_cycles": 2 * floor2 / cmp_roof["kernel_ms_avg"],
-                                      "per_merge_step": "16.6 VALU + 5.1 SALU + 1.8 branch + 2.9 LDS wave-instructions (profiles/r03_pmc_compare_tiled.json)"}
+                                      "per_merge_step": pmc.get("per_merge_step")}
         compare = {"metric": "signature pairs compared/sec (ordered pairs delivered, num=%d)" % NUM, "value": head["families"]["pairs_per_s"],
                    "unit": "pairs/s", "n_signatures": sizes[0], "seconds": head["families"]["seconds"],
                    "scaling": "strong: N = %d signatures at every world size (the %d x %d matrix of BASELINE configs[3])" % (sizes[0], sizes[0], sizes[0]),
