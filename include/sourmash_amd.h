@@ -134,6 +134,16 @@ int smh_collection_compare(SmhCollection *collection, uint32_t row_lo, uint32_t 
                            double *jaccard_dev, uint64_t *common_dev, uint64_t *size_dev, uint64_t *count_common_dev,
                            double *containment_dev, void *stream);
 void smh_collection_free(SmhCollection *collection);
+/* The exchange that completes ownership 2, device side (8-byte outputs: jaccard, common, size, count_common).
+ * smh_mirror_pack: for each of n_blocks peers holding rows [col_lo[b], col_hi[b]), this rank's block out_dev (n_local x
+ * n_total) restricted to those columns, TRANSPOSED, packed one block after the other into packed_dev -- the send buffer of
+ * an all-to-all.  smh_mirror_apply: from the blocks received (peer b holds rows [peer_lo[b], peer_hi[b]); block b is
+ * n_local x (peer_hi[b] - peer_lo[b]) row-major, one after the other in recv_dev) the entries the SENDER's rows own are
+ * written into out_dev; row_lo = global index of this rank's first row. */
+int smh_mirror_pack(const void *out_dev, uint32_t n_local, uint32_t n_total, const uint32_t *col_lo, const uint32_t *col_hi,
+                    uint32_t n_blocks, void *packed_dev, void *stream);
+int smh_mirror_apply(void *out_dev, uint32_t row_lo, uint32_t n_local, uint32_t n_total, const uint32_t *peer_lo,
+                     const uint32_t *peer_hi, uint32_t n_blocks, const void *recv_dev, void *stream);
 
 /* One query against many nodes: LinearIndex::find (reference src/index/linear.rs:25-45) with
  * search_minhashes / search_minhashes_containment (reference src/index/search.rs:3-9).  Writes the

@@ -113,6 +113,8 @@ _SIGS = {
     "smh_collection_compare": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "smh_collection_free": (None, [C.c_void_p]),
+    "smh_mirror_pack": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "smh_mirror_apply": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p]),
     "smh_find": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_double, C.c_bool, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smh_most_common": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), u64p]),
     "smh_index_new": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_uint32]),

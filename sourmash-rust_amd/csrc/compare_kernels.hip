@@ -882,24 +882,27 @@ __global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t shar
   ds->nfreq = nf;
   ds->part_built = 0;
 }
-// rank of every element of the collection, in collection order, from the slices' local ranks
-__global__ __launch_bounds__(256) void k_reassemble(const uint64_t* __restrict__ off, uint32_t nsk, uint64_t total,
+// rank of every element of the collection, in collection order, from the slices' local ranks: a workgroup per sketch
+// (its slice boundaries and the slices' segment starts sit in LDS; no search per element)
+__global__ __launch_bounds__(256) void k_reassemble(const uint64_t* __restrict__ off, uint32_t nsk,
                                                     const uint32_t* __restrict__ spart, uint32_t G, const uint32_t* __restrict__ segoff,
                                                     const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint64_t ranks_at,
                                                     const DictState* __restrict__ ds, uint32_t* __restrict__ rank) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= t
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= t) lo = mid; else hi = mid;
+  __shared__ uint32_t sp[65], so[64], rb[64];
+  for (uint32_t s = blockIdx.x; s < nsk; s += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x <= G) sp[threadIdx.x] = spart[(size_t)s * (G + 1) + threadIdx.x];
+    if (threadIdx.x < G) { so[threadIdx.x] = segoff[(size_t)threadIdx.x * (nsk + 1) + s]; rb[threadIdx.x] = ds->rbase[threadIdx.x]; }
+    __syncthreads();
+    const uint64_t base = off[s];
+    const uint32_t len = (uint32_t)(off[s + 1] - base);
+    for (uint32_t p = threadIdx.x; p < len; p += 256) {
+      uint32_t g = 0;
+      while (g + 1 < G && sp[g + 1] <= p) g++;     // last g with sp[g] <= p
+      const uint32_t* seg = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * share_bytes + ranks_at);
+      rank[base + p] = rb[g] + seg[so[g] + (p - sp[g])];
+    }
   }
-  const uint32_t s = lo, p = (uint32_t)(t - off[s]);
-  const uint32_t* sp = spart + (size_t)s * (G + 1);
-  uint32_t g = 0;
-  while (g + 1 < G && sp[g + 1] <= p) g++;     // last g with sp[g] <= p
-  const uint32_t* seg = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * share_bytes + ranks_at);
-  rank[t] = ds->rbase[g] + seg[segoff[(size_t)g * (nsk + 1) + s] + (p - sp[g])];
 }
 
 // ---- components of the "shares a hash" graph ------------------------------------------------
@@ -1522,7 +1525,7 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
     // ranks of every element, in collection order
     D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4);
     if (D.total)
-      hipLaunchKernelGGL(k_reassemble, dim3((unsigned)((D.total + 255) / 256)), dim3(256), 0, s, off, n, D.total, D.spart.as<uint32_t>(), G,
+      hipLaunchKernelGGL(k_reassemble, dim3(std::min<uint32_t>(n, 65536)), dim3(256), 0, s, off, n, D.spart.as<uint32_t>(), G,
                          D.segoff.as<uint32_t>(), gathered, D.share_bytes, D.ranks_at, ds, D.rankv.as<uint32_t>());
     // components: the slices' forests united
     T.parent.ensure((size_t)n * 4);
@@ -1810,6 +1813,51 @@ static void launch_tiled(const SketchSet& rows, const SketchSet& cols, uint64_t 
   collection_finish(&D, nullptr, dev, s);
   if (same) collection_compare(&D, 0, n, 0, n, num, row_nums, 1, out, dev, s);
   else collection_compare(&D, 0, rows.n, rows.n, n, num, row_nums, 0, out, dev, s);
+}
+
+// ---- the mirrored-block exchange of a sharded matrix (own_mode 2), device side ---------------------
+// pack: what rank r sends to the rank that holds rows [col_lo, col_hi): its own block's columns col_lo.. transposed, so that
+// the receiver gets (its rows) x (r's rows) row-major.  32 x 32 tiles through LDS: both sides coalesced.
+namespace {
+__global__ __launch_bounds__(256) void k_mirror_pack(const uint64_t* __restrict__ out, uint32_t n_local, uint32_t n_total,
+                                                     uint32_t col_lo, uint32_t ncols, uint64_t* __restrict__ packed) {
+  __shared__ uint64_t tile[32][33];
+  const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  const uint32_t j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  for (uint32_t k = ty; k < 32; k += 8) {
+    const uint32_t i = i0 + k, j = j0 + tx;
+    if (i < n_local && j < ncols) tile[k][tx] = out[(size_t)i * n_total + col_lo + j];
+  }
+  __syncthreads();
+  for (uint32_t k = ty; k < 32; k += 8) {
+    const uint32_t j = j0 + k, i = i0 + tx;
+    if (i < n_local && j < ncols) packed[(size_t)j * n_local + i] = tile[tx][k];
+  }
+}
+// apply: from a received block (this rank's rows x the sender's rows [peer_lo, peer_hi)) keep the entries the SENDER's
+// rows own -- pair (j, i) with j the sender's row -- the rest of the block is this rank's own work.
+__global__ __launch_bounds__(256) void k_mirror_apply(uint64_t* __restrict__ out, uint32_t row_lo, uint32_t n_local, uint32_t n_total,
+                                                      uint32_t peer_lo, uint32_t npeer, const uint64_t* __restrict__ recv) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)n_local * npeer) return;
+  const uint32_t i = (uint32_t)(t / npeer), j = (uint32_t)(t % npeer);
+  if (owns_pair(peer_lo + j, row_lo + i, n_total)) out[(size_t)i * n_total + peer_lo + j] = recv[t];
+}
+}  // namespace
+void launch_mirror_pack(const void* out, uint32_t n_local, uint32_t n_total, uint32_t col_lo, uint32_t col_hi, void* packed, hipStream_t s) {
+  const uint32_t nc = col_hi - col_lo;
+  if (nc == 0 || n_local == 0) return;
+  hipLaunchKernelGGL(k_mirror_pack, dim3((nc + 31) / 32, (n_local + 31) / 32), dim3(256), 0, s, (const uint64_t*)out, n_local, n_total,
+                     col_lo, nc, (uint64_t*)packed);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_mirror_apply(void* out, uint32_t row_lo, uint32_t n_local, uint32_t n_total, uint32_t peer_lo, uint32_t peer_hi, const void* recv,
+                         hipStream_t s) {
+  const uint32_t np = peer_hi - peer_lo;
+  if (np == 0 || n_local == 0) return;
+  hipLaunchKernelGGL(k_mirror_apply, dim3((unsigned)(((uint64_t)n_local * np + 255) / 256)), dim3(256), 0, s, (uint64_t*)out, row_lo, n_local,
+                     n_total, peer_lo, np, (const uint64_t*)recv);
+  HIP_CHECK(hipGetLastError());
 }
 
 void launch_compare_pair(const uint64_t* A, uint32_t la, const uint64_t* B, uint32_t lb, uint64_t n, PairOut* out_dev,

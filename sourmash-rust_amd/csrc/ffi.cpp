@@ -845,6 +845,41 @@ int smh_collection_compare(SmhCollection* c, uint32_t row_lo, uint32_t row_hi, u
   });
 }
 
+int smh_mirror_pack(const void* out_dev, uint32_t n_local, uint32_t n_total, const uint32_t* col_lo, const uint32_t* col_hi,
+                    uint32_t n_blocks, void* packed_dev, void* stream) {
+  return pad_code([&] {
+    if (n_blocks == 0) return;
+    require(out_dev, "out_dev"); require(col_lo, "col_lo"); require(col_hi, "col_hi"); require(packed_dev, "packed_dev");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    uint64_t at = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+      if (col_hi[b] < col_lo[b] || col_hi[b] > n_total) smh::throw_internal("smh_mirror_pack: block outside the matrix");
+      smh::launch_mirror_pack(out_dev, n_local, n_total, col_lo[b], col_hi[b], (uint64_t*)packed_dev + at, s);
+      at += (uint64_t)(col_hi[b] - col_lo[b]) * n_local;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+int smh_mirror_apply(void* out_dev, uint32_t row_lo, uint32_t n_local, uint32_t n_total, const uint32_t* peer_lo, const uint32_t* peer_hi,
+                     uint32_t n_blocks, const void* recv_dev, void* stream) {
+  return pad_code([&] {
+    if (n_blocks == 0) return;
+    require(out_dev, "out_dev"); require(peer_lo, "peer_lo"); require(peer_hi, "peer_hi"); require(recv_dev, "recv_dev");
+    auto& dev = smh::Device::get();
+    std::lock_guard<std::recursive_mutex> lock(dev.mutex());
+    hipStream_t s = dev.user_stream(stream);
+    uint64_t at = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+      if (peer_hi[b] < peer_lo[b] || peer_hi[b] > n_total) smh::throw_internal("smh_mirror_apply: block outside the matrix");
+      smh::launch_mirror_apply(out_dev, row_lo, n_local, n_total, peer_lo[b], peer_hi[b], (const uint64_t*)recv_dev + at, s);
+      at += (uint64_t)(peer_hi[b] - peer_lo[b]) * n_local;
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+  });
+}
+
 int smh_synth_dna_dev(void* out_dev, uint64_t start, uint64_t len, uint64_t seed, uint64_t n_every, void* stream) {
   return pad_code([&] {
     require(out_dev, "out_dev");

@@ -213,6 +213,12 @@ void collection_compare(CollectionDict* d, uint32_t row_lo, uint32_t row_hi, uin
                         const uint32_t* row_nums, uint32_t own_mode, const CompareOut& out, Device& dev, hipStream_t s);
 void collection_free(CollectionDict* d);
 
+// the mirrored-block exchange of a matrix computed with own_mode 2 (8-byte elements): the block this rank sends to the rank
+// holding rows [col_lo, col_hi) -- its own block's columns, transposed -- and what it keeps of a block it received
+void launch_mirror_pack(const void* out, uint32_t n_local, uint32_t n_total, uint32_t col_lo, uint32_t col_hi, void* packed, hipStream_t s);
+void launch_mirror_apply(void* out, uint32_t row_lo, uint32_t n_local, uint32_t n_total, uint32_t peer_lo, uint32_t peer_hi, const void* recv,
+                         hipStream_t s);
+
 void launch_compare_block(const SketchSet& rows, const SketchSet& cols, uint32_t num,
                           const uint32_t* row_nums, const CompareOut& out, Device& dev,
                           hipStream_t s, uint32_t max_row_len, uint32_t max_col_len, uint64_t nr_elems,

@@ -115,9 +115,14 @@ class HipEngine:
     """The product path: smh_collection_* (csrc/compare_kernels.hip)."""
 
     def begin(self, allsigs, n_total, world, rank):
+        """allsigs: (>= n_total, width) tensor of fixed-width signatures, or a (flat hashes, host offsets) pair (ragged)"""
         from . import matrix
-        width = allsigs.shape[1]
-        self.offsets = np.arange(n_total + 1, dtype=np.uint64) * np.uint64(width)
+        if isinstance(allsigs, tuple):
+            allsigs, offsets = allsigs
+            self.offsets = np.ascontiguousarray(offsets[: n_total + 1], dtype=np.uint64)
+        else:
+            width = allsigs.shape[1]
+            self.offsets = np.arange(n_total + 1, dtype=np.uint64) * np.uint64(width)
         self.coll = matrix.Collection(allsigs, self.offsets, world, rank)
         self.device = allsigs.device
         self.world, self.rank = world, rank
@@ -147,11 +152,30 @@ class HipEngine:
 
 def mirror_send_list(out, blocks, rank, n_total):
     """out: (n_local, n_total) tensor of this rank's row block.  -> per peer the flat transposed
-    block out[:, rows of peer]^T when this rank's rows own pairs with the peer's rows, else empty."""
+    block out[:, rows of peer]^T when this rank's rows own pairs with the peer's rows, else empty.
+    CUDA tensors: ONE call packs all the blocks into one buffer (smh_mirror_pack; the list holds views of it)."""
     lo, hi = blocks[rank]
+    peers = [c for c, (clo, chi) in enumerate(blocks) if c != rank and block_needs(lo, hi, clo, chi, n_total)]
+    if out.is_cuda and peers and hi > lo:
+        import ctypes as C
+        import torch
+        from ._lib import lib
+        from .errors import call
+        assert out.is_contiguous() and out.element_size() == 8
+        sizes = [(blocks[c][1] - blocks[c][0]) * (hi - lo) for c in peers]
+        packed = torch.empty(sum(sizes), dtype=out.dtype, device=out.device)
+        clo = (C.c_uint32 * len(peers))(*[blocks[c][0] for c in peers])
+        chi = (C.c_uint32 * len(peers))(*[blocks[c][1] for c in peers])
+        call(lib().smh_mirror_pack, C.c_void_p(out.data_ptr()), hi - lo, n_total, clo, chi, len(peers), C.c_void_p(packed.data_ptr()),
+             C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+        send, at = [out.new_empty(0) for _ in blocks], 0
+        for c, k in zip(peers, sizes):
+            send[c] = packed[at:at + k]
+            at += k
+        return send
     send = []
     for c, (clo, chi) in enumerate(blocks):
-        if c != rank and block_needs(lo, hi, clo, chi, n_total):
+        if c in peers:
             send.append(out[:, clo:chi].t().contiguous().reshape(-1))
         else:
             send.append(out.new_empty(0))
@@ -165,17 +189,38 @@ def mirror_recv_sizes(blocks, rank, n_total):
 
 
 def mirror_apply(out, recv, blocks, rank, n_total):
-    """keeps, from every received block, the entries the sender's rows own"""
+    """keeps, from every received block, the entries the sender's rows own
+    (CUDA tensors: smh_mirror_apply, one call for all blocks when they lie in one buffer)"""
     import torch
     lo, hi = blocks[rank]
+    got = [p for p in range(len(blocks)) if p != rank and recv[p].numel()]
+    if out.is_cuda and got:
+        import ctypes as C
+        from ._lib import lib
+        from .errors import call
+        flat = torch.cat([recv[p].reshape(-1) for p in got]) if len(got) > 1 and not _adjacent(recv, got) else recv[got[0]]
+        plo = (C.c_uint32 * len(got))(*[blocks[p][0] for p in got])
+        phi = (C.c_uint32 * len(got))(*[blocks[p][1] for p in got])
+        call(lib().smh_mirror_apply, C.c_void_p(out.data_ptr()), lo, hi - lo, n_total, plo, phi, len(got), C.c_void_p(flat.data_ptr()),
+             C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream))
+        return
     rows = torch.arange(lo, hi, device=out.device).unsqueeze(1)
-    for p, (plo, phi) in enumerate(blocks):
-        if p == rank or recv[p].numel() == 0:
-            continue
+    for p in got:
+        plo, phi = blocks[p]
         cols = torch.arange(plo, phi, device=out.device).unsqueeze(0)
         theirs = owns(cols, rows, n_total)               # the sender's row j owns (j, i)
         blk = recv[p].reshape(hi - lo, phi - plo)
         out[:, plo:phi] = torch.where(theirs, blk, out[:, plo:phi])
+
+
+def _adjacent(recv, got):
+    """are the received blocks consecutive views of one buffer (what _Comm.all_to_all returns)?"""
+    at = recv[got[0]].data_ptr()
+    for p in got:
+        if recv[p].data_ptr() != at or not recv[p].is_contiguous():
+            return False
+        at += recv[p].numel() * recv[p].element_size()
+    return True
 
 
 def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), engine=None, group=None, symmetric=True,
@@ -243,7 +288,7 @@ def simulate_sharded(allsigs, n_total, num, world, want=("jaccard",), engine_fac
     """The same steps as compare_matrix_sharded for `world` ranks run one after the other in ONE
     process (no process group): the collectives become concatenations and list shuffles, everything
     else -- slices of the dictionary, ownership, the mirrored blocks -- is the code the ranks run.
-    allsigs: (>= n_total, width) tensor.  Returns the list of the ranks' row blocks."""
+    allsigs: (>= n_total, width) tensor, or (flat hashes, offsets) for ragged sketches.  Returns the list of the ranks' row blocks."""
     import torch
     blocks = [shard_range(n_total, world, r)[:2] for r in range(world)]
     engs = [(engine_factory or HipEngine)() for _ in range(world)]

@@ -179,6 +179,41 @@ while time.time() < t_end:
                 print("MERGE MISMATCH case", case, eg, eo)
                 sys.exit(1)
         n_sk += 1
+    elif rng.random() < 0.12:
+        # the SHARDED all-vs-all matrix: `world` ranks played one after the other (distributed.simulate_sharded: the sliced
+        # dictionary, pair ownership, the mirrored-block exchange) on a ragged collection, whole matrix against the oracle
+        from sourmash_rust_amd import distributed as D
+        nrs = np.random.RandomState(rng.getrandbits(31))
+        n = rng.randint(2, 260)
+        world = rng.choice([2, 3, 4, 5, 8])
+        width = rng.choice([8, 60, 300])
+        shift = rng.choice([0, 0, 20, 40])                     # hash values crowded into a corner of hash space
+        pool = np.unique(nrs.randint(0, 1 << 62, size=width * rng.choice([2, 6, 30]), dtype=np.int64).astype(np.uint64) >> np.uint64(shift))
+        sks = [np.sort(nrs.choice(pool, min(len(pool), int(nrs.choice([0, 1, width // 2, width, 2 * width]))), replace=False)) for _ in range(n)]
+        if rng.random() < 0.3:
+            sks = [np.unique(np.concatenate([x, np.array([7, 99], dtype=np.uint64)])) if len(x) and nrs.rand() < 0.8 else x for x in sks]
+        num = rng.choice([0, width, width // 2, 3])
+        flat, off = pkg.matrix.csr_from_sketches(sks)
+        if flat.size == 0:
+            continue
+        t = torch.from_numpy(flat.view(np.int64)).cuda()
+        tune = rng.choice([dict(), dict(), dict(route="components"), dict(route="tiled"), dict(split_frequent=False)])
+        want = ("jaccard", "common", "size") + (("count_common", "containment") if rng.random() < 0.5 else ())
+        with pkg.matrix.tuning(**tune):
+            outs = D.simulate_sharded((t, off), n, num, world, want=want)
+        common, size, jac = coracle.compare_matrix(sks, sks, num, 31, 0 if num else 1 << 62)
+        got = {k: torch.cat([o[k] for o in outs]).cpu().numpy() for k in want}
+        ok = (got["common"].view(np.uint64) == common).all() and (got["size"].view(np.uint64) == size).all() and (got["jaccard"] == jac).all()
+        if ok and "count_common" in want:
+            cc = np.array([[len(np.intersect1d(a, b)) for b in sks] for a in sks], dtype=np.int64).reshape(n, n)
+            lens = np.array([len(x) for x in sks], dtype=np.float64)[:, None]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cont = cc / lens
+            ok = (got["count_common"] == cc).all() and ((got["containment"] == cont) | (np.isnan(cont) & np.isnan(got["containment"]))).all()
+        if not ok:
+            print("SHARDED MATRIX MISMATCH", n, world, width, shift, num, tune, want)
+            sys.exit(1)
+        n_cmp += 1
     elif rng.random() < 0.15:
         # a block with more than 2^18 sharing pairs: the shape-based default takes the tiled kernel.
         # Device CSR in, whole matrix against the C oracle's compare_matrix.
