@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void k_slice_parts(const uint64_t* __restrict_
 // segoff[g][s] = elements of slice g in the sketches before s (exclusive scan down column g; segoff[g][nsk] = slice size).
 // One workgroup per slice: every lane sums a stretch of sketches, the stretch sums are scanned in LDS.
 __global__ __launch_bounds__(1024) void k_slice_scan(const uint32_t* __restrict__ spart, uint32_t nsk, uint32_t G,
-                                                     uint32_t* __restrict__ segoff) {
+                                                     uint32_t* __restrict__ segoff, uint32_t* __restrict__ sizes) {
   __shared__ uint32_t part_sum[1024];
   const uint32_t g = blockIdx.x, tid = threadIdx.x;
   const uint32_t per = (nsk + 1023) / 1024;
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const uint32_t* __restrict_
     dst[s] = run;
     run += spart[(size_t)s * (G + 1) + g + 1] - spart[(size_t)s * (G + 1) + g];
   }
-  if (tid == 1023) dst[nsk] = part_sum[1023];
+  if (tid == 1023) { dst[nsk] = part_sum[1023]; sizes[g] = part_sum[1023]; }
 }
 // slice g of every sketch, sketch after sketch: keys[t], node[t] = its sketch, org[t] = t
 __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
@@ -1224,12 +1224,16 @@ __global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st
   const uint32_t wsum = (uint32_t)wave_sum64(mine);
   if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&st->count16, wsum);
 }
-// rows per wave (x 4 waves = rows per tile): 16-row tiles amortise the staging best; when few tiles
-// hold sharing pairs, shorter ones keep the chip full (the kernel is latency bound)
+// rows per wave (x 4 waves = rows per tile): 16-row tiles amortise the staging best; when few tiles hold sharing pairs,
+// shorter ones keep the chip full (one tile is one latency chain).  Thresholds re-measured with the round-3 walk
+// (profiles/r03_tile_height.txt): 16 rows from a quarter of a chip-filling round of 16-row tiles on, 8 rows from a sixteenth.
+__device__ __host__ inline uint32_t rows_per_wave_for(uint64_t count16, uint32_t fill_tiles) {
+  return 4 * count16 >= fill_tiles ? 4u : (16 * count16 >= fill_tiles ? 2u : 1u);
+}
 __global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t fill_tiles, uint32_t* part_built) {
   if (!st->skip_tiled) *part_built = 1;   // k_partition ran just before this launch (same stream)
   uint32_t rpw = forced_rpw;
-  if (!rpw) rpw = st->count16 >= fill_tiles ? 4u : (2 * st->count16 >= fill_tiles ? 2u : 1u);
+  if (!rpw) rpw = rows_per_wave_for(st->count16, fill_tiles);
   st->rpw = rpw;
 }
 __global__ __launch_bounds__(256) void k_flag_tiles(TileTest t, uint32_t wpb, uint32_t* __restrict__ tiles, uint32_t tiles_cap,
@@ -1390,7 +1394,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
 
   // ---- slices of hash space: splitters from a sorted sample, where every sketch crosses them, slice sizes
   D.splitters.ensure((size_t)G * 8);
-  const uint32_t S = G == 1 ? 0u : (uint32_t)std::min<uint64_t>(D.total, 8192);
+  const uint32_t S = G == 1 ? 0u : (uint32_t)std::min<uint64_t>(D.total, 4096);
   if (S) {
     T.sample0.ensure((size_t)S * 8); T.sample1.ensure((size_t)S * 8);
     hipLaunchKernelGGL(k_sample_keys, dim3((S + 255) / 256), dim3(256), 0, s, D.hashes, D.total, S, T.sample0.as<uint64_t>());
@@ -1407,12 +1411,13 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     D.segoff.ensure((size_t)G * (n + 1) * 4);
     hipLaunchKernelGGL(k_slice_parts, dim3((unsigned)(((uint64_t)n * (G + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, n,
                        D.splitters.as<uint64_t>(), G, D.spart.as<uint32_t>());
-    hipLaunchKernelGGL(k_slice_scan, dim3(G), dim3(1024), 0, s, D.spart.as<uint32_t>(), n, G, D.segoff.as<uint32_t>());
+    T.rstate.ensure(sizeof(RangeState) + 64 * 4);
+    uint32_t* d_sizes = reinterpret_cast<uint32_t*>(T.rstate.as<uint8_t>() + sizeof(RangeState));
+    hipLaunchKernelGGL(k_slice_scan, dim3(G), dim3(1024), 0, s, D.spart.as<uint32_t>(), n, G, D.segoff.as<uint32_t>(), d_sizes);
     HIP_CHECK(hipGetLastError());
     // the one read-back of building a shared dictionary: the slice sizes (every owner computes the same table)
     std::vector<uint32_t> sizes(G);
-    for (uint32_t g = 0; g < G; g++)
-      HIP_CHECK(hipMemcpyAsync(&sizes[g], D.segoff.as<uint32_t>() + (size_t)g * (n + 1) + n, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)G * 4, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     D.n_mine = sizes[rank];
     D.n_max = *std::max_element(sizes.begin(), sizes.end());
@@ -1424,7 +1429,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   D.share_bytes = align8(D.ranks_at + (uint64_t)D.n_max * 4);
   D.share.ensure(D.share_bytes);
   uint8_t* share = D.share.as<uint8_t>();
-  T.rstate.ensure(sizeof(RangeState));
+  T.rstate.ensure(sizeof(RangeState) + 64 * 4);
   RangeState* rs = T.rstate.as<RangeState>();
   HIP_CHECK(hipMemsetAsync(rs, 0, sizeof(RangeState), s));
 
@@ -1684,7 +1689,7 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     uint32_t forced_rpw = ex.rpw > 0 ? (uint32_t)ex.rpw : 0u;
     if (!forced_rpw && tune.visit_all_tiles) {
       const uint64_t all16 = (uint64_t)((nrows + 15) / 16) * tiles_c * (same ? 1 : 2) / 2;
-      forced_rpw = all16 >= fill_tiles ? 4u : (2 * all16 >= fill_tiles ? 2u : 1u);
+      forced_rpw = rows_per_wave_for(all16, fill_tiles);
     }
     if (!forced_rpw)
       hipLaunchKernelGGL(k_tiles_count16, dim3((unsigned)std::min<uint64_t>(((uint64_t)((nrows + 15) / 16) * tiles_c + 255) / 256, 4096)),
