@@ -964,14 +964,17 @@ __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ ke
 // LDS.  The unions of related sketches all meet at the same few parent words; in LDS that contention costs nanoseconds,
 // through the L2 (agent-scope atomics) microseconds each (1000 sketches of one family: 93 us for 7 800 sampled pairs).
 constexpr uint32_t kUfLdsNodes = 16384;
+// Several workgroups: each takes every gridDim.x-th sampled pair, builds a forest of its own in LDS and leaves every
+// sketch's root in its row of `out` ([gridDim.x][nsk]); k_uf_merge then unites the forests (nsk unions per workgroup, most
+// of them between sketches the earlier forests have connected already).
 template <int Shift>
 __global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
-                                                      const uint32_t* __restrict__ node, uint64_t n, uint32_t nsk, uint32_t* parent,
+                                                      const uint32_t* __restrict__ node, uint64_t n, uint32_t nsk, uint32_t* __restrict__ out,
                                                       const uint32_t* __restrict__ runid, const uint8_t* __restrict__ isfreq) {
   extern __shared__ uint32_t lpar[];
   for (uint32_t i = threadIdx.x; i < nsk; i += 1024) lpar[i] = i;
   __syncthreads();
-  for (uint64_t t = threadIdx.x + 1; (t << Shift) < n; t += 1024) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x + 1; (t << Shift) < n; t += (uint64_t)gridDim.x * 1024) {
     const uint64_t i = t << Shift;
     if (keys[i] != keys[i - 1]) continue;
     if (isfreq && isfreq[runid[i]]) continue;
@@ -986,10 +989,11 @@ __global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict
     }
   }
   __syncthreads();
+  uint32_t* dst = out + (size_t)blockIdx.x * nsk;
   for (uint32_t i = threadIdx.x; i < nsk; i += 1024) {   // flattened: every sketch points at its root
     uint32_t x = i;
     while (true) { const uint32_t p = lpar[x]; if (p == x) break; x = p; }
-    parent[i] = x;
+    dst[i] = x;
   }
 }
 // the slices' forests (root of every sketch within slice g) united into one
@@ -1273,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_flag_tiles(TileTest t, uint32_t wpb, ui
 // temporaries of building a dictionary and of planning one block compare: process-wide, grow-only, used under the device mutex
 struct TiledScratch {
   DeviceBuffer keys0, keys1, org0, org1, uniq, starts, node, parent, tiles, work, plan, pk0, pk1, pk2, pk3, rng, cnt, runid, isfreq,
-      sample0, sample1, rstate, cat;
+      sample0, sample1, rstate, cat, wroots;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -1321,7 +1325,7 @@ void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.node, &T.parent, &T.tiles, &T.work, &T.plan,
                           &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt, &T.runid, &T.isfreq, &T.sample0, &T.sample1, &T.rstate,
-                          &T.cat})
+                          &T.cat, &T.wroots})
     b->release();
   release_implicit_dict();
 }
@@ -1471,17 +1475,23 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   uint32_t* roots = reinterpret_cast<uint32_t*>(share + D.roots_at);
   hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
   if (nm) {
-    // a 1/256 sample first -- in LDS by one workgroup when the collection is small (k_uf_runs_lds), else straight to
-    // the atomic path -- then 1/16 and everything through the cached filter, which sends on only the pairs that are not
-    // connected yet
-    if (n <= kUfLdsNodes && nm <= (1u << 22))      // (one workgroup: beyond ~16 K sampled pairs the many-workgroup path wins)
-      hipLaunchKernelGGL((k_uf_runs_lds<8>), dim3(1), dim3(1024), (size_t)n * 4, s, sk, so, T.node.as<uint32_t>(), (uint64_t)nm, n,
-                         T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
-    else
+    // A sample of the neighbour pairs first.  A small pool (at most kUfLdsNodes sketches, 4 M hashes): 1/64 of the pairs, in LDS forests of a few
+    // workgroups (k_uf_runs_lds; ~8 K pairs each) that k_uf_merge unites -- the contended unions happen in LDS, the global
+    // parent array sees one union per sketch and forest.  Larger pools: 1/256 straight to the atomic path, then 1/16 through
+    // the cached filter.  Finally everything through the cached filter, which sends on only the pairs not connected yet.
+    if (n <= kUfLdsNodes && nm <= (1u << 22)) {     // (beyond ~4 M hashes the many-workgroup atomic path wins: measured)
+      const uint32_t W = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nm >> 6) / 8192));
+      T.wroots.ensure((size_t)W * n * 4);
+      hipLaunchKernelGGL((k_uf_runs_lds<6>), dim3(W), dim3(1024), (size_t)n * 4, s, sk, so, T.node.as<uint32_t>(), (uint64_t)nm, n,
+                         T.wroots.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+      hipLaunchKernelGGL(k_uf_merge, dim3((unsigned)(((uint64_t)W * n + 255) / 256)), dim3(256), 0, s, T.wroots.as<uint8_t>(), (uint64_t)n * 4,
+                         (uint64_t)0, W, n, T.parent.as<uint32_t>());
+    } else {
       hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                          (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
-    hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
-                       (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+      hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+                         (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+    }
     hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                        (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
   }
