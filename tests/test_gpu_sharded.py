@@ -147,3 +147,43 @@ def test_c4_dense_matrix_on_four_simulated_ranks(pkg, coracle):
     # boundary are walked by both sides)
     print("tiled kernel: 1 rank %.2f ms, 4 ranks summed %.2f ms" % (one, four))
     assert four <= 1.3 * one, (one, four)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_collection_degenerate_shapes(world, pkg, coracle):
+    """The collection dictionary on the shapes that break assumptions: every sketch EMPTY (no hash at all to slice or sort), one
+    sketch, two identical sketches, a single hash shared by all -- through smh_collection_* directly, every owner of the
+    (simulated) job, ownership 0 and the job's own mode, against the oracle."""
+    import torch
+    from sourmash_rust_amd import distributed as D, matrix as MX
+    shapes = {
+        "all_empty": [np.zeros(0, np.uint64) for _ in range(7)],
+        "one_sketch": [np.array([3, 9, 27], dtype=np.uint64)],
+        "identical": [np.arange(1, 400, dtype=np.uint64)] * 2,
+        "one_shared_hash": [np.array([5], dtype=np.uint64) for _ in range(40)],
+        "mostly_empty": [np.zeros(0, np.uint64)] * 5 + [np.array([1, 2, 3], dtype=np.uint64)] + [np.zeros(0, np.uint64)] * 4,
+    }
+    for name, sks in shapes.items():
+        n = len(sks)
+        flat, off = MX.csr_from_sketches(sks)
+        t = torch.from_numpy(np.concatenate([flat, np.zeros(1, np.uint64)]).view(np.int64)).cuda()    # (never a 0-byte allocation)
+        for num in (0, 2):
+            common, size, jac = coracle.compare_matrix(sks, sks, num, 31, 0)
+            colls = [MX.Collection(t, off, world, r) for r in range(world)]
+            gathered = None
+            if world > 1:
+                gathered = torch.empty(world * colls[0].share_bytes, dtype=torch.uint8, device="cuda")
+                for r, c in enumerate(colls):
+                    c.share_to(gathered[r * c.share_bytes:(r + 1) * c.share_bytes])
+            for r, c in enumerate(colls):
+                c.finish(gathered)
+                lo, hi, _ = D.shard_range(n, world, r)
+                full = c.compare(lo, hi, num, want=("common", "size", "jaccard"), ownership=MX.OWN_ALL)
+                assert (full["common"].cpu().numpy().view(np.uint64) == common[lo:hi]).all(), (name, world, r, num)
+                assert (full["size"].cpu().numpy().view(np.uint64) == size[lo:hi]).all(), (name, world, r, num)
+                assert (full["jaccard"].cpu().numpy() == jac[lo:hi]).all(), (name, world, r, num)
+                c.close()
+            if world > 1 and n >= 2:
+                outs = D.simulate_sharded((t, off), n, num, world, want=("common", "jaccard"))
+                got = torch.cat([o["common"] for o in outs]).cpu().numpy().view(np.uint64)
+                assert (got == common).all(), (name, world, num)
