@@ -1568,7 +1568,14 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
   (void)dev;
 }
 
-void collection_free(CollectionDict* D) { delete D; }
+void collection_free(CollectionDict* D) {
+  if (!D) return;
+  (void)hipDeviceSynchronize();    // ONE wait for whatever may still be using the buffers, then they all go back to the pool
+  for (DeviceBuffer* b : {&D->off, &D->splitters, &D->spart, &D->segoff, &D->share, &D->dstate, &D->rankv, &D->root, &D->fmask, &D->fpos,
+                          &D->hbound, &D->part})
+    b->release_after_sync();
+  delete D;
+}
 static CollectionDict& implicit_dict();
 static void release_implicit_dict() {
   CollectionDict& D = implicit_dict();

@@ -117,6 +117,11 @@ void DeviceBuffer::release() {
   ptr = nullptr;
   bytes = 0;
 }
+void DeviceBuffer::release_after_sync() {
+  if (ptr) device_pool_free(ptr, bytes, false);
+  ptr = nullptr;
+  bytes = 0;
+}
 DeviceBuffer::~DeviceBuffer() { release(); }
 
 void PinnedBuffer::ensure(size_t need) {

@@ -38,6 +38,7 @@ struct DeviceBuffer {
   size_t bytes = 0;
   void ensure(size_t need);
   void release();
+  void release_after_sync();   // the caller has just waited for the device: no second wait
   template <class T> T* as() const { return reinterpret_cast<T*>(ptr); }
   DeviceBuffer() = default;
   DeviceBuffer(const DeviceBuffer&) = delete;
