@@ -223,6 +223,23 @@ def _adjacent(recv, got):
     return True
 
 
+def _kernel_outputs(want, exchange):
+    """containment = count_common / |row|: after a transpose the mirrored value would have the OTHER sketch's length as its
+    denominator, so with an exchange it is derived afterwards from the (symmetric) count"""
+    if not exchange:
+        return tuple(want)
+    extra = ("count_common",) if "containment" in want and "count_common" not in want else ()
+    return tuple(k for k in want if k != "containment") + extra
+
+
+def _ownership(world, symmetric):
+    """smh_collection_compare's ownership: 2 = this rank's share of a matrix the ranks compute together, 1 = the whole
+    matrix on one rank (upper triangle + mirrors), 0 = every pair of the block here"""
+    if not symmetric:
+        return 0
+    return 2 if world > 1 else 1
+
+
 def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), engine=None, group=None, symmetric=True,
                            timings=None):
     """local_sigs: (per, width) int64 tensor holding this rank's rows (rows beyond its share are
@@ -259,11 +276,8 @@ def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), engine=N
     del gathered
     tick("dictionary_assemble")
     exchange = symmetric and world > 1
-    # containment = count_common / |row|: the mirrored value has the other denominator, so it is
-    # derived after the exchange from the (symmetric) count
-    kernel_want = tuple(k for k in want if k != "containment") + (("count_common",) if "containment" in want and "count_common" not in want else ()) \
-        if exchange else want
-    out = eng.compare(lo, hi, num, kernel_want, (2 if exchange else (1 if world == 1 and symmetric else 0)))
+    kernel_want = _kernel_outputs(want, exchange)
+    out = eng.compare(lo, hi, num, kernel_want, _ownership(world, symmetric))
     tick("compare")
     if exchange:
         for name in kernel_want:
@@ -299,10 +313,8 @@ def simulate_sharded(allsigs, n_total, num, world, want=("jaccard",), engine_fac
         e.finish(gathered)
     want = tuple(want)
     exchange = symmetric and world > 1
-    kernel_want = tuple(k for k in want if k != "containment") + (("count_common",) if "containment" in want and "count_common" not in want else ()) \
-        if exchange else want
-    outs = [e.compare(blocks[r][0], blocks[r][1], num, kernel_want, (2 if exchange else (1 if world == 1 and symmetric else 0)))
-            for r, e in enumerate(engs)]
+    kernel_want = _kernel_outputs(want, exchange)
+    outs = [e.compare(blocks[r][0], blocks[r][1], num, kernel_want, _ownership(world, symmetric)) for r, e in enumerate(engs)]
     if exchange:
         for name in kernel_want:
             sends = [mirror_send_list(outs[r][name], blocks, r, n_total) for r in range(world)]
