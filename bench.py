@@ -323,6 +323,14 @@ def main():
             wfloor = floor_ms * (1.0 + half_share)
             valu_bound["rate_weighted"] = {"half_rate_share": half_share, "floor_ms": wfloor, "frac": wfloor / kern_ms,
                                            "label": "the same floor with the kernel's half-rate instructions priced at 4 cycles"}
+            mc = pmc.get("measured_cycles_per_wave_inst")
+            if mc:
+                # ... and at the issue rates the microbenchmark measured on this chip for the two classes
+                mfloor = floor_ms / VALU_CYCLES * ((1.0 - half_share) * mc["two_operand"] + half_share * mc["slow_class"])
+                valu_bound["at_measured_rates"] = {"cycles_two_operand": mc["two_operand"], "cycles_slow_class": mc["slow_class"],
+                                                   "floor_ms": mfloor, "frac": mfloor / kern_ms,
+                                                   "label": "VALU issue time of the kernel's instruction mix at the measured issue rates "
+                                                            "(profiles/r02_instr_rates.txt); what is left is attributed in DESIGN.md section 7"}
 
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
