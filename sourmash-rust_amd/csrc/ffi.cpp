@@ -600,6 +600,11 @@ struct SmhIndex {
   std::vector<smh::KmerMinHash> params;   // parameters only (mins cleared): check_compatible per node
   uint32_t max_len = 0;
   uint32_t n = 0;
+  // the dictionary of the resident set (dense ranks, components, frequent hashes), built by the first all-vs-all compare
+  // of the index with itself and kept: later ones skip the pre-pass (the nodes of an index never change)
+  smh::CollectionDict* dict = nullptr;
+  uint32_t dict_split = 0;      // the frequent-hash setting the dictionary was built under
+  ~SmhIndex() { if (dict) smh::collection_free(dict); }
 };
 
 SmhIndex* smh_index_new(KmerMinHash* const* nodes, uint32_t n_nodes) {
@@ -728,6 +733,19 @@ int smh_index_compare(SmhIndex* rows, SmhIndex* cols, double* jaccard, uint64_t*
     // one num for every row: pass it as the launch-wide value (lets an index against itself use symmetry)
     bool uniform = true;
     for (uint32_t v : rows->h_nums) uniform &= v == rows->h_nums[0];
+    const smh::CompareTuning tune = smh::compare_get_tuning();
+    const bool block_route = tune.route == smh::kRouteAuto ? (np >= 4096 && rows->n >= 16) : (tune.route == smh::kRouteComponents || tune.route == smh::kRouteTiled);
+    if (rows == cols && block_route && rows->h_offsets.back() > 0) {
+      // an index against itself: its dictionary is built once and reused (the pre-pass is most of a sparse matrix's time)
+      if (rows->dict && rows->dict_split != tune.split_frequent) { smh::collection_free(rows->dict); rows->dict = nullptr; }
+      if (!rows->dict) {
+        rows->dict = smh::collection_begin(R.hashes, R.offsets, rows->h_offsets.data(), rows->n, 1, 0, dev, s);
+        smh::collection_finish(rows->dict, nullptr, dev, s);
+        rows->dict_split = tune.split_frequent;
+      }
+      smh::collection_compare(rows->dict, 0, rows->n, 0, rows->n, uniform ? rows->h_nums[0] : 0,
+                              uniform ? nullptr : rows->nums.as<uint32_t>(), 1, o, dev, s);
+    } else
     smh::launch_compare_block(R, C, uniform ? rows->h_nums[0] : 0, uniform ? nullptr : rows->nums.as<uint32_t>(), o, dev, s,
                               rows->max_len, cols->max_len, rows->h_offsets.back(), cols->h_offsets.back(), rows == cols);
     if (common) HIP_CHECK(hipMemcpyAsync(common, d_common, np * 8, hipMemcpyDeviceToHost, s));

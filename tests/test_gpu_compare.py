@@ -466,6 +466,14 @@ def test_resident_index(pkg, coracle, sbt_subset_sketches):
     out = sub.compare(idx, want=("jaccard", "count_common"))
     ref = pkg.matrix.compare_block(nodes[:20], nodes, want=("jaccard", "count_common"))
     assert (out["jaccard"] == ref["jaccard"]).all() and (out["count_common"] == ref["count_common"]).all()
+    # the index against ITSELF: its dictionary (ranks, components, frequent hashes) is built by the first call and reused by
+    # the later ones, on every route and for every output
+    full = pkg.matrix.compare_block(nodes, nodes, want=("jaccard", "common", "size", "count_common", "containment"))
+    for tune in (dict(), dict(route="tiled"), dict(route="components"), dict(), dict(split_frequent=False), dict()):
+        with pkg.matrix.tuning(**tune):
+            own = idx.compare(idx, want=("jaccard", "common", "size", "count_common", "containment"))
+        for k in full:
+            assert (own[k] == full[k]).all() or (k == "containment" and np.array_equal(own[k], full[k], equal_nan=True)), (k, tune)
     bad = pkg.KmerMinHash(0, 31, False, 42, 9223372036854776)
     with pytest.raises(pkg.SourmashError) as ei:
         idx.find(bad, 0.1)

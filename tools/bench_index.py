@@ -37,3 +37,13 @@ for name in (b"compare_few", b"compare_wave", b"compare_tiled"):
 assert a == b and len(a) > 0
 print("n=%d num=%d hits=%d | smh_find %.2f ms/query | index build %.1f ms, smh_index_find %.3f ms/query (%.1f M nodes/s)"
       % (n, num, len(a), t_call * 1e3, t_build * 1e3, t_res * 1e3, n / t_res / 1e6))
+
+# the resident index against itself: the first call builds its dictionary, the later ones reuse it
+if n <= 20000:
+    import numpy as _np
+    t0 = time.perf_counter(); m1 = idx.compare(idx, want=("jaccard",)); t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(3): m2 = idx.compare(idx, want=("jaccard",))
+    t_next = (time.perf_counter() - t0) / 3
+    assert (m1["jaccard"] == m2["jaccard"]).all() and (_np.diag(m2["jaccard"]) == 1.0).all()
+    print("index x index (%d^2, host outputs): first call %.1f ms, later calls %.1f ms (dictionary kept with the index)" % (n, t_first * 1e3, t_next * 1e3))
