@@ -56,23 +56,53 @@ void KmerMinHash::materialize() const {
   std::lock_guard<std::recursive_mutex> lock(d.mutex());
   hipStream_t s = d.stream();
   const size_t n = (size_t)dev->n;
-  std::vector<uint64_t>& hm = mins.w();
-  hm.resize(n);
-  if (n) HIP_CHECK(hipMemcpyAsync(hm.data(), dev->uniq.ptr, n * 8, hipMemcpyDeviceToHost, s));
   d.count("sketch_to_host");   // (evidence for the tests: a sketch that accumulates in HBM must not pass here between batches)
-  std::vector<uint32_t> st;
-  if (has_abunds) abunds.resize(n);
-  if (has_abunds && n) {
+  // Large states come over in 16 MB pieces through two page-locked buffers (link speed instead of a pageable bounce copy),
+  // and the vectors are APPENDED to: `resize` would first write 80 MB of zeros for a 10^7-hash sketch.
+  Engine& E = Engine::get();
+  constexpr size_t kPiece = 16u << 20;
+  auto fetch = [&](const void* src, size_t bytes, auto&& sink) {     // sink(const uint8_t* piece, size_t piece_bytes), in order
+    if (bytes <= (1u << 20)) {
+      std::vector<uint8_t> tmp(bytes);
+      if (bytes) HIP_CHECK(hipMemcpyAsync(tmp.data(), src, bytes, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      sink(tmp.data(), bytes);
+      return;
+    }
+    PinnedBuffer* pin[2] = {&E.pin_a, &E.pin_b};
+    pin[0]->ensure(kPiece); pin[1]->ensure(kPiece);
+    size_t off = 0, prev_bytes = 0;
+    int which = 0;
+    while (off < bytes || prev_bytes) {
+      const size_t cur = std::min(kPiece, bytes - off);
+      if (cur) HIP_CHECK(hipMemcpyAsync(pin[which]->ptr, (const uint8_t*)src + off, cur, hipMemcpyDeviceToHost, s));
+      if (prev_bytes) sink(pin[which ^ 1]->as<uint8_t>(), prev_bytes);    // the piece before this one, while this one is in flight
+      HIP_CHECK(hipStreamSynchronize(s));
+      off += cur; prev_bytes = cur; which ^= 1;
+    }
+  };
+  std::vector<uint64_t>& hm = mins.w();
+  hm.clear(); hm.reserve(n);
+  fetch(dev->uniq.ptr, n * 8, [&](const uint8_t* p, size_t b) { hm.insert(hm.end(), (const uint64_t*)p, (const uint64_t*)(p + b)); });
+  if (has_abunds) {
+    abunds.clear(); abunds.reserve(n);
     if (dev->has_counts) {
-      HIP_CHECK(hipMemcpyAsync(abunds.data(), dev->counts.ptr, n * 8, hipMemcpyDeviceToHost, s));
+      fetch(dev->counts.ptr, n * 8, [&](const uint8_t* p, size_t b) { abunds.insert(abunds.end(), (const uint64_t*)p, (const uint64_t*)(p + b)); });
     } else {
-      st.resize(n);
-      HIP_CHECK(hipMemcpyAsync(st.data(), dev->starts.ptr, n * 4, hipMemcpyDeviceToHost, s));
+      // run starts -> abundances, piece by piece (the end of a piece's last run is the next piece's first start)
+      bool have = false;
+      uint32_t last = 0;
+      fetch(dev->starts.ptr, n * 4, [&](const uint8_t* p, size_t b) {
+        const uint32_t* st = (const uint32_t*)p;
+        const size_t k = b / 4;
+        for (size_t i = 0; i < k; i++) {
+          if (have) abunds.push_back((uint64_t)(st[i] - last));
+          last = st[i]; have = true;
+        }
+      });
+      if (have) abunds.push_back((uint64_t)((uint32_t)dev->total - last));
     }
   }
-  HIP_CHECK(hipStreamSynchronize(s));
-  if (has_abunds && !dev->has_counts)
-    for (size_t k = 0; k < n; k++) abunds[k] = (k + 1 < n ? st[k + 1] : (uint32_t)dev->total) - st[k];
   // the device copy stays on as the mirror of the host vector: a compare right after needs no upload
   auto m = std::make_shared<DeviceMirror>();
   std::swap(m->ptr, dev->uniq.ptr);
