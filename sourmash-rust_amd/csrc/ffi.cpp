@@ -796,7 +796,10 @@ int smh_sketch_absorb_dev(KmerMinHash* ptr, const uint64_t* mins_dev, const uint
 }
 
 // ---- SmhCollection: the dictionary of one collection (all-vs-all, shareable among ranks) ----
-struct SmhCollection { smh::CollectionDict* d = nullptr; };
+struct SmhCollection {
+  smh::CollectionDict* d = nullptr;
+  ~SmhCollection() { if (d) smh::collection_free(d); }
+};
 
 SmhCollection* smh_collection_begin(const uint64_t* hashes_dev, const uint64_t* offsets, uint32_t n, uint32_t world, uint32_t rank,
                                     void* stream) {
@@ -820,7 +823,6 @@ void smh_collection_free(SmhCollection* c) {
   (void)pad_code([&] {
     auto& dev = smh::Device::get();
     std::lock_guard<std::recursive_mutex> lock(dev.mutex());
-    smh::collection_free(c->d);
     delete c;
   });
 }
