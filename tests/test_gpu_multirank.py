@@ -37,6 +37,11 @@ def test_bench_two_ranks_sharing_the_gpu(pkg):
     c = d["compare"]
     assert c["n_signatures"] == 601 and c["self_jaccard_is_1"] is True   # 601: the last row block is short
     assert d["cpu_baseline"] is None                                      # reported at N=1 only
+    # the ranks' partial sketches united on the device, timed on its own (never part of `value`)
+    u = d["union_across_ranks"]
+    assert u["parts"] == 2 and u["hashes"] > d["config"]["retained_hashes"] and u["union_ms"] > 0
+    assert "strong" in c["scaling"] and "used" in c["symmetry"]
+    assert set(c["families"]["rank0_phase_ms"]) >= {"all_gather_signatures", "dictionary_slice", "all_gather_shares", "compare", "exchange_mirrors"}
 
 
 def test_bench_gpus_2_with_no_launcher_around_it(pkg):
