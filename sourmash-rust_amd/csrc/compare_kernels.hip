@@ -824,20 +824,31 @@ __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict
   org[t] = t;
   node[t] = lo;
 }
-// world == 1: the one slice is the collection itself
-__global__ __launch_bounds__(256) void k_whole_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
-                                                      uint32_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ org,
-                                                      uint32_t* __restrict__ node) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= t
+// world == 1: the one slice is the collection itself, in its own order (the sort reads it in place and numbers it); what is
+// left to make is node[t] = the sketch of element t.  A lane takes 8 consecutive elements: one search, then a walk.
+__global__ __launch_bounds__(256) void k_whole_nodes(const uint64_t* __restrict__ off, uint32_t nsk, uint32_t n, uint32_t* __restrict__ node) {
+  const uint32_t t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
+  if (t0 >= n) return;
+  uint32_t lo = 0, hi = nsk;   // last s with off[s] <= t0
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= t) lo = mid; else hi = mid;
+    if (off[mid] <= t0) lo = mid; else hi = mid;
   }
-  keys[t] = hashes[t];
-  org[t] = t;
-  node[t] = lo;
+  uint64_t next = off[lo + 1];
+  const uint32_t t1 = min(t0 + 8u, n);
+  uint32_t v[8];
+#pragma unroll
+  for (uint32_t j = 0; j < 8; j++) {
+    const uint32_t t = t0 + j;
+    while (t < t1 && (uint64_t)t >= next) { lo++; next = off[lo + 1]; }     // (empty sketches are stepped over)
+    v[j] = lo;
+  }
+  if (t1 - t0 == 8) {
+    *reinterpret_cast<uint4*>(node + t0) = make_uint4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<uint4*>(node + t0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+  } else {
+    for (uint32_t j = 0; j < t1 - t0; j++) node[t0 + j] = v[j];
+  }
 }
 // What an owner publishes about its slice.  The share is [SliceHeader][roots: nsk u32][hbound: Rg u64][ranks: nmax u32].
 struct SliceHeader {
@@ -1444,16 +1455,19 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   uint64_t* sk = T.keys0.as<uint64_t>();
   uint32_t* so = T.org0.as<uint32_t>();
   if (nm) {
-    if (G == 1)
-      hipLaunchKernelGGL(k_whole_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, nm, T.keys0.as<uint64_t>(),
-                         T.org0.as<uint32_t>(), T.node.as<uint32_t>());
-    else
+    // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
+    int cur;
+    if (G == 1) {
+      hipLaunchKernelGGL(k_whole_nodes, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, off, n, nm, T.node.as<uint32_t>());
+      cur = radix_sort_u64_place(D.hashes, T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
+                                 dev.scratch, s, 0xffu);
+    } else {
       hipLaunchKernelGGL(k_slice_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
                          D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.org0.as<uint32_t>(),
                          T.node.as<uint32_t>());
-    // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
-    const int cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
-                                       dev.scratch, s, 0xffu);
+      cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
+                               dev.scratch, s, 0xffu);
+    }
     if (cur) { sk = T.keys1.as<uint64_t>(); so = T.org1.as<uint32_t>(); }
   }
   run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr, &rs->nruns,

@@ -117,6 +117,10 @@ void small_fold_async(const uint64_t* keys, const unsigned long long* count_dev,
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
                        hipStream_t s, uint32_t pass_mask = 0);
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask);
+// keys[0 .. n) (read only) sorted into k0 or k1 (the return value says which), v0 / v1 alongside = where every sorted key
+// was in `keys`: the first pass reads `keys` and numbers them itself -- no copy of the keys, no index array.  pass_mask != 0.
+int radix_sort_u64_place(const uint64_t* keys, uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
+                         hipStream_t s, uint32_t pass_mask);
 // run_length_encode_u64 without its read-back: *nruns_dev (device) receives the number of runs;
 // skip (device, nullable): non-zero = the launches do nothing
 void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,

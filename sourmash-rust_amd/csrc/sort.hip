@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
       if (idx < n) {
         const uint32_t lp = lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu);
         if (VB == 8) stage[lp] = static_cast<const uint64_t*>(vin_)[idx];
-        if (VB == 4) reinterpret_cast<uint32_t*>(stage)[lp] = static_cast<const uint32_t*>(vin_)[idx];
+        if (VB == 4) reinterpret_cast<uint32_t*>(stage)[lp] = vin_ ? static_cast<const uint32_t*>(vin_)[idx] : (uint32_t)idx;   // (no payload array: the key's place)
       }
     }
     __syncthreads();
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __res
   for (uint32_t i = t; i < n; i += kBsThreads) {
     kout[i] = L.sk[i];
     if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[L.si[i]];
-    if (VB == 4) static_cast<uint32_t*>(vout_)[i] = static_cast<const uint32_t*>(vin_)[L.si[i]];
+    if (VB == 4) static_cast<uint32_t*>(vout_)[i] = vin_ ? static_cast<const uint32_t*>(vin_)[L.si[i]] : (uint32_t)L.si[i];
   }
 }
 
@@ -612,12 +612,23 @@ static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanCh
 
 // pass_mask != 0: run exactly the byte passes whose bit is set (the caller knows which bytes of the
 // keys can differ) -- no digit-histogram read-back, so no host synchronisation inside the sort.
+// first_in (nullable; needs pass_mask): the keys are read from there by the first pass that runs, k0 is only a work buffer, and
+// the payload (vbytes 4) starts as every key's index in first_in -- the caller's array stays untouched and no index array is made.
 static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
-                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0) {
-  if (n < 2) return 0;
+                           DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0,
+                           const uint64_t* first_in = nullptr) {
+  if (first_in && (!pass_mask || vbytes != 4 || !v0)) throw_internal("radix_sort: first_in needs a pass mask and a 32-bit payload");
+  if (n < 2) {
+    if (first_in && n == 1) {
+      HIP_CHECK(hipMemcpyAsync(k0, first_in, 8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemsetAsync(v0, 0, 4, s));
+    }
+    return 0;
+  }
   if (n >= (1ull << 31)) throw_internal("radix_sort_u64: more than 2^31 keys in one call");
   if (n <= (size_t)kBlockSortMax && first_pass == 0 && last_pass == 8) {
-    if (v0 && vbytes == 8) hipLaunchKernelGGL(k_block_sort<8>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, v0, v1, (uint32_t)n);
+    if (first_in) hipLaunchKernelGGL(k_block_sort<4>, dim3(1), dim3(kBsThreads), 0, s, first_in, k1, nullptr, v1, (uint32_t)n);
+    else if (v0 && vbytes == 8) hipLaunchKernelGGL(k_block_sort<8>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, v0, v1, (uint32_t)n);
     else if (v0 && vbytes == 4) hipLaunchKernelGGL(k_block_sort<4>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, v0, v1, (uint32_t)n);
     else hipLaunchKernelGGL(k_block_sort<0>, dim3(1), dim3(kBsThreads), 0, s, k0, k1, nullptr, nullptr, (uint32_t)n);
     HIP_CHECK(hipGetLastError());
@@ -646,6 +657,7 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   int cur = 0;
   uint64_t* kk[2] = {k0, k1};
   void* vv[2] = {v0, v1};
+  const uint64_t* src_first = first_in;
   for (int p = first_pass; p < last_pass; p++) {
     bool trivial = false;
     if (pass_mask) trivial = !((pass_mask >> p) & 1u);
@@ -653,6 +665,22 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
       for (int d = 0; d < 256; d++)
         if (hh[p * 256 + d] == n) { trivial = true; break; }
     if (trivial) continue;  // every key has the same digit: the pass is the identity
+    if (src_first) {        // the first pass that runs reads the caller's keys and numbers them
+      hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, src_first, n, 8 * p, blockhist, nblocks);
+      const uint32_t* dt = nullptr;
+      if (nblocks <= kRowScanMax) {
+        hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, blockhist, nblocks, scan_tmp);
+        dt = scan_tmp;
+      } else {
+        exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, scan_tmp, s);
+      }
+      hipLaunchKernelGGL(k_radix_scatter<4>, dim3(nblocks), dim3(kSortThreads), 0, s, src_first, kk[cur ^ 1], nullptr, vv[cur ^ 1], n, 8 * p,
+                         blockhist, nblocks, dt);
+      HIP_CHECK(hipGetLastError());
+      src_first = nullptr;
+      cur ^= 1;
+      continue;
+    }
     hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
                        blockhist, nblocks);
     const uint32_t* dtot = nullptr;
@@ -674,6 +702,7 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
     HIP_CHECK(hipGetLastError());
     cur ^= 1;
   }
+  if (src_first) throw_internal("radix_sort: first_in with a pass mask that runs no pass");
   return cur;
 }
 
@@ -694,6 +723,10 @@ int radix_sort_u64(uint64_t* k0, uint64_t* k1, uint64_t* v0, uint64_t* v1, size_
 int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
                        hipStream_t s, uint32_t pass_mask) {
   return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask);
+}
+int radix_sort_u64_place(const uint64_t* keys, uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
+                         hipStream_t s, uint32_t pass_mask) {
+  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask, keys);
 }
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask) {
   return radix_sort_impl(k0, k1, nullptr, nullptr, 0, n, scratch, s, 0, 8, pass_mask);

@@ -44,6 +44,8 @@ for world in worlds:
             _, ms = timed(lambda: c.finish(gathered)); ph["assemble"].append(ms)
             own = MX.OWN_CIRCULAR if world > 1 else MX.OWN_TRIANGLE
             o, ms = timed(lambda: c.compare(blocks[r][0], blocks[r][1], num, want=("jaccard",), ownership=own)); ph["compare"].append(ms)
+            if r == 0:
+                st0 = MX.last_stats()
             outs.append(o["jaccard"])
         if world > 1:
             sends = []
@@ -64,4 +66,5 @@ for world in worlds:
     tot, ph, share, sent = best
     print("N=%d %s world=%d: compute critical path %.2f ms | " % (n, kind, world, tot) +
           " ".join("%s max %.2f avg %.2f" % (k, v[0], v[1]) for k, v in ph.items()) +
-          " | share %.1f MB per rank, mirrored blocks sent by rank 0: %.1f MB" % (share / 1e6, sent / 1e6), flush=True)
+          " | share %.1f MB per rank, mirrored blocks sent by rank 0: %.1f MB | rank 0: %s, %d of %d tiles of %d pairs" %
+          (share / 1e6, sent / 1e6, st0["route"], st0["tiles_visited"], st0["tiles_total"], st0["pairs_per_tile"]), flush=True)
