@@ -398,6 +398,7 @@ struct PlanState {
   uint32_t nwork;                // work items of the per-component kernel
   uint32_t count16;              // tiles that hold sharing pairs at the 16-row geometry
   uint32_t next_tile[8];         // tiled: tiles handed out so far, per XCD stretch of the list
+  uint32_t pf;                   // tiled: the software-pipelined kernel walks the tiles (k_compare_tiled_pf), not the plain one
 };
 // What the owner of one slice of hash space finds in it (see "collection dictionary" below)
 struct RangeState {
@@ -425,6 +426,69 @@ struct TiledArgs {
   CompareOut out;
 };
 
+// One row against the 64 staged columns (lane = column) over one staged stretch of rank space: A = the row's la ranks +
+// sentinels, Bl = this lane's column (elements kTB dwords apart, lb of them + sentinels), n = the row's cut (bottom-n of the
+// union), ucount / common / cc = the pair's running union size, matches inside the cut, all matches.
+template <bool WantCC>
+__device__ __forceinline__ void tiled_walk_row(const uint32_t* A, const uint32_t* Bl, uint32_t la, uint32_t lb, uint32_t n,
+                                               uint32_t& ucount, uint32_t& common, uint32_t& cc) {
+  if (!WantCC && ucount >= n) { ucount += la + lb; return; }  // past the cut: nothing can count
+  const uint32_t u0 = ucount;
+  // No lane's cut can fall inside this range (even with no match at all the union stays within n), or every lane is
+  // past it already (count_common wanted): only the NUMBER of matches of the range matters, and the walk needs no
+  // counters at all -- a step advances A, B or both, so A's and B's final positions say how many steps were matches.
+  // Addresses advance by a constant per step (folded into the reads' immediate offsets) minus what the compares
+  // take back, all in two-operand full-rate instructions; the end (both at a sentinel) is looked for every 4 steps.
+  uint32_t sa = (uint32_t)(uintptr_t)A, sb = (uint32_t)(uintptr_t)Bl;   // LDS byte addresses
+  const uint32_t sa0 = sa;
+  uint32_t av = *(LdsU32)(uintptr_t)sa, bv = *(LdsU32)(uintptr_t)sb;
+  uint32_t iters = 0;
+  if (__all((u0 + la + lb <= n) || (WantCC && u0 >= n))) {
+    while ((av & bv) != kSentA) {
+#pragma unroll
+      for (uint32_t j = 1; j <= 4; j++) {
+        const uint32_t g = (bv - av) >> 31;      // 1: bv < av, only B's element is consumed (ranks are < 2^31)
+        const uint32_t l = (av - bv) >> 31;      // 1: av < bv, only A's
+        sa -= g << 2;
+        sb -= l << 8;
+        av = *(LdsU32)(uintptr_t)(sa + 4u * j);
+        bv = *(LdsU32)(uintptr_t)(sb + (4u * kTB) * j);
+      }
+      sa += 16u; sb += 16u * kTB;
+      iters += 1;
+    }
+    // A fell behind the unconditional 4 bytes per step once for every B-only step; B's elements are B-only or matches
+    const uint32_t m = lb - ((sa0 + 16u * iters - sa) >> 2);
+    ucount = u0 + la + lb - m;
+    if (u0 + la + lb <= n) common += m;
+    if (WantCC) cc += m;
+    return;
+  }
+  // The cut may fall inside this range for some lane: the same walk with the matches counted while the union is
+  // short of n (r = u - n is negative until then), still in two-operand arithmetic on VGPRs only.
+  int32_t r = (int32_t)(u0 - n);
+  uint32_t cmv = 0, ccv = 0;
+  while ((av & bv) != kSentA) {
+#pragma unroll
+    for (uint32_t j = 1; j <= 4; j++) {
+      const uint32_t t1 = bv - av, t2 = av - bv;
+      const uint32_t eq = ((t1 | t2) >> 31) ^ 1u;     // neither is smaller
+      cmv += eq & ((uint32_t)r >> 31);
+      if (WantCC) ccv += eq;
+      r += 1;
+      sa -= (t1 >> 31) << 2;
+      sb -= (t2 >> 31) << 8;
+      av = *(LdsU32)(uintptr_t)(sa + 4u * j);
+      bv = *(LdsU32)(uintptr_t)(sb + (4u * kTB) * j);
+    }
+    sa += 16u; sb += 16u * kTB;
+  }
+  // a lane that did not reach its cut has counted every match; one that did only needs ucount >= n from here on
+  ucount = u0 + la + lb - (WantCC ? ccv : cmv);
+  common += cmv;
+  if (WantCC) cc += ccv;
+}
+
 // RPW rows per wave, WPB waves per workgroup (they share the staged column tile), MINW = waves per
 // SIMD the register allocator must leave room for
 template <bool WantCC, int RPW, int WPB, int MINW>
@@ -446,7 +510,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // the plan picks ONE of the launched instantiations (rows per wave) -- or none of them
-  if (a.st->skip_tiled || a.st->rpw != (uint32_t)RPW) return;
+  if (a.st->skip_tiled || a.st->rpw != (uint32_t)RPW || a.st->pf) return;
   const uint32_t ntiles = min(a.st->ntiles, a.tiles_cap);
   // A persistent grid pulls tiles off the list (tile times differ: a static split left the chip
   // half idle at the end).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
@@ -568,64 +632,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; q++) {
         const int t = w * kRowsPerWave + q;
-        const uint32_t la = lenA[t];
-        const uint32_t n = nrowL[t];
-        if (!WantCC && ucount[q] >= n) { ucount[q] += la + lb; continue; }  // past the cut: nothing can count
-        const uint32_t* A = poolA + offA[t];
-        const uint32_t u0 = ucount[q];
-        // No lane's cut can fall inside this range (even with no match at all the union stays within n), or every lane is
-        // past it already (count_common wanted): only the NUMBER of matches of the range matters, and the walk needs no
-        // counters at all -- a step advances A, B or both, so A's and B's final positions say how many steps were matches.
-        // Addresses advance by a constant per step (folded into the reads' immediate offsets) minus what the compares
-        // take back, all in two-operand full-rate instructions; the end (both at a sentinel) is looked for every 4 steps.
-        uint32_t sa = (uint32_t)(uintptr_t)A, sb = (uint32_t)(uintptr_t)(Bt + lane);   // LDS byte addresses
-        const uint32_t sa0 = sa;
-        uint32_t av = *(LdsU32)(uintptr_t)sa, bv = *(LdsU32)(uintptr_t)sb;
-        uint32_t iters = 0;
-        if (__all((u0 + la + lb <= n) || (WantCC && u0 >= n))) {
-          while ((av & bv) != kSentA) {
-#pragma unroll
-            for (uint32_t j = 1; j <= 4; j++) {
-              const uint32_t g = (bv - av) >> 31;      // 1: bv < av, only B's element is consumed (ranks are < 2^31)
-              const uint32_t l = (av - bv) >> 31;      // 1: av < bv, only A's
-              sa -= g << 2;
-              sb -= l << 8;
-              av = *(LdsU32)(uintptr_t)(sa + 4u * j);
-              bv = *(LdsU32)(uintptr_t)(sb + (4u * kTB) * j);
-            }
-            sa += 16u; sb += 16u * kTB;
-            iters += 1;
-          }
-          // A fell behind the unconditional 4 bytes per step once for every B-only step; B's elements are B-only or matches
-          const uint32_t m = lb - ((sa0 + 16u * iters - sa) >> 2);
-          ucount[q] = u0 + la + lb - m;
-          if (u0 + la + lb <= n) common[q] += m;
-          if (WantCC) cc[q] += m;
-          continue;
-        }
-        // The cut may fall inside this range for some lane: the same walk with the matches counted while the union is
-        // short of n (r = u - n is negative until then), still in two-operand arithmetic on VGPRs only.
-        int32_t r = (int32_t)(u0 - n);
-        uint32_t cmv = 0, ccv = 0;
-        while ((av & bv) != kSentA) {
-#pragma unroll
-          for (uint32_t j = 1; j <= 4; j++) {
-            const uint32_t t1 = bv - av, t2 = av - bv;
-            const uint32_t eq = ((t1 | t2) >> 31) ^ 1u;     // neither is smaller
-            cmv += eq & ((uint32_t)r >> 31);
-            if (WantCC) ccv += eq;
-            r += 1;
-            sa -= (t1 >> 31) << 2;
-            sb -= (t2 >> 31) << 8;
-            av = *(LdsU32)(uintptr_t)(sa + 4u * j);
-            bv = *(LdsU32)(uintptr_t)(sb + (4u * kTB) * j);
-          }
-          sa += 16u; sb += 16u * kTB;
-        }
-        // a lane that did not reach its cut has counted every match; one that did only needs ucount >= n from here on
-        ucount[q] = u0 + la + lb - (WantCC ? ccv : cmv);
-        common[q] += cmv;
-        if (WantCC) cc[q] += ccv;
+        tiled_walk_row<WantCC>(poolA + offA[t], Bt + lane, lenA[t], lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
       }
     } else {
       // ---- rare: this range does not fit LDS for this tile; merge from global memory
@@ -685,6 +692,306 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
       if (gj >= a.scope.mir_lo && gj < a.scope.mir_hi && gi != gj) {
         // the column is one of the local rows and there is one num: the walk is symmetric in its two
         // inputs, so this is also pair (col, row) -- tiles that hold no owned pair are not launched
+        const size_t pid2 = (size_t)(gj - a.scope.mir_lo) * a.ncols + (gi - a.scope.col_base);
+        if (a.out.common) a.out.common[pid2] = common[q];
+        if (a.out.size) a.out.size[pid2] = size;
+        if (a.out.jaccard) a.out.jaccard[pid2] = (double)common[q] / (double)(size > 1 ? size : 1);
+        if (WantCC) {
+          if (a.out.count_common) a.out.count_common[pid2] = cc[q];
+          if (a.out.containment) {
+            const uint64_t lb_full = a.coff[col + 1] - a.coff[col];
+            a.out.containment[pid2] = (double)cc[q] / (double)lb_full;
+          }
+        }
+      }
+    }
+  }
+  }   // tiles of this workgroup
+}
+
+// ---- the same tile walk, software-pipelined: while a stretch of rank space is walked, the next ones are on their way ----
+// k_compare_tiled spends a third of a workgroup's time in three barriers and two dependent global loads per stretch (where the
+// sketches cross the range boundaries, then their ranks) that nothing in the workgroup overlaps with the walk.  Here, while
+// stretch i is walked: the ranks of stretch i+1 travel straight into a second LDS stage (global_load_lds: no registers,
+// asynchronous), two waves build the table of stretch i+2 from boundary crossings that were prefetched the same way, and
+// the crossings of stretch i+3 are requested.  ONE barrier per stretch (the "every pair past its cut?" vote), preceded by the
+// wait for what was requested.  Twice the stage, three tables: a workgroup is 8 waves sharing one column stage (4 workgroups
+// = 32 waves per CU, as before).  A stretch that does not fit the stage at the span it tried (the span is grown
+// speculatively, see k_compare_tiled) is rebuilt with plain loads and halved spans before its ranks are requested.
+constexpr uint32_t kPfTab = 5 * 64;                  // lenA, offA, endA, lenB, endB
+constexpr uint32_t kPfHeader = 16 + 3 * 64 + 128 + 2 * 128 + 3 * kPfTab;
+template <bool WantCC, int RPW, int WPB, int MINW>
+__global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a) {
+  constexpr int kRowsPerWave = RPW;
+  constexpr int kTR = WPB * RPW;   // rows per tile (<= 64)
+  constexpr uint32_t kNone = 0xffffffffu;
+  extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+  uint32_t* ctl = sm;              // [2 s], [2 s + 1]: table slot s does not fit (rows, columns); [8] the tile taken
+  uint32_t* nrowL = sm + 16;       // [64] truncation length of each row (0xffffffff = none, 0 = no row)
+  uint32_t* rowid = sm + 80;       // [64]
+  uint32_t* colid = sm + 144;      // [64]
+  uint32_t* goff = sm + 208;       // [128] where each row (0..63) / column (64..127) starts in the rank array
+  uint32_t* raw = sm + 336;        // [2][128] prefetched boundary crossings (rows, columns), alternating
+  uint32_t* tab = sm + 592;        // three tables
+  uint32_t* stage = sm + kPfHeader;   // two stages
+  const uint32_t stage_dw = a.capA + a.capBt;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the plan picks a tile height; this instantiation serves one of them -- or none
+  if (a.st->skip_tiled || a.st->rpw * 4u != (uint32_t)kTR || !a.st->pf) return;
+  const uint32_t ntiles = min(a.st->ntiles, a.tiles_cap);
+  const uint32_t nstretch = (a.use_xcd && ntiles >= 64) ? 8u : 1u;
+  const uint32_t chunk = (ntiles + nstretch - 1) / nstretch;
+  const uint32_t R = a.R;
+  uint32_t steal = 0;     // (thread 0) stretches given up so far
+
+  // table slot s for ranges [r, r + mt) (waves 0 and 1): lengths, LDS offsets, where the segments end.  They start where the
+  // table in slot p ended (first: read), and end at prefetched crossings (rawp) or at ones read here.
+  auto build_table = [&](uint32_t s, uint32_t p, uint32_t r, uint32_t mt, bool first, const uint32_t* rawp) {
+    uint32_t* T = tab + s * kPfTab;
+    const uint32_t* P = tab + p * kPfTab;
+    if (tid < 64) {
+      const uint32_t row = rowid[tid];
+      uint32_t lo = 0, hi = 0;
+      if (row != kNone) {
+        lo = first ? a.rpart[(size_t)row * (R + 1) + r] : P[128 + tid];
+        hi = rawp ? rawp[tid] : a.rpart[(size_t)row * (R + 1) + r + mt];
+      }
+      T[tid] = hi - lo; T[128 + tid] = hi;
+      uint32_t v = tid < kTR ? hi - lo + kPad : 0, incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      T[64 + tid] = incl - v;
+      const uint32_t totA = __shfl(incl, 63);
+      if (tid == 0) ctl[2 * s] = totA > a.capA ? 1u : 0u;
+    } else if (tid < 128) {
+      const uint32_t c = colid[tid - 64];
+      uint32_t lo = 0, hi = 0;
+      if (c != kNone) {
+        lo = first ? a.cpart[(size_t)c * (R + 1) + r] : P[256 + tid - 64];
+        hi = rawp ? rawp[tid] : a.cpart[(size_t)c * (R + 1) + r + mt];
+      }
+      T[192 + tid - 64] = hi - lo; T[256 + tid - 64] = hi;
+      uint32_t mx = hi - lo;
+      for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
+      if (tid == 64) ctl[2 * s + 1] = ((mx + kPad) * kTB > a.capBt) ? 1u : 0u;
+    }
+  };
+  // the ranks of table slot s's segments -> stage slot g, asynchronously (rows packed: wave w its rows; columns transposed:
+  // lane = column); the sentinels behind them with ordinary LDS stores
+  auto issue_stage = [&](uint32_t s, uint32_t g) {
+    const uint32_t* T = tab + s * kPfTab;
+    uint32_t* pA = stage + g * stage_dw;
+    uint32_t* pB = pA + a.capA;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+      const int t = w * kRowsPerWave + q;
+      const uint32_t la = T[t], oa = T[64 + t];
+      const uint32_t* src = a.rrank + goff[t] + (T[128 + t] - la);
+      for (uint32_t e0 = 0; e0 < la; e0 += 64)
+        if (e0 + lane < la) __builtin_amdgcn_global_load_lds(src + e0 + lane, pA + oa + e0, 4, 0, 0);
+      if (lane < (int)kPad) pA[oa + la + lane] = kSentA;
+    }
+    const uint32_t lb = T[192 + lane];
+    const uint32_t* src = a.crank + goff[64 + lane] + (T[256 + lane] - lb);
+    uint32_t lbmax = lb;
+    for (int off = 32; off; off >>= 1) lbmax = max(lbmax, (uint32_t)__shfl_xor(lbmax, off));
+    for (uint32_t e = w; e < lbmax + kPad; e += WPB) {
+      if (e < lb) __builtin_amdgcn_global_load_lds(src + e, pB + e * kTB, 4, 0, 0);
+      else if (e < lb + kPad) pB[e * kTB + lane] = kSent;
+    }
+  };
+  // where the rows and columns cross boundary `at`, asynchronously into rawp[] (waves 0 and 1)
+  auto issue_raw = [&](uint32_t at, uint32_t* rawp) {
+    if (tid < 64) {
+      const uint32_t row = rowid[tid];
+      if (row != kNone) __builtin_amdgcn_global_load_lds(a.rpart + (size_t)row * (R + 1) + at, rawp, 4, 0, 0);
+    } else if (tid < 128) {
+      const uint32_t c = colid[tid - 64];
+      if (c != kNone) __builtin_amdgcn_global_load_lds(a.cpart + (size_t)c * (R + 1) + at, rawp + 64, 4, 0, 0);
+    }
+  };
+  // the span of the stretch at r after one of span m: doubled while the segments have been fitting (see k_compare_tiled)
+  auto next_span = [&](uint32_t m, uint32_t& cool, uint32_t r) {
+    uint32_t mt = m;
+    if (cool == 0 && m < 64) mt = m * 2; else if (cool) cool--;
+    if (mt > R - r) mt = R - r;
+    return mt;
+  };
+  auto flags = [&](uint32_t s) { return (ctl[2 * s] | ctl[2 * s + 1]) != 0; };
+  // table slot s (segments start where slot p's ended, or are read when first) with plain loads, the span halved until it
+  // fits or is one range; workgroup-wide, ends after a barrier.  Returns "does not fit".
+  auto settle_table = [&](uint32_t s, uint32_t p, uint32_t r, uint32_t& mt, bool first, uint32_t& cool) {
+    while (true) {
+      build_table(s, p, r, mt, first, nullptr);
+      __syncthreads();
+      const bool o = flags(s);
+      if (!o || mt == 1) return o;
+      __syncthreads();           // everyone has read the flags before the table is rebuilt
+      mt >>= 1; cool = 16;
+    }
+  };
+
+  while (true) {
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // (vmcnt 0: nothing of the previous tile is still on its way into LDS)
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t t = kNone;
+    while (steal < nstretch) {
+      const uint32_t x = ((blockIdx.x & 7u) + steal) % nstretch;
+      const uint32_t lo = x * chunk, hi = min(lo + chunk, ntiles);
+      if (lo < hi) {
+        const uint32_t k = atomicAdd(&a.st->next_tile[x], 1u);
+        if (lo + k < hi) { t = lo + k; break; }
+      }
+      steal++;
+    }
+    ctl[8] = t;
+  }
+  __syncthreads();
+  const uint32_t tix = ctl[8];
+  if (tix == kNone) break;
+  const uint32_t bi = a.tiles[2 * tix], bj = a.tiles[2 * tix + 1];
+  if (tid < 64) {
+    const uint32_t rs = bi * kTR + tid, cs = bj * kTB + tid;
+    const uint32_t row = (tid < kTR && rs < a.nrows) ? (uint32_t)a.rkey[rs] : kNone;
+    const uint32_t c = cs < a.ncols ? (uint32_t)a.ckey[cs] : kNone;
+    rowid[tid] = row; colid[tid] = c;
+    uint32_t n = 0;
+    if (row != kNone) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : kNone; }
+    nrowL[tid] = n;
+    goff[tid] = row != kNone ? (uint32_t)a.roff[row] : 0u;
+    goff[64 + tid] = c != kNone ? (uint32_t)a.coff[c] : 0u;
+  }
+  __syncthreads();
+  const uint32_t col = colid[lane];
+  const bool col_ok = col != kNone;
+
+  uint32_t ucount[kRowsPerWave], common[kRowsPerWave], cc[WantCC ? kRowsPerWave : 1];
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; q++) {
+    ucount[q] = 0; common[q] = 0;
+    if (WantCC) cc[q] = 0;
+  }
+
+  // ---- stretches 0 and 1 with plain loads; the ranks of stretch 0 and the crossings at the end of stretch 2 requested
+  // (s0, s1, s2: table slots of the stretch being walked, the next, the one after; stage slot = stretch number & 1)
+  uint32_t cool = 0, it = 0;
+  uint32_t r0 = 0, mt0 = next_span(1, cool, 0);
+  bool ovf0 = settle_table(0, 0, r0, mt0, true, cool);
+  if (!ovf0) issue_stage(0, 0);
+  uint32_t r1 = r0 + mt0, mt1 = 0;
+  bool ovf1 = false;
+  if (r1 < R) {
+    mt1 = next_span(mt0, cool, r1);
+    ovf1 = settle_table(1, 0, r1, mt1, false, cool);
+  }
+  uint32_t raw_at = 0, raw_slot = 0;   // the boundary whose crossings are (arriving) in raw[raw_slot] (0: none asked for yet)
+  if (mt1 && r1 + mt1 < R) {
+    uint32_t c2 = cool;
+    raw_at = r1 + mt1 + next_span(mt1, c2, r1 + mt1);
+    raw_slot ^= 1u;
+    issue_raw(raw_at, raw + raw_slot * 128);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  __syncthreads();
+  uint32_t s0 = 0, s1 = 1, s2 = 2;
+
+  while (true) {
+    // ---- here: table s0 = stretch `it` (its ranks in stage it & 1, unless ovf0), table s1 = the next one (mt1 != 0), the
+    // crossings at raw_at are in raw[raw_slot]; everything visible to everybody
+    if (mt1 && !ovf1) issue_stage(s1, (it & 1u) ^ 1u);
+    uint32_t r2 = r1 + mt1, mt2 = 0;
+    if (mt1 && r2 < R) {
+      mt2 = next_span(mt1, cool, r2);
+      build_table(s2, s1, r2, mt2, false, raw_at == r2 + mt2 ? raw + raw_slot * 128 : nullptr);
+      if (r2 + mt2 < R) {
+        uint32_t c2 = cool;
+        raw_at = r2 + mt2 + next_span(mt2, c2, r2 + mt2);     // (if table s2 turns out not to fit, this is not the boundary asked for later)
+        raw_slot ^= 1u;                                       // (not the slot just read; the other one was last read an iteration ago)
+        issue_raw(raw_at, raw + raw_slot * 128);
+      }
+    }
+    // ---- walk stretch `it`
+    const uint32_t* T = tab + s0 * kPfTab;
+    if (!ovf0) {
+      const uint32_t* pA = stage + (it & 1u) * stage_dw;
+      const uint32_t* pB = pA + a.capA;
+      const uint32_t lb = T[192 + lane];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const int t = w * kRowsPerWave + q;
+        tiled_walk_row<WantCC>(pA + T[64 + t], pB + lane, T[t], lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
+      }
+    } else {
+      // ---- rare: one range that does not fit LDS for this tile; merge from global memory
+      if (tid == 0) atomicAdd(a.ovf_steps, 1ull);
+      const uint32_t lb = T[192 + lane];
+      const uint32_t* B = a.crank + goff[64 + lane] + (T[256 + lane] - lb);
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const int t = w * kRowsPerWave + q;
+        const uint32_t la = T[t];
+        const uint32_t* A = a.rrank + goff[t] + (T[128 + t] - la);
+        uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
+        const uint32_t n = nrowL[t];
+        while (pa < la && pb < lb) {
+          const uint32_t av = A[pa], bv = B[pb];
+          const bool eq = av == bv;
+          cm += (eq && u < n) ? 1u : 0u;
+          if (WantCC) c2 += eq ? 1u : 0u;
+          u += 1;
+          pa += av <= bv ? 1u : 0u;
+          pb += bv <= av ? 1u : 0u;
+        }
+        u += (la - pa) + (lb - pb);
+        ucount[q] = u; common[q] = cm;
+        if (WantCC) cc[q] += c2;
+      }
+    }
+    // ---- all pairs of the tile past their cut: the remaining ranges cannot change common or size
+    bool done = !WantCC;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) done = done && (ucount[q] >= nrowL[w * kRowsPerWave + q]);
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // what this wave requested has arrived
+    if (__syncthreads_and(done || !col_ok)) break;
+    if (!mt1) break;
+    // ---- the next stretch becomes the current one
+    bool ovf2 = mt2 ? flags(s2) : false;
+    if (ovf2 && mt2 > 1) {
+      // it did not fit at the span it tried: halve it with plain loads until it does (a single range that does not fit stays
+      // as it is: it is merged from global memory)
+      __syncthreads();
+      mt2 >>= 1; cool = 16;
+      ovf2 = settle_table(s2, s1, r2, mt2, false, cool);
+    }
+    it++;
+    r0 = r1; mt0 = mt1; ovf0 = ovf1;
+    r1 = r2; mt1 = mt2; ovf1 = ovf2;
+    const uint32_t sx = s0; s0 = s1; s1 = s2; s2 = sx;
+  }
+
+#pragma unroll
+  for (int q = 0; q < kRowsPerWave; q++) {
+    const uint32_t row = rowid[w * kRowsPerWave + q];
+    if (row != kNone && col_ok) {
+      const size_t pid = (size_t)row * a.ncols + col;
+      const uint32_t nq = nrowL[w * kRowsPerWave + q];
+      const uint64_t size = ucount[q] < nq ? ucount[q] : nq;
+      if (a.out.common) a.out.common[pid] = common[q];
+      if (a.out.size) a.out.size[pid] = size;
+      if (a.out.jaccard) a.out.jaccard[pid] = (double)common[q] / (double)(size > 1 ? size : 1);
+      if (WantCC) {
+        if (a.out.count_common) a.out.count_common[pid] = cc[q];
+        if (a.out.containment) {
+          const uint64_t la_full = a.roff[row + 1] - a.roff[row];
+          a.out.containment[pid] = (double)cc[q] / (double)la_full;
+        }
+      }
+      const uint32_t gi = a.scope.row_base + row, gj = a.scope.col_base + col;
+      if (gj >= a.scope.mir_lo && gj < a.scope.mir_hi && gi != gj) {
         const size_t pid2 = (size_t)(gj - a.scope.mir_lo) * a.ncols + (gi - a.scope.col_base);
         if (a.out.common) a.out.common[pid2] = common[q];
         if (a.out.size) a.out.size[pid2] = size;
@@ -1239,17 +1546,25 @@ __global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st
   const uint32_t wsum = (uint32_t)wave_sum64(mine);
   if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&st->count16, wsum);
 }
-// rows per wave (x 4 waves = rows per tile): 16-row tiles amortise the staging best; when few tiles hold sharing pairs,
-// shorter ones keep the chip full (one tile is one latency chain).  Thresholds re-measured with the round-3 walk
-// (profiles/r03_tile_height.txt): 16 rows from a quarter of a chip-filling round of 16-row tiles on, 8 rows from a sixteenth.
-__device__ __host__ inline uint32_t rows_per_wave_for(uint64_t count16, uint32_t fill_tiles) {
-  return 4 * count16 >= fill_tiles ? 4u : (16 * count16 >= fill_tiles ? 2u : 1u);
+// The shape of the tiles and the kernel that walks them, from the number of 16-row tiles that hold sharing pairs
+// (tools/sweep_pf.sh, profiles/r03_tile_shape.txt; one family, every pair walked):
+//   * many tiles (more than ~2.5 rounds of the chip's 2048 workgroup slots): 16 rows, the plain kernel -- four rows per
+//     wave between barriers amortise the per-stretch work best, and eight workgroups per CU hide each other's loads;
+//   * fewer: 16 rows, the pipelined kernel (its loads overlap its own walk: 1500 x 1500 1.34 -> 1.07 ms);
+//   * fewer than ~0.4 rounds: 8 rows, the pipelined kernel -- one tile is one latency chain, shorter tiles keep more of
+//     the chip busy (1000 x 1000 0.85 -> 0.68 ms, 300 x 300 0.58 -> 0.42).
+// rpw x 4 = rows per tile (rpw 1 = 4-row tiles: experiments only).
+struct TileShape { uint32_t rpw, pf; };
+__device__ __host__ inline TileShape tile_shape_for(uint64_t count16, uint32_t fill_tiles) {
+  if (10 * count16 < fill_tiles) return {2u, 1u};
+  if (8 * count16 < 5ull * fill_tiles) return {4u, 1u};
+  return {4u, 0u};
 }
-__global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t fill_tiles, uint32_t* part_built) {
+__global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t forced_pf, uint32_t fill_tiles, uint32_t* part_built) {
   if (!st->skip_tiled) *part_built = 1;   // k_partition ran just before this launch (same stream)
-  uint32_t rpw = forced_rpw;
-  if (!rpw) rpw = rows_per_wave_for(st->count16, fill_tiles);
-  st->rpw = rpw;
+  TileShape sh = {forced_rpw, forced_pf};
+  if (!forced_rpw) sh = tile_shape_for(st->count16, fill_tiles);
+  st->rpw = sh.rpw; st->pf = sh.pf;
 }
 __global__ __launch_bounds__(256) void k_flag_tiles(TileTest t, uint32_t wpb, uint32_t* __restrict__ tiles, uint32_t tiles_cap,
                                                     PlanState* st) {
@@ -1312,6 +1627,7 @@ struct TiledExperiments {
   uint32_t per_range = 24;            // pooled elements per sketch per range
   uint32_t capA = 1024, capB = 48;    // LDS dwords of the row pool; column elements per range
   int rpw = 0, wpb = 4, minw = 8;     // rpw 0 = chosen by the plan
+  bool pf = false;                    // with rpw: the pipelined kernel
   bool xcd = true;
 };
 static const TiledExperiments& tiled_experiments() {
@@ -1324,6 +1640,7 @@ static const TiledExperiments& tiled_experiments() {
       if (sscanf(v, "%d,%d", &ca, &cb) == 2 && ca >= 256 && cb >= 8) { e.capA = (uint32_t)ca; e.capB = (uint32_t)cb; }
     }
     if (const char* v = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(v, "%d,%d,%d", &e.rpw, &e.wpb, &e.minw);
+    if (const char* v = std::getenv("SOURMASH_AMD_CMP_PF")) e.pf = std::atoi(v) != 0;
     if (std::getenv("SOURMASH_AMD_CMP_NO_XCD")) e.xcd = false;
 #endif
     return e;
@@ -1717,10 +2034,12 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     // profiles/r01_compare_small_geometry.txt).  With every tile launched the count is known here.
     const uint32_t fill_tiles = (uint32_t)dev.cu_count() * 32;
     const uint32_t tiles_c = (ncols + kTB - 1) / kTB;
-    uint32_t forced_rpw = ex.rpw > 0 ? (uint32_t)ex.rpw : 0u;
+    // (experiments build: SOURMASH_AMD_CMP_GEO forces the height, SOURMASH_AMD_CMP_PF = 1 the pipelined kernel)
+    uint32_t forced_rpw = ex.rpw > 0 ? (uint32_t)ex.rpw : 0u, forced_pf = ex.pf ? 1u : 0u;
     if (!forced_rpw && tune.visit_all_tiles) {
       const uint64_t all16 = (uint64_t)((nrows + 15) / 16) * tiles_c * (same ? 1 : 2) / 2;
-      forced_rpw = rows_per_wave_for(all16, fill_tiles);
+      const TileShape sh = tile_shape_for(all16, fill_tiles);
+      forced_rpw = sh.rpw; forced_pf = sh.pf;
     }
     if (!forced_rpw)
       hipLaunchKernelGGL(k_tiles_count16, dim3((unsigned)std::min<uint64_t>(((uint64_t)((nrows + 15) / 16) * tiles_c + 255) / 256, 4096)),
@@ -1728,7 +2047,7 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     DictState* ds = D.dstate.as<DictState>();
     hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, D.n,
                        D.hbound_ptr, R, D.part.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
-    hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, fill_tiles, &ds->part_built);
+    hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, forced_pf, fill_tiles, &ds->part_built);
     // the list: at 16 rows per tile at most every tile; shorter tiles are only chosen when fewer than
     // fill_tiles 16-row tiles are flagged (each splits into at most 4)
     const uint32_t rows_min = (forced_rpw ? forced_rpw : 1u) * (uint32_t)wpb;
@@ -1766,11 +2085,25 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     if (want_cc) hipLaunchKernelGGL((k_compare_tiled<true, R_, W_, M_>), dim3(grid), dim3(64 * W_), lds, s, a);    \
     else hipLaunchKernelGGL((k_compare_tiled<false, R_, W_, M_>), dim3(grid), dim3(64 * W_), lds, s, a);           \
   }
-    SMH_CT(4, 4, 8) SMH_CT(2, 4, 8) SMH_CT(1, 4, 8)
+    // the instantiations the plan chooses among (each returns at once unless it is the one): 16-row tiles by the plain kernel
+    // (4 waves x 4 rows), 16- and 8-row tiles by the pipelined one (8 waves x 2 rows / x 1 row, twice the LDS)
+    const size_t lds_pf = (size_t)(kPfHeader + 2 * (a.capA + a.capBt)) * 4;
+    const unsigned grid_pf = (unsigned)dev.cu_count() * 4;
+#define SMH_PF(R_, W_)                                                                                                      \
+  if (wpb == 4 && minw == 8 && (forced_rpw == 0 || (forced_rpw * 4u == R_ * W_ && forced_pf))) {                           \
+    launched = true;                                                                                                        \
+    if (want_cc) hipLaunchKernelGGL((k_compare_tiled_pf<true, R_, W_, 8>), dim3(grid_pf), dim3(64 * W_), lds_pf, s, a);   \
+    else hipLaunchKernelGGL((k_compare_tiled_pf<false, R_, W_, 8>), dim3(grid_pf), dim3(64 * W_), lds_pf, s, a);          \
+  }
+    if (!forced_pf) SMH_CT(4, 4, 8)
+    SMH_PF(2, 8) SMH_PF(1, 8)
 #ifdef SMH_EXPERIMENTS
+    if (forced_rpw && forced_pf) { SMH_PF(1, 4) }
+    if (forced_rpw && !forced_pf) { SMH_CT(2, 4, 8) SMH_CT(1, 4, 8) }
     SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
     SMH_CT(1, 8, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
 #endif
+#undef SMH_PF
 #undef SMH_CT
     if (!launched) throw_internal("compare geometry not instantiated");
     HIP_CHECK(hipGetLastError());

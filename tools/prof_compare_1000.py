@@ -18,6 +18,8 @@ off = np.arange(n + 1, dtype=np.uint64) * np.uint64(2000)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 if mode == "components":
     tune = dict(route="components")
+if os.environ.get("PROF_FORCE_TILED"):
+    tune = dict(tune, route="tiled")
 import ctypes as C
 L = pkg.lib()
 times = []
