@@ -2099,6 +2099,15 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     SMH_PF(2, 8) SMH_PF(1, 8)
 #ifdef SMH_EXPERIMENTS
     if (forced_rpw && forced_pf) { SMH_PF(1, 4) }
+    if (forced_rpw == 8 && forced_pf && wpb == 4 && minw == 8) {
+      // 32-row tiles: 8 waves x 4 rows, a row stage of twice the size, 3 workgroups per CU
+      TiledArgs a32 = a;
+      a32.capA = 2 * a.capA;
+      const size_t lds32 = (size_t)(kPfHeader + 2 * (a32.capA + a32.capBt)) * 4;
+      launched = true;
+      if (want_cc) hipLaunchKernelGGL((k_compare_tiled_pf<true, 4, 8, 6>), dim3((unsigned)dev.cu_count() * 3), dim3(512), lds32, s, a32);
+      else hipLaunchKernelGGL((k_compare_tiled_pf<false, 4, 8, 6>), dim3((unsigned)dev.cu_count() * 3), dim3(512), lds32, s, a32);
+    }
     if (forced_rpw && !forced_pf) { SMH_CT(2, 4, 8) SMH_CT(1, 4, 8) }
     SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
     SMH_CT(1, 8, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
