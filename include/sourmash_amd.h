@@ -229,7 +229,7 @@ uint64_t smh_pool_bytes(void);
 
 /* HIP-event timing of the library's kernels, on the stream they run on.
  * name: "dna_rolling", "dna_generic", "protein_fused", "translate", "hash_windows", "compare_wave", "compare_few",
- * "compare_pair", "compare_fill", "compare_comp", "compare_tiled" (all three tile heights of one call together). */
+ * "compare_pair", "compare_fill", "compare_comp", "compare_tiled" (the plain and the pipelined tiled kernels of one call together). */
 void smh_profile_enable(int on);
 void smh_profile_reset(void);
 int smh_profile_get(const char *name, double *total_ms, uint64_t *launches);
