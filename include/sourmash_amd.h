@@ -212,6 +212,7 @@ typedef struct SmhCompareStats {
   uint64_t pairs_per_tile;
   uint64_t lds_overflow_steps;  /* tiled: (tile, range) steps merged from global memory instead of the LDS stage */
   uint32_t frequent_hashes;     /* hashes set aside as frequent in this block (0 = none, or too many to set aside) */
+  uint32_t pipelined;           /* tiled: 1 = the software-pipelined kernel walked the tiles (blocks that do not fill the chip for long) */
 } SmhCompareStats;
 void smh_compare_last_stats(SmhCompareStats *out);
 

@@ -2138,6 +2138,7 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     rec.tiles_total = (uint64_t)((nrows + tr - 1) / tr) * ((ncols + kTB - 1) / kTB);
     rec.pairs_per_tile = (uint64_t)tr * kTB;
     rec.lds_overflow_steps = h.ovf_steps;
+    rec.pipelined = h.pf;
   }
   rec.frequent_hashes = D.split ? hd[1] : 0;
   set_stats(rec);

@@ -938,6 +938,7 @@ void smh_compare_last_stats(SmhCompareStats* out) {
   out->tiles_visited = st.tiles_visited; out->tiles_total = st.tiles_total; out->pairs_per_tile = st.pairs_per_tile;
   out->lds_overflow_steps = st.lds_overflow_steps;
   out->frequent_hashes = st.frequent_hashes;
+  out->pipelined = st.pipelined;
 }
 void smh_compare_get_tuning(SmhCompareTuning* out) {
   if (!out) return;

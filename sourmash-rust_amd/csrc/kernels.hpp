@@ -194,6 +194,7 @@ struct CompareStats {                      // of the last block compare
   uint64_t tiles_visited = 0, tiles_total = 0, pairs_per_tile = 0;   // components route: pairs walked / pairs / 1
   uint64_t lds_overflow_steps = 0;         // tiled: (tile, range) steps merged from global memory instead of LDS
   uint32_t frequent_hashes = 0;            // hashes set aside as frequent (decided from per-sketch positions, not walked)
+  uint32_t pipelined = 0;                  // tiled: k_compare_tiled_pf walked the tiles
 };
 void compare_set_tuning(const CompareTuning& t);
 CompareTuning compare_get_tuning();

@@ -31,7 +31,7 @@ def last_stats():
     names = {v: k for k, v in ROUTES.items()}
     return {"route": names.get(st.route, "none"), "rows_per_tile": st.rows_per_tile, "tiles_visited": st.tiles_visited,
             "tiles_total": st.tiles_total, "pairs_per_tile": st.pairs_per_tile, "lds_overflow_steps": st.lds_overflow_steps,
-            "frequent_hashes": st.frequent_hashes}
+            "frequent_hashes": st.frequent_hashes, "pipelined": st.pipelined}
 
 
 def compare_block(rows, cols, want=("jaccard",)):

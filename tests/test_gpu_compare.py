@@ -671,3 +671,35 @@ def test_components_and_disjoint_pairs(same_set, uniform_num, tune, expect, pkg,
                 assert np.isnan(out["containment"][i, j])
     out2 = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(list(gr), list(gc), want=("jaccard", "size")))
     assert (out2["jaccard"] == out["jaccard"]).all() and (out2["size"] == out["size"]).all()
+
+
+@pytest.mark.parametrize("n,rows_per_tile,pipelined", [(320, 8, 1), (1000, 8, 1), (1700, 16, 1), (4600, 16, 0)])
+def test_tile_shape_and_kernel_follow_the_block_size(n, rows_per_tile, pipelined, pkg, coracle):
+    """ONE family (every pair has to be walked) at four sizes: the device plan picks 8-row tiles and the software-pipelined
+    kernel (k_compare_tiled_pf) while fewer than ~820 sixteen-row tiles hold sharing pairs, 16-row tiles and the
+    pipelined kernel up to ~5100, 16-row tiles and the plain kernel (k_compare_tiled) beyond.  Whichever walks the tiles,
+    sampled rows x all columns equal the C oracle, the matrix is symmetric and its diagonal is 1 (reference
+    src/lib.rs:470-508)."""
+    import torch
+    from sourmash_rust_amd import synth
+    num = 2000
+    sigs = synth.family_signatures(0, n, num=num, seed=5, n_families=1)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(num)
+    with pkg.matrix.tuning(route="tiled"):
+        out = pkg.matrix.compare_block_dev(t, off, t, off, num, want=("jaccard", "common", "size", "count_common"))
+    st = pkg.matrix.last_stats()
+    assert (st["route"], st["rows_per_tile"], st["pipelined"]) == ("tiled", rows_per_tile, pipelined), st
+    j = out["jaccard"]
+    assert bool((j == j.T).all()) and bool((j.diagonal() == 1.0).all())
+    rows = sorted(set([0, 1, 15, 16, n // 2, n - 17, n - 1] + list(range(5, n, max(1, n // 11)))))
+    cols = [sigs[k] for k in range(n)]
+    ocommon, osize, ojac = coracle.compare_matrix([sigs[i] for i in rows], cols, num, 31, 0)
+    idx = torch.tensor(rows, device="cuda")
+    assert (out["jaccard"][idx].cpu().numpy() == ojac).all()
+    assert (out["common"][idx].cpu().numpy().view(np.uint64) == ocommon).all()
+    assert (out["size"][idx].cpu().numpy().view(np.uint64) == osize).all()
+    cc = out["count_common"][idx].cpu().numpy().view(np.uint64)
+    for a, i in enumerate(rows[:4]):
+        want = [len(np.intersect1d(sigs[i], sigs[k])) for k in range(0, n, max(1, n // 50))]
+        assert list(cc[a, ::max(1, n // 50)]) == want
