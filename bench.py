@@ -384,7 +384,7 @@ def main():
             rec = {"seconds": cdt, "pairs_per_s": n_sig * n_sig / cdt, "self_jaccard_is_1": bool(okt.item()),
                    "route": st["route"], "tiles_visited": st["tiles_visited"], "tiles_total": st["tiles_total"],
                    "pairs_per_tile": st["pairs_per_tile"], "rank0_pairs_walked": walked,
-                   "rank0_kernel": "k_compare_" + ("tiled" if st["route"] == "tiled" else "comp"), "rank0_kernel_ms": kms,
+                   "rank0_kernel": "k_compare_" + (("tiled_pf" if st.get("pipelined") else "tiled") if st["route"] == "tiled" else "comp"), "rank0_kernel_ms": kms,
                    "rank0_fill_ms": kern["compare_fill"][0] / max(1, kern["compare_fill"][1]),
                    "rank0_pairs_walked_per_s": walked / (kms * 1e-3) if kms > 0 else None,
                    "rank0_union_elements_walked_per_s": walked * NUM / (kms * 1e-3) if kms > 0 else None,
