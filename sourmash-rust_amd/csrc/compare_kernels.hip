@@ -1811,12 +1811,24 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     // parent array sees one union per sketch and forest.  Larger pools: 1/256 straight to the atomic path, then 1/16 through
     // the cached filter.  Finally everything through the cached filter, which sends on only the pairs not connected yet.
     if (n <= kUfLdsNodes && nm <= (1u << 22)) {     // (beyond ~4 M hashes the many-workgroup atomic path wins: measured)
-      const uint32_t W = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nm >> 6) / 8192));
+      // how much of the pairs the forests see: enough to connect n sketches (about 6 n sampled positions; a random graph is
+      // connected from ~n ln n / 2 edges on), not more -- what they leave unconnected costs the full pass its atomic path
+      // (one rank's slice of the dense 10 000-sketch collection at 1/64: 207 us there), what they see costs LDS time
+      int shift = 8;
+      while (shift > 4 && ((uint64_t)nm >> shift) < 6ull * n) shift--;
+      const uint32_t W = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nm >> shift) / 8192));
       T.wroots.ensure((size_t)W * n * 4);
-      hipLaunchKernelGGL((k_uf_runs_lds<6>), dim3(W), dim3(1024), (size_t)n * 4, s, sk, so, T.node.as<uint32_t>(), (uint64_t)nm, n,
-                         T.wroots.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+#define SMH_UF(S_)                                                                                                            \
+  if (shift == S_)                                                                                                            \
+    hipLaunchKernelGGL((k_uf_runs_lds<S_>), dim3(W), dim3(1024), (size_t)n * 4, s, sk, so, T.node.as<uint32_t>(), (uint64_t)nm, n, \
+                       T.wroots.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+      SMH_UF(4) SMH_UF(5) SMH_UF(6) SMH_UF(7) SMH_UF(8)
+#undef SMH_UF
       hipLaunchKernelGGL(k_uf_merge, dim3((unsigned)(((uint64_t)W * n + 255) / 256)), dim3(256), 0, s, T.wroots.as<uint8_t>(), (uint64_t)n * 4,
                          (uint64_t)0, W, n, T.parent.as<uint32_t>());
+      // every sketch straight under its root: the cached filter of the full pass below gives up after 64 hops, and whatever it
+      // cannot prove connected takes the atomic path
+      hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
     } else {
       hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                          (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
