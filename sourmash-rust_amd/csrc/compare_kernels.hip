@@ -1810,7 +1810,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     // workgroups (k_uf_runs_lds; ~8 K pairs each) that k_uf_merge unites -- the contended unions happen in LDS, the global
     // parent array sees one union per sketch and forest.  Larger pools: 1/256 straight to the atomic path, then 1/16 through
     // the cached filter.  Finally everything through the cached filter, which sends on only the pairs not connected yet.
-    if (n <= kUfLdsNodes && nm <= (1u << 22)) {     // (beyond ~4 M hashes the many-workgroup atomic path wins: measured)
+    if (n <= kUfLdsNodes) {
       // how much of the pairs the forests see: enough to connect n sketches (about 6 n sampled positions; a random graph is
       // connected from ~n ln n / 2 edges on), not more -- what they leave unconnected costs the full pass its atomic path
       // (one rank's slice of the dense 10 000-sketch collection at 1/64: 207 us there), what they see costs LDS time
@@ -1829,11 +1829,18 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       // every sketch straight under its root: the cached filter of the full pass below gives up after 64 hops, and whatever it
       // cannot prove connected takes the atomic path
       hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
+      if (nm > (1u << 22)) {     // a large pool: 1/16 of the pairs through the cached filter before all of them
+        hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+                           (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+        hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
+      }
     } else {
       hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                          (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+      hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
       hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                          (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
+      hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
     }
     hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
                        (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
