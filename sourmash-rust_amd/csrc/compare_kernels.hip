@@ -1546,19 +1546,21 @@ __global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st
   const uint32_t wsum = (uint32_t)wave_sum64(mine);
   if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(&st->count16, wsum);
 }
-// The shape of the tiles and the kernel that walks them, from the number of 16-row tiles that hold sharing pairs
-// (tools/sweep_pf.sh, profiles/r03_tile_shape.txt; one family, every pair walked):
-//   * many tiles (more than ~2.5 rounds of the chip's 2048 workgroup slots): 16 rows, the plain kernel -- four rows per
-//     wave between barriers amortise the per-stretch work best, and eight workgroups per CU hide each other's loads;
-//   * fewer: 16 rows, the pipelined kernel (its loads overlap its own walk: 1500 x 1500 1.34 -> 1.07 ms);
-//   * fewer than ~0.4 rounds: 8 rows, the pipelined kernel -- one tile is one latency chain, shorter tiles keep more of
-//     the chip busy (1000 x 1000 0.85 -> 0.68 ms, 300 x 300 0.58 -> 0.42).
-// rpw x 4 = rows per tile (rpw 1 = 4-row tiles: experiments only).
+// The height of the tiles, from the number of 16-row tiles that hold sharing pairs (tools/sweep_pf*.sh,
+// profiles/r03_tile_shape.txt; one family, every pair walked).  One tile is one latency chain, and a wave walks its rows
+// one after the other:
+//   * fewer than ~0.4 rounds of the chip's workgroup slots: 8 rows (8 waves x 1 row) keep more of the chip busy
+//     (1000 x 1000: 0.68 ms against 0.79 with 16 rows);
+//   * up to ~2800: 16 rows (8 waves x 2 rows; 1500 x 1500 1.07 against 1.22 / 1.27 with 8 / 32 rows);
+//   * more: 32 rows (8 waves x 4 rows) -- four rows per wave between barriers and one column stage for 32 rows amortise the
+//     per-stretch work best (10 000 x 10 000: 25.0 ms against 29.5 with 16 rows).
+// All by the pipelined kernel; the plain one (k_compare_tiled, 16 rows by 4 waves x 4 rows: 26.4 ms at 10 000 x 10 000, and
+// behind at every smaller size) is kept for the experiments build.  rpw x 4 = rows per tile.
 struct TileShape { uint32_t rpw, pf; };
 __device__ __host__ inline TileShape tile_shape_for(uint64_t count16, uint32_t fill_tiles) {
   if (10 * count16 < fill_tiles) return {2u, 1u};
-  if (8 * count16 < 5ull * fill_tiles) return {4u, 1u};
-  return {4u, 0u};
+  if (35 * count16 < 12ull * fill_tiles) return {4u, 1u};
+  return {8u, 1u};
 }
 __global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t forced_pf, uint32_t fill_tiles, uint32_t* part_built) {
   if (!st->skip_tiled) *part_built = 1;   // k_partition ran just before this launch (same stream)
@@ -2094,8 +2096,8 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     a.capBt = ex.capB * kTB;  // columns up to 47 elements in one range
     a.ovf_steps = &st->ovf_steps;
     a.out = out;
-    const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;
-    const unsigned grid = (unsigned)dev.cu_count() * 8;   // a multiple of 8: one stretch of the list per XCD
+    [[maybe_unused]] const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;      // (the plain kernel: experiments build)
+    [[maybe_unused]] const unsigned grid = (unsigned)dev.cu_count() * 8;          // a multiple of 8: one stretch of the list per XCD
     dev.prof_begin(s);
     bool launched = false;
 #define SMH_CT(R_, W_, M_)                                                                                           \
@@ -2104,8 +2106,8 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     if (want_cc) hipLaunchKernelGGL((k_compare_tiled<true, R_, W_, M_>), dim3(grid), dim3(64 * W_), lds, s, a);    \
     else hipLaunchKernelGGL((k_compare_tiled<false, R_, W_, M_>), dim3(grid), dim3(64 * W_), lds, s, a);           \
   }
-    // the instantiations the plan chooses among (each returns at once unless it is the one): 16-row tiles by the plain kernel
-    // (4 waves x 4 rows), 16- and 8-row tiles by the pipelined one (8 waves x 2 rows / x 1 row, twice the LDS)
+    // the instantiations the plan chooses among (each returns at once unless it is the one): 8-, 16- and 32-row tiles by the
+    // pipelined kernel (8 waves x 1 / 2 / 4 rows, 39 KB of LDS: 4 workgroups per CU)
     const size_t lds_pf = (size_t)(kPfHeader + 2 * (a.capA + a.capBt)) * 4;
     const unsigned grid_pf = (unsigned)dev.cu_count() * 4;
 #define SMH_PF(R_, W_)                                                                                                      \
@@ -2114,20 +2116,24 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     if (want_cc) hipLaunchKernelGGL((k_compare_tiled_pf<true, R_, W_, 8>), dim3(grid_pf), dim3(64 * W_), lds_pf, s, a);   \
     else hipLaunchKernelGGL((k_compare_tiled_pf<false, R_, W_, 8>), dim3(grid_pf), dim3(64 * W_), lds_pf, s, a);          \
   }
-    if (!forced_pf) SMH_CT(4, 4, 8)
+    bool pf32_big = false;
+#ifdef SMH_EXPERIMENTS
+    pf32_big = std::getenv("SOURMASH_AMD_CMP_PF32_BIG") != nullptr;
+#endif
+    if (!pf32_big) SMH_PF(4, 8)
     SMH_PF(2, 8) SMH_PF(1, 8)
 #ifdef SMH_EXPERIMENTS
     if (forced_rpw && forced_pf) { SMH_PF(1, 4) }
-    if (forced_rpw == 8 && forced_pf && wpb == 4 && minw == 8) {
-      // 32-row tiles: 8 waves x 4 rows, a row stage of twice the size, 3 workgroups per CU
+    if (forced_rpw && !forced_pf) { SMH_CT(4, 4, 8) SMH_CT(2, 4, 8) SMH_CT(1, 4, 8) }
+    if (forced_rpw == 8 && forced_pf && wpb == 4 && minw == 8 && pf32_big) {
+      launched = true;
+      // 32-row tiles with a row stage of twice the size: 3 workgroups per CU (28.0 ms at 10 000 x 10 000 against 25.0)
       TiledArgs a32 = a;
       a32.capA = 2 * a.capA;
       const size_t lds32 = (size_t)(kPfHeader + 2 * (a32.capA + a32.capBt)) * 4;
-      launched = true;
       if (want_cc) hipLaunchKernelGGL((k_compare_tiled_pf<true, 4, 8, 6>), dim3((unsigned)dev.cu_count() * 3), dim3(512), lds32, s, a32);
       else hipLaunchKernelGGL((k_compare_tiled_pf<false, 4, 8, 6>), dim3((unsigned)dev.cu_count() * 3), dim3(512), lds32, s, a32);
     }
-    if (forced_rpw && !forced_pf) { SMH_CT(2, 4, 8) SMH_CT(1, 4, 8) }
     SMH_CT(4, 4, 1) SMH_CT(8, 4, 1) SMH_CT(16, 4, 1) SMH_CT(4, 8, 1) SMH_CT(8, 8, 1) SMH_CT(2, 8, 1)
     SMH_CT(1, 8, 8) SMH_CT(4, 8, 8) SMH_CT(2, 8, 8) SMH_CT(4, 8, 6) SMH_CT(4, 4, 6) SMH_CT(2, 16, 8) SMH_CT(4, 16, 8)
 #endif
