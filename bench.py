@@ -413,12 +413,12 @@ def main():
             walked, kms = dense["rank0_pairs_walked"], dense["rank0_kernel_ms"]
             lds_bytes = pmc.get("lds_bytes_per_walked_pair") * walked if pmc and pmc.get("lds_bytes_per_walked_pair") else None
             lds_achieved = lds_bytes / (kms * 1e-3) / 1e12 if lds_bytes else None
-            cmp_roof = {"kernel": "k_compare_tiled", "bound": "lds", "unit": "TB/s", "peak": LDS_READ_B32_PEAK_TBS,
+            cmp_roof = {"kernel": dense["rank0_kernel"], "bound": "lds", "unit": "TB/s", "peak": LDS_READ_B32_PEAK_TBS,
                         "kernel_ms_avg": kms, "pairs_walked": walked, "n_signatures": sizes[0],
                         "achieved": lds_achieved, "frac": lds_achieved / LDS_READ_B32_PEAK_TBS if lds_achieved else None,
                         "lds_bytes": lds_bytes,
-                        "lds_bytes_source": ("profiles/r03_pmc_compare_tiled.json (SQ_INSTS_LDS of a separate rocprofv3 --pmc pass "
-                                             "x 64 lanes x 4 B per walked pair; committed, not measured in this run)") if lds_bytes else None,
+                        "lds_bytes_source": ("profiles/r03_pmc_compare_tiled.json (SQ_INSTS_LDS of a separate rocprofv3 --pmc pass of %s "
+                                             "x 64 lanes x 4 B per walked pair; committed, not measured in this run)" % pmc.get("kernel", "the kernel")) if lds_bytes else None,
                         "effective_bytes": walked * ((NUM + NUM) * 8 + 8),
                         "effective_TBps": walked * ((NUM + NUM) * 8 + 8) / (kms * 1e-3) / 1e12,
                         "compulsory_hbm_bytes": sizes[0] * NUM * 8 + D.shard_range(sizes[0], world, 0)[2] * sizes[0] * 8,

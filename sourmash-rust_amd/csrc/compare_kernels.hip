@@ -724,6 +724,7 @@ template <bool WantCC, int RPW, int WPB, int MINW>
 __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a) {
   constexpr int kRowsPerWave = RPW;
   constexpr int kTR = WPB * RPW;   // rows per tile (<= 64)
+  static_assert(WPB >= (int)kPad && kTR <= 64, "waves 0..3 write the column sentinels");
   constexpr uint32_t kNone = 0xffffffffu;
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
   uint32_t* ctl = sm;              // [2 s], [2 s + 1]: table slot s does not fit (rows, columns); [8] the tile taken
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   uint32_t* stage = sm + kPfHeader;   // two stages
   const uint32_t stage_dw = a.capA + a.capBt;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (w: a scalar)
   // the plan picks a tile height; this instantiation serves one of them -- or none
   if (a.st->skip_tiled || a.st->rpw * 4u != (uint32_t)kTR || !a.st->pf) return;
   const uint32_t ntiles = min(a.st->ntiles, a.tiles_cap);
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       T[192 + tid - 64] = hi - lo; T[256 + tid - 64] = hi;
       uint32_t mx = hi - lo;
       for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
-      if (tid == 64) ctl[2 * s + 1] = ((mx + kPad) * kTB > a.capBt) ? 1u : 0u;
+      if (tid == 64) { ctl[2 * s + 1] = ((mx + kPad) * kTB > a.capBt) ? 1u : 0u; ctl[12 + s] = mx; }   // (the longest column segment: issue_stage)
     }
   };
   // the ranks of table slot s's segments -> stage slot g, asynchronously (rows packed: wave w its rows; columns transposed:
@@ -796,12 +797,10 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     }
     const uint32_t lb = T[192 + lane];
     const uint32_t* src = a.crank + goff[64 + lane] + (T[256 + lane] - lb);
-    uint32_t lbmax = lb;
-    for (int off = 32; off; off >>= 1) lbmax = max(lbmax, (uint32_t)__shfl_xor(lbmax, off));
-    for (uint32_t e = w; e < lbmax + kPad; e += WPB) {
+    const uint32_t lbmax = ctl[12 + s];
+    for (uint32_t e = w; e < lbmax; e += WPB)
       if (e < lb) __builtin_amdgcn_global_load_lds(src + e, pB + e * kTB, 4, 0, 0);
-      else if (e < lb + kPad) pB[e * kTB + lane] = kSent;
-    }
+    if (w < (int)kPad) pB[(lb + w) * kTB + lane] = kSent;      // (waves 0..3: one of the column's four sentinels each)
   };
   // where the rows and columns cross boundary `at`, asynchronously into rawp[] (waves 0 and 1)
   auto issue_raw = [&](uint32_t at, uint32_t* rawp) {
