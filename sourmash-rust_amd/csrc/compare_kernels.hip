@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   static_assert(WPB >= (int)kPad && kTR <= 64, "waves 0..3 write the column sentinels");
   constexpr uint32_t kNone = 0xffffffffu;
   extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
-  uint32_t* ctl = sm;              // [2 s], [2 s + 1]: table slot s does not fit (rows, columns); [8] the tile taken
+  uint32_t* ctl = sm;              // [2 s], [2 s + 1]: table slot s does not fit (rows, columns); [8] the tile taken; [9..11] votes; [12 + s] longest column segment
   uint32_t* nrowL = sm + 16;       // [64] truncation length of each row (0xffffffff = none, 0 = no row)
   uint32_t* rowid = sm + 80;       // [64]
   uint32_t* colid = sm + 144;      // [64]
@@ -848,6 +848,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       steal++;
     }
     ctl[8] = t;
+    ctl[9] = 0; ctl[10] = 0; ctl[11] = 0;      // the "a pair is short of its cut" flags of three consecutive stretches
   }
   __syncthreads();
   const uint32_t tix = ctl[8];
@@ -954,8 +955,14 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     bool done = !WantCC;
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) done = done && (ucount[q] >= nrowL[w * kRowsPerWave + q]);
+    // the vote with ONE barrier (__syncthreads_and takes three): a wave with a pair still short of its cut raises the flag of
+    // this stretch; the flag of the stretch after the next is cleared now (the last readers of that slot -- the stretch
+    // before the previous one -- have all passed a barrier since)
+    if (tid == 0) ctl[9 + (it + 1) % 3] = 0;
+    if (!__all(done || !col_ok) && lane == 0) ctl[9 + it % 3] = 1;
     __builtin_amdgcn_s_waitcnt(0x0f70);        // what this wave requested has arrived
-    if (__syncthreads_and(done || !col_ok)) break;
+    __syncthreads();
+    if (ctl[9 + it % 3] == 0) break;
     if (!mt1) break;
     // ---- the next stretch becomes the current one
     bool ovf2 = mt2 ? flags(s2) : false;
