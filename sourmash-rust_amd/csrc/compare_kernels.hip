@@ -489,6 +489,53 @@ __device__ __forceinline__ void tiled_walk_row(const uint32_t* A, const uint32_t
   if (WantCC) cc += ccv;
 }
 
+// The same merge for one range that does not fit the LDS stage: A and B straight from global memory (rare)
+template <bool WantCC>
+__device__ __forceinline__ void tiled_merge_global_row(const uint32_t* __restrict__ A, uint32_t la, const uint32_t* __restrict__ B, uint32_t lb,
+                                                       uint32_t n, uint32_t& ucount, uint32_t& common, uint32_t& cc) {
+  uint32_t pa = 0, pb = 0, u = ucount, cm = common, c2 = 0;
+  while (pa < la && pb < lb) {
+    const uint32_t av = A[pa], bv = B[pb];
+    const bool eq = av == bv;
+    cm += (eq && u < n) ? 1u : 0u;
+    if (WantCC) c2 += eq ? 1u : 0u;
+    u += 1;
+    pa += av <= bv ? 1u : 0u;
+    pb += bv <= av ? 1u : 0u;
+  }
+  u += (la - pa) + (lb - pb);
+  ucount = u; common = cm;
+  if (WantCC) cc += c2;
+}
+// What a lane has found for pair (row, col) goes to the outputs -- and to the mirrored entry when the column is one of the
+// local rows and there is one num: the walk is symmetric in its two inputs, so this is also pair (col, row); tiles that
+// hold no owned pair are not launched.  nq: the row's cut.
+template <bool WantCC>
+__device__ __forceinline__ void tiled_write_pair(const TiledArgs& a, uint32_t row, uint32_t col, uint32_t nq, uint32_t ucount, uint32_t common,
+                                                 uint32_t cc) {
+  const size_t pid = (size_t)row * a.ncols + col;
+  const uint64_t size = ucount < nq ? ucount : nq;
+  const double jac = (double)common / (double)(size > 1 ? size : 1);
+  if (a.out.common) a.out.common[pid] = common;
+  if (a.out.size) a.out.size[pid] = size;
+  if (a.out.jaccard) a.out.jaccard[pid] = jac;
+  if (WantCC) {
+    if (a.out.count_common) a.out.count_common[pid] = cc;
+    if (a.out.containment) a.out.containment[pid] = (double)cc / (double)(a.roff[row + 1] - a.roff[row]);
+  }
+  const uint32_t gi = a.scope.row_base + row, gj = a.scope.col_base + col;
+  if (gj >= a.scope.mir_lo && gj < a.scope.mir_hi && gi != gj) {
+    const size_t pid2 = (size_t)(gj - a.scope.mir_lo) * a.ncols + (gi - a.scope.col_base);
+    if (a.out.common) a.out.common[pid2] = common;
+    if (a.out.size) a.out.size[pid2] = size;
+    if (a.out.jaccard) a.out.jaccard[pid2] = jac;
+    if (WantCC) {
+      if (a.out.count_common) a.out.count_common[pid2] = cc;
+      if (a.out.containment) a.out.containment[pid2] = (double)cc / (double)(a.coff[col + 1] - a.coff[col]);
+    }
+  }
+}
+
 // RPW rows per wave, WPB waves per workgroup (they share the staged column tile), MINW = waves per
 // SIMD the register allocator must leave room for
 template <bool WantCC, int RPW, int WPB, int MINW>
@@ -642,22 +689,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; q++) {
         const int t = w * kRowsPerWave + q;
-        const uint32_t la = lenA[t];
-        const uint32_t* A = a.rrank + gA[t];
-        uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
-        const uint32_t n = nrowL[t];
-        while (pa < la && pb < lb) {
-          const uint32_t av = A[pa], bv = B[pb];
-          const bool eq = av == bv;
-          cm += (eq && u < n) ? 1u : 0u;
-          if (WantCC) c2 += eq ? 1u : 0u;
-          u += 1;
-          pa += av <= bv ? 1u : 0u;
-          pb += bv <= av ? 1u : 0u;
-        }
-        u += (la - pa) + (lb - pb);
-        ucount[q] = u; common[q] = cm;
-        if (WantCC) cc[q] += c2;
+        tiled_merge_global_row<WantCC>(a.rrank + gA[t], lenA[t], B, lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
       }
     }
     // ---- all pairs of the tile past their cut: the remaining ranges cannot change common or size
@@ -674,37 +706,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
 #pragma unroll
   for (int q = 0; q < kRowsPerWave; q++) {
     const uint32_t row = rowid[w * kRowsPerWave + q];
-    if (row != 0xffffffffu && col_ok) {
-      const size_t pid = (size_t)row * a.ncols + col;
-      const uint32_t nq = nrowL[w * kRowsPerWave + q];
-      const uint64_t size = ucount[q] < nq ? ucount[q] : nq;
-      if (a.out.common) a.out.common[pid] = common[q];
-      if (a.out.size) a.out.size[pid] = size;
-      if (a.out.jaccard) a.out.jaccard[pid] = (double)common[q] / (double)(size > 1 ? size : 1);
-      if (WantCC) {
-        if (a.out.count_common) a.out.count_common[pid] = cc[q];
-        if (a.out.containment) {
-          const uint64_t la_full = a.roff[row + 1] - a.roff[row];
-          a.out.containment[pid] = (double)cc[q] / (double)la_full;
-        }
-      }
-      const uint32_t gi = a.scope.row_base + row, gj = a.scope.col_base + col;
-      if (gj >= a.scope.mir_lo && gj < a.scope.mir_hi && gi != gj) {
-        // the column is one of the local rows and there is one num: the walk is symmetric in its two
-        // inputs, so this is also pair (col, row) -- tiles that hold no owned pair are not launched
-        const size_t pid2 = (size_t)(gj - a.scope.mir_lo) * a.ncols + (gi - a.scope.col_base);
-        if (a.out.common) a.out.common[pid2] = common[q];
-        if (a.out.size) a.out.size[pid2] = size;
-        if (a.out.jaccard) a.out.jaccard[pid2] = (double)common[q] / (double)(size > 1 ? size : 1);
-        if (WantCC) {
-          if (a.out.count_common) a.out.count_common[pid2] = cc[q];
-          if (a.out.containment) {
-            const uint64_t lb_full = a.coff[col + 1] - a.coff[col];
-            a.out.containment[pid2] = (double)cc[q] / (double)lb_full;
-          }
-        }
-      }
-    }
+    if (row != 0xffffffffu && col_ok)
+      tiled_write_pair<WantCC>(a, row, col, nrowL[w * kRowsPerWave + q], ucount[q], common[q], WantCC ? cc[q] : 0u);
   }
   }   // tiles of this workgroup
 }
@@ -934,21 +937,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       for (int q = 0; q < kRowsPerWave; q++) {
         const int t = w * kRowsPerWave + q;
         const uint32_t la = T[t];
-        const uint32_t* A = a.rrank + goff[t] + (T[128 + t] - la);
-        uint32_t pa = 0, pb = 0, u = ucount[q], cm = common[q], c2 = 0;
-        const uint32_t n = nrowL[t];
-        while (pa < la && pb < lb) {
-          const uint32_t av = A[pa], bv = B[pb];
-          const bool eq = av == bv;
-          cm += (eq && u < n) ? 1u : 0u;
-          if (WantCC) c2 += eq ? 1u : 0u;
-          u += 1;
-          pa += av <= bv ? 1u : 0u;
-          pb += bv <= av ? 1u : 0u;
-        }
-        u += (la - pa) + (lb - pb);
-        ucount[q] = u; common[q] = cm;
-        if (WantCC) cc[q] += c2;
+        tiled_merge_global_row<WantCC>(a.rrank + goff[t] + (T[128 + t] - la), la, B, lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
       }
     }
     // ---- all pairs of the tile past their cut: the remaining ranges cannot change common or size
@@ -982,35 +971,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
 #pragma unroll
   for (int q = 0; q < kRowsPerWave; q++) {
     const uint32_t row = rowid[w * kRowsPerWave + q];
-    if (row != kNone && col_ok) {
-      const size_t pid = (size_t)row * a.ncols + col;
-      const uint32_t nq = nrowL[w * kRowsPerWave + q];
-      const uint64_t size = ucount[q] < nq ? ucount[q] : nq;
-      if (a.out.common) a.out.common[pid] = common[q];
-      if (a.out.size) a.out.size[pid] = size;
-      if (a.out.jaccard) a.out.jaccard[pid] = (double)common[q] / (double)(size > 1 ? size : 1);
-      if (WantCC) {
-        if (a.out.count_common) a.out.count_common[pid] = cc[q];
-        if (a.out.containment) {
-          const uint64_t la_full = a.roff[row + 1] - a.roff[row];
-          a.out.containment[pid] = (double)cc[q] / (double)la_full;
-        }
-      }
-      const uint32_t gi = a.scope.row_base + row, gj = a.scope.col_base + col;
-      if (gj >= a.scope.mir_lo && gj < a.scope.mir_hi && gi != gj) {
-        const size_t pid2 = (size_t)(gj - a.scope.mir_lo) * a.ncols + (gi - a.scope.col_base);
-        if (a.out.common) a.out.common[pid2] = common[q];
-        if (a.out.size) a.out.size[pid2] = size;
-        if (a.out.jaccard) a.out.jaccard[pid2] = (double)common[q] / (double)(size > 1 ? size : 1);
-        if (WantCC) {
-          if (a.out.count_common) a.out.count_common[pid2] = cc[q];
-          if (a.out.containment) {
-            const uint64_t lb_full = a.coff[col + 1] - a.coff[col];
-            a.out.containment[pid2] = (double)cc[q] / (double)lb_full;
-          }
-        }
-      }
-    }
+    if (row != kNone && col_ok)
+      tiled_write_pair<WantCC>(a, row, col, nrowL[w * kRowsPerWave + q], ucount[q], common[q], WantCC ? cc[q] : 0u);
   }
   }   // tiles of this workgroup
 }
