@@ -489,6 +489,23 @@ __device__ __forceinline__ void tiled_walk_row(const uint32_t* A, const uint32_t
   if (WantCC) cc += ccv;
 }
 
+// The next tile of this workgroup (thread 0): a persistent grid pulls tiles off the list (tile times differ: a static split
+// left the chip half idle at the end).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: workgroup b
+// first serves stretch b % 8 of the list, so that the tiles an XCD works on share rows and columns, and helps the other
+// stretches out once its own is exhausted (steal = stretches given up so far).  0xffffffff: none left.
+__device__ __forceinline__ uint32_t tiled_take_tile(PlanState* st, uint32_t ntiles, uint32_t nstretch, uint32_t chunk, uint32_t& steal) {
+  while (steal < nstretch) {
+    const uint32_t x = ((blockIdx.x & 7u) + steal) % nstretch;
+    const uint32_t lo = x * chunk, hi = min(lo + chunk, ntiles);
+    if (lo < hi) {
+      const uint32_t k = atomicAdd(&st->next_tile[x], 1u);
+      if (lo + k < hi) return lo + k;
+    }
+    steal++;
+  }
+  return 0xffffffffu;
+}
+
 // The same merge for one range that does not fit the LDS stage: A and B straight from global memory (rare)
 template <bool WantCC>
 __device__ __forceinline__ void tiled_merge_global_row(const uint32_t* __restrict__ A, uint32_t la, const uint32_t* __restrict__ B, uint32_t lb,
@@ -559,28 +576,13 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled(TiledArgs a) {
   // the plan picks ONE of the launched instantiations (rows per wave) -- or none of them
   if (a.st->skip_tiled || a.st->rpw != (uint32_t)RPW || a.st->pf) return;
   const uint32_t ntiles = min(a.st->ntiles, a.tiles_cap);
-  // A persistent grid pulls tiles off the list (tile times differ: a static split left the chip
-  // half idle at the end).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2:
-  // workgroup b first serves stretch b % 8 of the list, so that the tiles an XCD works on share
-  // rows and columns, and helps the other stretches out once its own is exhausted.
+  // (tiles are pulled off the list dynamically, one stretch of it per XCD first: tiled_take_tile)
   const uint32_t nstretch = (a.use_xcd && ntiles >= 64) ? 8u : 1u;
   const uint32_t chunk = (ntiles + nstretch - 1) / nstretch;
   uint32_t steal = 0;     // (thread 0) stretches given up so far
   while (true) {
   __syncthreads();                 // the previous tile's tables and stage are no longer being read
-  if (tid == 0) {
-    uint32_t t = 0xffffffffu;
-    while (steal < nstretch) {
-      const uint32_t x = ((blockIdx.x & 7u) + steal) % nstretch;
-      const uint32_t lo = x * chunk, hi = min(lo + chunk, ntiles);
-      if (lo < hi) {
-        const uint32_t k = atomicAdd(&a.st->next_tile[x], 1u);
-        if (lo + k < hi) { t = lo + k; break; }
-      }
-      steal++;
-    }
-    ctl[2] = t;
-  }
+  if (tid == 0) ctl[2] = tiled_take_tile(a.st, ntiles, nstretch, chunk, steal);
   __syncthreads();
   const uint32_t tix = ctl[2];
   if (tix == 0xffffffffu) break;
@@ -840,17 +842,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   __builtin_amdgcn_s_waitcnt(0x0f70);   // (vmcnt 0: nothing of the previous tile is still on its way into LDS)
   __syncthreads();
   if (tid == 0) {
-    uint32_t t = kNone;
-    while (steal < nstretch) {
-      const uint32_t x = ((blockIdx.x & 7u) + steal) % nstretch;
-      const uint32_t lo = x * chunk, hi = min(lo + chunk, ntiles);
-      if (lo < hi) {
-        const uint32_t k = atomicAdd(&a.st->next_tile[x], 1u);
-        if (lo + k < hi) { t = lo + k; break; }
-      }
-      steal++;
-    }
-    ctl[8] = t;
+    ctl[8] = tiled_take_tile(a.st, ntiles, nstretch, chunk, steal);
     ctl[9] = 0; ctl[10] = 0; ctl[11] = 0;      // the "a pair is short of its cut" flags of three consecutive stretches
   }
   __syncthreads();
