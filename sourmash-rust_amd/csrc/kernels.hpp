@@ -186,7 +186,8 @@ struct CompareTuning {
   uint32_t visit_all_tiles = 0;            // 1: launch every tile, not only those that can hold sharing pairs
   uint32_t use_symmetry = 1;               // all-vs-all with one num: compute the upper triangle, mirror the rest
   uint32_t split_frequent = 1;             // hashes held by a large share of the sketches do not make components
-  uint64_t comp_pairs_limit = 1ull << 18;  // at most this many sharing pairs: per-component pair kernel, else tiled
+  uint64_t comp_pairs_limit = 96ull << 10;  // at most this many sharing pairs: per-component pair kernel, else tiled (the pair kernel
+                                           // takes ~3.7 ns per pair of num = 2000 sketches, one round of tiles ~0.45 ms: profiles/r03_tile_shape.txt)
 };
 struct CompareStats {                      // of the last block compare
   uint32_t route = 0;                      // CompareRoute that ran

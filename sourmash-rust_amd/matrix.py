@@ -14,7 +14,7 @@ ROUTES = {"auto": 0, "wave": 1, "few": 2, "components": 3, "tiled": 4}
 
 
 @contextlib.contextmanager
-def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=1 << 18, split_frequent=True):
+def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=96 << 10, split_frequent=True):
     """Pins which kernel serves the block compares inside the `with` (additive ABI
     smh_compare_set_tuning; results never depend on it), then restores the defaults."""
     t = SmhCompareTuning(ROUTES[route], int(visit_all_tiles), int(use_symmetry), comp_pairs_limit, int(split_frequent))

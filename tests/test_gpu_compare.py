@@ -263,7 +263,7 @@ def test_matrix_at_benchmark_size_vs_oracle(pkg, coracle):
 
 def test_matrix_at_c4_size_vs_oracle(pkg, coracle):
     """C4 at full size on one GPU (10 000 x 10 000, num=2000): the shape-based default route (the
-    tiled kernel: > 2^18 sharing pairs) on the family collection and on the one-component
+    tiled kernel: > 96 Ki sharing pairs) on the family collection and on the one-component
     collection, 32 sampled rows x all 10 000 columns against the C oracle."""
     rows = sorted(set([0, 1, 49, 50, 4999, 5000, 9999] + list(range(13, 10000, 400))))
     _full_size_matrix_check(pkg, coracle, 10000, 4, rows, [(dict(), "tiled"), (dict(split_frequent=False), "tiled")])

@@ -215,7 +215,7 @@ while time.time() < t_end:
             sys.exit(1)
         n_cmp += 1
     elif rng.random() < 0.15:
-        # a block with more than 2^18 sharing pairs: the shape-based default takes the tiled kernel.
+        # a block with more than 96 Ki sharing pairs: the shape-based default takes the tiled kernel.
         # Device CSR in, whole matrix against the C oracle's compare_matrix.
         nrs = np.random.RandomState(rng.getrandbits(31))
         nrow, ncol = rng.randint(520, 700), rng.randint(520, 900)

@@ -20,6 +20,8 @@ if mode == "components":
     tune = dict(route="components")
 if os.environ.get("PROF_FORCE_TILED"):
     tune = dict(tune, route="tiled")
+if os.environ.get("PROF_COMP_LIMIT"):
+    tune = dict(tune, comp_pairs_limit=int(os.environ["PROF_COMP_LIMIT"]))
 import ctypes as C
 L = pkg.lib()
 times = []

@@ -25,6 +25,10 @@ def timed(fn):
     return r, (time.perf_counter() - t0) * 1e3
 
 
+import contextlib
+_lim = os.environ.get("PROF_COMP_LIMIT")
+_ctx = MX.tuning(comp_pairs_limit=int(_lim)) if _lim else contextlib.nullcontext()
+_ctx.__enter__()
 for world in worlds:
     blocks = [D.shard_range(n, world, r)[:2] for r in range(world)]
     best = None
