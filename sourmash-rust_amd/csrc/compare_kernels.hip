@@ -1079,17 +1079,27 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
                                                       const uint32_t* __restrict__ spart, uint32_t G, uint32_t g,
                                                       const uint32_t* __restrict__ segoff_g, uint32_t n,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ org, uint32_t* __restrict__ node) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  uint32_t lo = 0, hi = nsk;   // last s with segoff_g[s] <= t  (its segment is not empty: t < n)
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ node) {
+  // a lane takes 8 consecutive slice positions: one search for the sketch of the first, then a walk (the sort numbers the keys)
+  const uint32_t t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
+  if (t0 >= n) return;
+  uint32_t lo = 0, hi = nsk;   // last s with segoff_g[s] <= t0  (its segment is not empty: t0 < n)
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (segoff_g[mid] <= t) lo = mid; else hi = mid;
+    if (segoff_g[mid] <= t0) lo = mid; else hi = mid;
   }
-  keys[t] = hashes[off[lo] + spart[(size_t)lo * (G + 1) + g] + (t - segoff_g[lo])];
-  org[t] = t;
-  node[t] = lo;
+  uint32_t seg0 = segoff_g[lo], next = segoff_g[lo + 1];
+  const uint64_t* src = hashes + off[lo] + spart[(size_t)lo * (G + 1) + g];
+  const uint32_t t1 = min(t0 + 8u, n);
+  for (uint32_t t = t0; t < t1; t++) {
+    while (t >= next) {          // (sketches with nothing in this slice are stepped over)
+      lo++;
+      seg0 = next; next = segoff_g[lo + 1];
+      src = hashes + off[lo] + spart[(size_t)lo * (G + 1) + g];
+    }
+    keys[t] = src[t - seg0];
+    node[t] = lo;
+  }
 }
 // world == 1: the one slice is the collection itself, in its own order (the sort reads it in place and numbers it); what is
 // left to make is node[t] = the sketch of element t.  A lane takes 8 consecutive elements: one search, then a walk.
@@ -1741,11 +1751,11 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       cur = radix_sort_u64_place(D.hashes, T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
                                  dev.scratch, s, 0xffu);
     } else {
-      hipLaunchKernelGGL(k_slice_gather, dim3((nm + 255) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
-                         D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.org0.as<uint32_t>(),
-                         T.node.as<uint32_t>());
-      cur = radix_sort_u64_v32(T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
-                               dev.scratch, s, 0xffu);
+      hipLaunchKernelGGL(k_slice_gather, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
+                         D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>());
+      // (the first pass reads keys0 and writes keys1: keys0 is input and work buffer at once)
+      cur = radix_sort_u64_place(T.keys0.as<uint64_t>(), T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(),
+                                 T.org1.as<uint32_t>(), nm, dev.scratch, s, 0xffu);
     }
     if (cur) { sk = T.keys1.as<uint64_t>(); so = T.org1.as<uint32_t>(); }
   }

@@ -612,7 +612,7 @@ static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanCh
 
 // pass_mask != 0: run exactly the byte passes whose bit is set (the caller knows which bytes of the
 // keys can differ) -- no digit-histogram read-back, so no host synchronisation inside the sort.
-// first_in (nullable; needs pass_mask): the keys are read from there by the first pass that runs, k0 is only a work buffer, and
+// first_in (nullable; needs pass_mask; may be k0 itself): the keys are read from there by the first pass that runs, k0 is only a work buffer, and
 // the payload (vbytes 4) starts as every key's index in first_in -- the caller's array stays untouched and no index array is made.
 static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
                            DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0,
@@ -620,7 +620,7 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
   if (first_in && (!pass_mask || vbytes != 4 || !v0)) throw_internal("radix_sort: first_in needs a pass mask and a 32-bit payload");
   if (n < 2) {
     if (first_in && n == 1) {
-      HIP_CHECK(hipMemcpyAsync(k0, first_in, 8, hipMemcpyDeviceToDevice, s));
+      if (first_in != k0) HIP_CHECK(hipMemcpyAsync(k0, first_in, 8, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipMemsetAsync(v0, 0, 4, s));
     }
     return 0;
