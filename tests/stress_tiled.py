@@ -1,7 +1,7 @@
 """Randomised parity of the tiled route on MID-SIZE and LARGE blocks (16- and 32-row tiles of k_compare_tiled_pf), which the
 fuzz's small blocks do not reach: ragged sketches, a few families, random num (0 = no cut), same set and two sets, every
 output.  Sampled rows x all columns against the C oracle; symmetry when rows == columns.
-    python tools/stress_tiled.py <seconds> <seed>"""
+    python tests/stress_tiled.py <seconds> <seed>      (run by tests/test_gpu_compare.py for 20 seconds; the C oracle is the checker)"""
 import os, random, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

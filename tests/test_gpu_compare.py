@@ -705,11 +705,11 @@ def test_tile_shape_and_kernel_follow_the_block_size(n, rows_per_tile, pipelined
 
 
 def test_tiled_route_on_random_mid_size_blocks(pkg):
-    """tools/stress_tiled.py for 20 seconds with a fixed seed: random ragged collections of 1300-3600 sketches (one or two
+    """tests/stress_tiled.py for 20 seconds with a fixed seed: random ragged collections of 1300-3600 sketches (one or two
     sets, a few families, random num) through the tiled route -- 8-, 16- and 32-row tiles of the pipelined kernel -- against
     the C oracle on sampled rows, symmetry included."""
     import subprocess
     import sys
     from conftest import ROOT
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_tiled.py"), "20", "7"], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stress_tiled.py"), "20", "7"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "stress ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
