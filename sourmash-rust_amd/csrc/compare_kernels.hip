@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st
 // one after the other:
 //   * fewer than ~0.4 rounds of the chip's workgroup slots: 8 rows (8 waves x 1 row) keep more of the chip busy
 //     (1000 x 1000: 0.68 ms against 0.79 with 16 rows);
-//   * up to ~2800: 16 rows (8 waves x 2 rows; 1500 x 1500 1.07 against 1.22 / 1.27 with 8 / 32 rows);
+//   * up to ~2400: 16 rows (8 waves x 2 rows; 1600 x 1600 1.05 against 1.12 / 1.24 with 8 / 32 rows);
 //   * more: 32 rows (8 waves x 4 rows) -- four rows per wave between barriers and one column stage for 32 rows amortise the
 //     per-stretch work best (10 000 x 10 000: 25.0 ms against 29.5 with 16 rows).
 // All by the pipelined kernel; the plain one (k_compare_tiled, 16 rows by 4 waves x 4 rows: 26.4 ms at 10 000 x 10 000, and
@@ -1529,7 +1529,7 @@ __global__ __launch_bounds__(256) void k_tiles_count16(TileTest t, PlanState* st
 struct TileShape { uint32_t rpw, pf; };
 __device__ __host__ inline TileShape tile_shape_for(uint64_t count16, uint32_t fill_tiles) {
   if (10 * count16 < fill_tiles) return {2u, 1u};
-  if (35 * count16 < 12ull * fill_tiles) return {4u, 1u};
+  if (17 * count16 < 5ull * fill_tiles) return {4u, 1u};
   return {8u, 1u};
 }
 __global__ void k_plan_geometry(PlanState* st, uint32_t forced_rpw, uint32_t forced_pf, uint32_t fill_tiles, uint32_t* part_built) {

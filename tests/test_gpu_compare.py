@@ -676,7 +676,7 @@ def test_components_and_disjoint_pairs(same_set, uniform_num, tune, expect, pkg,
 @pytest.mark.parametrize("n,rows_per_tile,pipelined", [(320, 8, 1), (1000, 8, 1), (1700, 16, 1), (4600, 32, 1)])
 def test_tile_shape_and_kernel_follow_the_block_size(n, rows_per_tile, pipelined, pkg, coracle):
     """ONE family (every pair has to be walked) at four sizes: the device plan picks 8-row tiles while fewer than ~820
-    sixteen-row tiles hold sharing pairs, 16-row tiles up to ~2800, 32-row tiles beyond (8 waves x 1 / 2 / 4 rows of the
+    sixteen-row tiles hold sharing pairs, 16-row tiles up to ~2400, 32-row tiles beyond (8 waves x 1 / 2 / 4 rows of the
     software-pipelined kernel k_compare_tiled_pf).  Whatever the shape, sampled rows x all columns equal the C oracle, the
     matrix is symmetric and its diagonal is 1 (reference src/lib.rs:470-508)."""
     import torch
