@@ -489,6 +489,28 @@ __device__ __forceinline__ void tiled_walk_row(const uint32_t* A, const uint32_t
   if (WantCC) cc += ccv;
 }
 
+// Wave-wide inclusive prefix sum / maximum in DPP steps (row shifts inside the 16-lane rows, then the last lane of a row
+// broadcast to the following rows): VALU speed -- __shfl_up / __shfl_xor go through the LDS crossbar, ~100 cycles a step,
+// and the two waves that build a stretch's table are what the other six wait for.
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // the maximum, in every lane's return value
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // The next tile of this workgroup (thread 0): a persistent grid pulls tiles off the list (tile times differ: a static split
 // left the chip half idle at the end).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: workgroup b
 // first serves stretch b % 8 of the list, so that the tiles an XCD works on share rows and columns, and helps the other
@@ -764,14 +786,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
         hi = rawp ? rawp[tid] : a.rpart[(size_t)row * (R + 1) + r + mt];
       }
       T[tid] = hi - lo; T[128 + tid] = hi;
-      uint32_t v = tid < kTR ? hi - lo + kPad : 0, incl = v;
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
+      const uint32_t v = tid < kTR ? hi - lo + kPad : 0, incl = wave_incl_scan_add(v);
       T[64 + tid] = incl - v;
-      const uint32_t totA = __shfl(incl, 63);
-      if (tid == 0) ctl[2 * s] = totA > a.capA ? 1u : 0u;
+      if (tid == 63) ctl[2 * s] = incl > a.capA ? 1u : 0u;
     } else if (tid < 128) {
       const uint32_t c = colid[tid - 64];
       uint32_t lo = 0, hi = 0;
@@ -780,8 +797,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
         hi = rawp ? rawp[tid] : a.cpart[(size_t)c * (R + 1) + r + mt];
       }
       T[192 + tid - 64] = hi - lo; T[256 + tid - 64] = hi;
-      uint32_t mx = hi - lo;
-      for (int off = 32; off; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
+      const uint32_t mx = wave_max_u32(hi - lo);
       if (tid == 64) { ctl[2 * s + 1] = ((mx + kPad) * kTB > a.capBt) ? 1u : 0u; ctl[12 + s] = mx; }   // (the longest column segment: issue_stage)
     }
   };
