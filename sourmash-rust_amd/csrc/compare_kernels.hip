@@ -810,7 +810,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
       const int t = w * kRowsPerWave + q;
-      const uint32_t la = T[t], oa = T[64 + t];
+      const uint32_t la = __builtin_amdgcn_readfirstlane(T[t]), oa = __builtin_amdgcn_readfirstlane(T[64 + t]);   // (scalars)
       const uint32_t idx = goff[t] + T[128 + t] - la + (uint32_t)lane;     // (element indices in 32 bits: one 64-bit add per request)
       if ((uint32_t)lane < la) __builtin_amdgcn_global_load_lds(a.rrank + idx, pA + oa, 4, 0, 0);
       for (uint32_t e0 = 64; e0 < la; e0 += 64)                             // (a segment of more than 64 ranks: rare)
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     }
     const uint32_t lb = T[192 + lane];
     const uint32_t idxc = goff[64 + lane] + T[256 + lane] - lb;
-    const uint32_t lbmax = ctl[12 + s];
+    const uint32_t lbmax = __builtin_amdgcn_readfirstlane(ctl[12 + s]);      // (a scalar: the loop is wave-uniform)
     for (uint32_t e = w; e < lbmax; e += WPB)
       if (e < lb) __builtin_amdgcn_global_load_lds(a.crank + (idxc + e), pB + e * kTB, 4, 0, 0);
     if (w < (int)kPad) pB[(lb + w) * kTB + lane] = kSent;      // (waves 0..3: one of the column's four sentinels each)
