@@ -765,6 +765,10 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   const uint32_t stage_dw = a.capA + a.capBt;
 
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (w: a scalar)
+  // What only a tile's set-up and write-out need (the tile list, the keys, offsets, nums, outputs, the pair scope) is read
+  // from the kernel-argument segment where it is used, not carried in scalar registers across the stretch loop (which
+  // spills them into vector lanes: a v_readlane per use)
+  const TiledArgs& ka = *(const TiledArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   // the plan picks a tile height; this instantiation serves one of them -- or none
   if (a.st->skip_tiled || a.st->rpw * 4u != (uint32_t)kTR || !a.st->pf) return;
   const uint32_t ntiles = min(a.st->ntiles, a.tiles_cap);
@@ -859,23 +863,23 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   __builtin_amdgcn_s_waitcnt(0x0f70);   // (vmcnt 0: nothing of the previous tile is still on its way into LDS)
   __syncthreads();
   if (tid == 0) {
-    ctl[8] = tiled_take_tile(a.st, ntiles, nstretch, chunk, steal);
+    ctl[8] = tiled_take_tile(ka.st, ntiles, nstretch, chunk, steal);
     ctl[9] = 0; ctl[10] = 0; ctl[11] = 0;      // the "a pair is short of its cut" flags of three consecutive stretches
   }
   __syncthreads();
   const uint32_t tix = ctl[8];
   if (tix == kNone) break;
-  const uint32_t bi = a.tiles[2 * tix], bj = a.tiles[2 * tix + 1];
+  const uint32_t bi = ka.tiles[2 * tix], bj = ka.tiles[2 * tix + 1];
   if (tid < 64) {
     const uint32_t rs = bi * kTR + tid, cs = bj * kTB + tid;
-    const uint32_t row = (tid < kTR && rs < a.nrows) ? (uint32_t)a.rkey[rs] : kNone;
-    const uint32_t c = cs < a.ncols ? (uint32_t)a.ckey[cs] : kNone;
+    const uint32_t row = (tid < kTR && rs < ka.nrows) ? (uint32_t)ka.rkey[rs] : kNone;
+    const uint32_t c = cs < ka.ncols ? (uint32_t)ka.ckey[cs] : kNone;
     rowid[tid] = row; colid[tid] = c;
     uint32_t n = 0;
-    if (row != kNone) { n = a.row_nums ? a.row_nums[row] : a.num; n = n ? n : kNone; }
+    if (row != kNone) { n = ka.row_nums ? ka.row_nums[row] : ka.num; n = n ? n : kNone; }
     nrowL[tid] = n;
-    goff[tid] = row != kNone ? (uint32_t)a.roff[row] : 0u;
-    goff[64 + tid] = c != kNone ? (uint32_t)a.coff[c] : 0u;
+    goff[tid] = row != kNone ? (uint32_t)ka.roff[row] : 0u;
+    goff[64 + tid] = c != kNone ? (uint32_t)ka.coff[c] : 0u;
   }
   __syncthreads();
   const uint32_t col = colid[lane];
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       }
     } else {
       // ---- rare: one range that does not fit LDS for this tile; merge from global memory
-      if (tid == 0) atomicAdd(a.ovf_steps, 1ull);
+      if (tid == 0) atomicAdd(ka.ovf_steps, 1ull);
       const uint32_t lb = T[192 + lane];
       const uint32_t* B = a.crank + goff[64 + lane] + (T[256 + lane] - lb);
 #pragma unroll
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   for (int q = 0; q < kRowsPerWave; q++) {
     const uint32_t row = rowid[w * kRowsPerWave + q];
     if (row != kNone && col_ok)
-      tiled_write_pair<WantCC>(a, row, col, nrowL[w * kRowsPerWave + q], ucount[q], common[q], WantCC ? cc[q] : 0u);
+      tiled_write_pair<WantCC>(ka, row, col, nrowL[w * kRowsPerWave + q], ucount[q], common[q], WantCC ? cc[q] : 0u);
   }
   }   // tiles of this workgroup
 }
