@@ -1958,6 +1958,43 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
   // choice (k_plan_route, same value) can produce: a tuning value never changes a result or raises
   const uint64_t kWorkCapMax = 1ull << 26;
   const uint64_t comp_limit = std::min<uint64_t>(tune.comp_pairs_limit, kWorkCapMax > ncols ? kWorkCapMax - ncols : 0);
+  // ---- every pair as if it shared nothing but frequent hashes; the compare kernels overwrite the pairs they walk
+  // (with every tile launched nothing would be left: skipped).  It needs nothing the plan makes and is bound by its writes
+  // (800 MB at 10 000 x 10 000), so it runs on the library's second stream beside the plan's small launches and is
+  // waited for before the first compare kernel.
+  const uint64_t np = (uint64_t)nrows * ncols;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;       // (under the device mutex, one device per process)
+  bool fill_pending = false;
+  struct FillGuard {            // an error on the way out must not leave the fill writing into the caller's buffers
+    bool& pending; hipStream_t s2;
+    ~FillGuard() { if (pending) (void)hipStreamSynchronize(s2); }
+  } fill_guard{fill_pending, dev.copy_stream()};
+  if (!(tune.visit_all_tiles && tune.route == kRouteTiled)) {
+    if (!ev_fork) {
+      HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    // (a small block's fill is a few microseconds: not worth two events)
+    const bool beside = np >= (4ull << 20);
+    hipStream_t s2 = beside ? dev.copy_stream() : s;
+    const unsigned long long* fm = D.split ? D.fmask.as<unsigned long long>() : nullptr;
+    const uint32_t* fp = D.split ? D.fpos.as<uint32_t>() : nullptr;
+    if (beside) {
+      HIP_CHECK(hipEventRecord(ev_fork, s));        // what came before on s (the dictionary, the caller's buffers) is done
+      HIP_CHECK(hipStreamWaitEvent(s2, ev_fork, 0));
+    }
+    dev.prof_begin(s2);
+    hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s2, rows.offsets, nrows, cols.offsets, ncols, num,
+                       row_nums, out, fm ? fm + row_lo : nullptr, fp ? fp + (size_t)row_lo * kMaxFreq : nullptr,
+                       fm ? fm + col_lo : nullptr, fp ? fp + (size_t)col_lo * kMaxFreq : nullptr);
+    HIP_CHECK(hipGetLastError());
+    dev.prof_end("compare_fill", s2);
+    if (beside) {
+      HIP_CHECK(hipEventRecord(ev_join, s2));
+      fill_pending = true;
+    }
+  }
+
   T.plan.ensure(sizeof(PlanState));
   PlanState* st = T.plan.as<PlanState>();
   HIP_CHECK(hipMemsetAsync(st, 0, sizeof(PlanState), s));
@@ -1989,35 +2026,17 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
   hipLaunchKernelGGL(k_plan_route, dim3(1), dim3(1), 0, s, st, tune.route, tune.visit_all_tiles, (unsigned long long)comp_limit);
   HIP_CHECK(hipGetLastError());
 
-  // ---- every pair as if it shared nothing but frequent hashes; the compare kernels overwrite the pairs they walk
-  // (with every tile launched nothing would be left: skipped)
-  const uint64_t np = (uint64_t)nrows * ncols;
-  if (!(tune.visit_all_tiles && tune.route == kRouteTiled)) {
-    const unsigned long long* fm = D.split ? D.fmask.as<unsigned long long>() : nullptr;
-    const uint32_t* fp = D.split ? D.fpos.as<uint32_t>() : nullptr;
-    dev.prof_begin(s);
-    hipLaunchKernelGGL(k_fill_disjoint, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, rows.offsets, nrows, cols.offsets, ncols, num,
-                       row_nums, out, fm ? fm + row_lo : nullptr, fp ? fp + (size_t)row_lo * kMaxFreq : nullptr,
-                       fm ? fm + col_lo : nullptr, fp ? fp + (size_t)col_lo * kMaxFreq : nullptr);
-    HIP_CHECK(hipGetLastError());
-    dev.prof_end("compare_fill", s);
-  }
-
-  // ---- per-component pair kernel: one workgroup per (column, <= 32 rows of its component)
+  // ---- per-component pair kernel: one workgroup per (column, <= 32 rows of its component).  Its work list is made here; the
+  // kernel is launched with the tiled ones, after the fill has been waited for (the compare kernels write over what it wrote)
   uint32_t work_cap = 0;
-  if (tune.route != kRouteTiled) {
-    // the route is taken when pairs <= comp_limit: every item holds a pair, every column adds at most one
-    // partly filled item.  (A forced route on a huge block is capped; the overflow is reported.)
-    uint64_t cap = (tune.route == kRouteComponents ? ((uint64_t)ncols * ((nrows + kRowsPerItem - 1) / kRowsPerItem)) : comp_limit) + ncols;
-    if (cap > kWorkCapMax) cap = kWorkCapMax;
-    work_cap = (uint32_t)cap;
-    T.cnt.ensure((size_t)ncols * 4);
-    T.work.ensure((size_t)work_cap * sizeof(CompWork));
-    hipLaunchKernelGGL(k_comp_count, dim3((ncols + 255) / 256), dim3(256), 0, s, ncols, row_lo_s, row_hi_s, same ? 1u : 0u,
-                       T.cnt.as<uint32_t>(), st);
-    exclusive_scan_u32_dev(T.cnt.as<uint32_t>(), ncols, &st->nwork, dev.scratch, s);
-    hipLaunchKernelGGL(k_comp_fill, dim3((ncols + 255) / 256), dim3(256), 0, s, ckey, ncols, row_lo_s, row_hi_s, same ? 1u : 0u,
-                       T.cnt.as<uint32_t>(), reinterpret_cast<CompWork*>(T.work.ptr), work_cap, st);
+  bool comp_planned = false;
+  auto join_fill = [&] {
+    if (fill_pending) HIP_CHECK(hipStreamWaitEvent(s, ev_join, 0));
+    fill_pending = false;
+  };
+  auto launch_comp = [&] {
+    if (!comp_planned) return;
+    comp_planned = false;
     const uint32_t col_max = D.max_len;
     const bool q_lds = col_max <= 8192;
     const size_t lds = q_lds ? (size_t)(col_max ? col_max : 1) * 8 : 16;
@@ -2031,7 +2050,23 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
 #undef SMH_CC
     HIP_CHECK(hipGetLastError());
     dev.prof_end("compare_comp", s);
+  };
+  if (tune.route != kRouteTiled) {
+    // the route is taken when pairs <= comp_limit: every item holds a pair, every column adds at most one
+    // partly filled item.  (A forced route on a huge block is capped; the overflow is reported.)
+    uint64_t cap = (tune.route == kRouteComponents ? ((uint64_t)ncols * ((nrows + kRowsPerItem - 1) / kRowsPerItem)) : comp_limit) + ncols;
+    if (cap > kWorkCapMax) cap = kWorkCapMax;
+    work_cap = (uint32_t)cap;
+    T.cnt.ensure((size_t)ncols * 4);
+    T.work.ensure((size_t)work_cap * sizeof(CompWork));
+    hipLaunchKernelGGL(k_comp_count, dim3((ncols + 255) / 256), dim3(256), 0, s, ncols, row_lo_s, row_hi_s, same ? 1u : 0u,
+                       T.cnt.as<uint32_t>(), st);
+    exclusive_scan_u32_dev(T.cnt.as<uint32_t>(), ncols, &st->nwork, dev.scratch, s);
+    hipLaunchKernelGGL(k_comp_fill, dim3((ncols + 255) / 256), dim3(256), 0, s, ckey, ncols, row_lo_s, row_hi_s, same ? 1u : 0u,
+                       T.cnt.as<uint32_t>(), reinterpret_cast<CompWork*>(T.work.ptr), work_cap, st);
+    comp_planned = true;
   }
+  if (tune.route == kRouteComponents) { join_fill(); launch_comp(); }       // (no tiled part follows)
 
   // ---- tiled kernel: tile list, launch
   const int wpb = ex.wpb, minw = ex.minw;
@@ -2087,6 +2122,8 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     a.capBt = ex.capB * kTB;  // columns up to 47 elements in one range
     a.ovf_steps = &st->ovf_steps;
     a.out = out;
+    join_fill();
+    launch_comp();
     [[maybe_unused]] const size_t lds = (size_t)(520 + a.capA + a.capBt) * 4;      // (the plain kernel: experiments build)
     [[maybe_unused]] const unsigned grid = (unsigned)dev.cu_count() * 8;          // a multiple of 8: one stretch of the list per XCD
     dev.prof_begin(s);
