@@ -269,7 +269,10 @@ def main():
         uni = D.union_across_ranks(mh)
         barrier()
         union_s = max_over_ranks(time.perf_counter() - t0)
-        union = {"union_ms": union_s * 1e3, "hashes": len(uni), "parts": world,
+        vt = torch.tensor([1 if D.verify_union(mh, uni) else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(vt, op=dist.ReduceOp.MIN)
+        union = {"union_ms": union_s * 1e3, "hashes": len(uni), "parts": world, "verified": bool(vt.item()),
+                 "verified_what": "on every rank, in HBM: the union holds each of the rank's own hashes, with a count >= the rank's own",
                  "what": "the %d ranks' partial sketches -> one sketch on every rank, in HBM (all-gather of the hash arrays over RCCL, "
                          "then per part a union by rank arithmetic and two scatters; KmerMinHash::merge semantics, "
                          "reference src/lib.rs:307-403).  Not part of `value`" % world}
@@ -377,11 +380,21 @@ def main():
             okt = torch.tensor([1 if diag_ok else 0], dtype=torch.int64, device="cuda")
             if world > 1:
                 dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            # ... and, untimed: every output once more through the sharded path, then ~16 sampled rows of every rank's block
+            # recomputed by that rank ALONE (its own world-1 dictionary, ownership 0: every pair of the row walked locally,
+            # nothing mirrored or received) and compared bit for bit -- so that the first run over real RCCL says by itself
+            # whether the sliced dictionary, the ownership rule and the exchange of the mirrored blocks were right
+            names = ("jaccard", "common", "size", "count_common", "containment")
+            full = D.compare_matrix_sharded(mine, n_sig, NUM, want=names)
+            same_again = bool((full["jaccard"] == out["jaccard"]).all().item()) if hi > lo else True
+            ver = D.verify_exchange(mine, n_sig, NUM, full, names=names, k_rows=16)
+            del full
             st = MX.last_stats()
             walked = min(st["tiles_visited"] * st["pairs_per_tile"], (hi - lo) * n_sig)   # pairs walked on this rank
             kname = "compare_tiled" if st["route"] == "tiled" else "compare_comp"
             kms = kern[kname][0] / max(1, kern[kname][1])
             rec = {"seconds": cdt, "pairs_per_s": n_sig * n_sig / cdt, "self_jaccard_is_1": bool(okt.item()),
+                   "exchange_verified": bool(ver["ok"] and same_again), "verified_rows_rank0": ver["rows_checked"],
                    "route": st["route"], "tiles_visited": st["tiles_visited"], "tiles_total": st["tiles_total"],
                    "pairs_per_tile": st["pairs_per_tile"], "rank0_pairs_walked": walked,
                    "rank0_kernel": "k_compare_" + (("tiled_pf" if st.get("pipelined") else "tiled") if st["route"] == "tiled" else "comp"), "rank0_kernel_ms": kms,
@@ -444,6 +457,11 @@ def main():
                                "(j - i) mod N < N/2, every rank walks the pairs its rows own and the mirrored blocks are exchanged "
                                "(world 1: upper triangle + mirror writes).  pairs/s counts ORDERED pairs delivered (N^2)",
                    "self_jaccard_is_1": all(v["self_jaccard_is_1"] for v in head.values()),
+                   "exchange_verified": all(v["exchange_verified"] for v in head.values()),
+                   "exchange_verified_what": "per collection and rank, untimed: ~16 sampled rows of the rank's block (first, last, seeded "
+                                             "places) recomputed by the rank alone -- a dictionary of its own, every pair walked locally -- "
+                                             "equal bit for bit to the block after the exchange, all five outputs; conjunction over the ranks "
+                                             "(distributed.verify_exchange; per pair the contract is reference src/lib.rs:470-508)",
                    "collection": "50 families of related signatures (SURVEY.md 8d): pairs across families share no hash and are "
                                  "filled without being walked (DESIGN.md 3.4) -- a property of the collection, not of the kernel",
                    "families": head["families"],
@@ -575,6 +593,11 @@ def main():
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    # a matrix that fails its own check is not a result: the line above says which check, the exit code says so too
+    if compare is not None and rank == 0 and not (compare["exchange_verified"] and compare["self_jaccard_is_1"]):
+        sys.exit(3)
+    if union is not None and rank == 0 and not union["verified"]:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -213,6 +213,8 @@ typedef struct SmhCompareStats {
   uint64_t lds_overflow_steps;  /* tiled: (tile, range) steps merged from global memory instead of the LDS stage */
   uint32_t frequent_hashes;     /* hashes set aside as frequent in this block (0 = none, or too many to set aside) */
   uint32_t pipelined;           /* tiled: 1 = the software-pipelined kernel walked the tiles (blocks that do not fill the chip for long) */
+  uint32_t span_halvings;       /* pipelined kernel: stretches whose speculatively grown span did not fit LDS and was rebuilt, halved */
+  uint32_t prefetched_after_halving; /* ... tables built from prefetched boundary crossings later in a tile that had such a rebuild */
 } SmhCompareStats;
 void smh_compare_last_stats(SmhCompareStats *out);
 

@@ -25,7 +25,8 @@ class SmhCompareTuning(C.Structure):
 class SmhCompareStats(C.Structure):
     _fields_ = [("route", C.c_uint32), ("rows_per_tile", C.c_uint32), ("tiles_visited", C.c_uint64),
                 ("tiles_total", C.c_uint64), ("pairs_per_tile", C.c_uint64), ("lds_overflow_steps", C.c_uint64),
-                ("frequent_hashes", C.c_uint32), ("pipelined", C.c_uint32)]
+                ("frequent_hashes", C.c_uint32), ("pipelined", C.c_uint32),
+                ("span_halvings", C.c_uint32), ("prefetched_after_halving", C.c_uint32)]
 
 
 def build(force=False):

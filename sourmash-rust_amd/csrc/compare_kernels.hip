@@ -399,6 +399,9 @@ struct PlanState {
   uint32_t count16;              // tiles that hold sharing pairs at the 16-row geometry
   uint32_t next_tile[8];         // tiled: tiles handed out so far, per XCD stretch of the list
   uint32_t pf;                   // tiled: the software-pipelined kernel walks the tiles (k_compare_tiled_pf), not the plain one
+  uint32_t halvings;             // pipelined kernel: stretches whose speculative span did not fit and was rebuilt, halved, with plain loads
+  uint32_t pf_after_halving;     // ... tables built from PREFETCHED boundary crossings later in a tile that had such a rebuild
+  uint32_t bad_tables;           // a segment that would end before it starts (never, unless a table was built from crossings of the wrong boundary)
 };
 // What the owner of one slice of hash space finds in it (see "collection dictionary" below)
 struct RangeState {
@@ -788,6 +791,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       if (row != kNone) {
         lo = first ? a.rpart[(size_t)row * (R + 1) + r] : P[128 + tid];
         hi = rawp ? rawp[tid] : a.rpart[(size_t)row * (R + 1) + r + mt];
+        if (hi < lo) { hi = lo; ka.st->bad_tables = 1; }      // (see "The fault of round 3" in DESIGN.md 3.4: reported, never followed)
       }
       T[tid] = hi - lo; T[128 + tid] = hi;
       const uint32_t v = tid < kTR ? hi - lo + kPad : 0, incl = wave_incl_scan_add(v);
@@ -799,6 +803,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       if (c != kNone) {
         lo = first ? a.cpart[(size_t)c * (R + 1) + r] : P[256 + tid - 64];
         hi = rawp ? rawp[tid] : a.cpart[(size_t)c * (R + 1) + r + mt];
+        if (hi < lo) { hi = lo; ka.st->bad_tables = 1; }
       }
       T[192 + tid - 64] = hi - lo; T[256 + tid - 64] = hi;
       const uint32_t mx = wave_max_u32(hi - lo);
@@ -914,6 +919,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   __builtin_amdgcn_s_waitcnt(0x0f70);
   __syncthreads();
   uint32_t s0 = 0, s1 = 1, s2 = 2;
+  bool halved = false;    // (this tile had a stretch rebuilt with a halved span: for the record only)
 
   while (true) {
     // ---- here: table s0 = stretch `it` (its ranks in stage it & 1, unless ovf0), table s1 = the next one (mt1 != 0), the
@@ -922,7 +928,12 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     uint32_t r2 = r1 + mt1, mt2 = 0;
     if (mt1 && r2 < R) {
       mt2 = next_span(mt1, cool, r2);
-      build_table(s2, s1, r2, mt2, false, raw_at == r2 + mt2 ? raw + raw_slot * 128 : nullptr);
+      // Prefetched crossings are used for the table that ENDS at the boundary they were requested for, and for no other:
+      // where a row or column crosses boundary b is a function of b alone, so `raw_at == r2 + mt2` is exact whatever route
+      // (spans grown, halved, rebuilt) led to r2 and mt2; a table that ends anywhere else reads its ends with plain loads
+      const bool use_raw = raw_at == r2 + mt2;
+      if (halved && use_raw && tid == 0) atomicAdd(&ka.st->pf_after_halving, 1u);
+      build_table(s2, s1, r2, mt2, false, use_raw ? raw + raw_slot * 128 : nullptr);
       if (r2 + mt2 < R) {
         uint32_t c2 = cool;
         raw_at = r2 + mt2 + next_span(mt2, c2, r2 + mt2);     // (if table s2 turns out not to fit, this is not the boundary asked for later)
@@ -974,6 +985,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       __syncthreads();
       mt2 >>= 1; cool = 16;
       ovf2 = settle_table(s2, s1, r2, mt2, false, cool);
+      if (tid == 0) atomicAdd(&ka.st->halvings, 1u);
+      halved = true;
     }
     it++;
     r0 = r1; mt0 = mt1; ovf0 = ovf1;
@@ -2192,6 +2205,9 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     rec.pairs_per_tile = (uint64_t)tr * kTB;
     rec.lds_overflow_steps = h.ovf_steps;
     rec.pipelined = h.pf;
+    rec.span_halvings = h.halvings;
+    rec.prefetched_after_halving = h.pf_after_halving;
+    if (h.bad_tables) throw_internal("compare block: a range table of the tiled kernel was inconsistent (segment end before its start)");
   }
   rec.frequent_hashes = D.split ? hd[1] : 0;
   set_stats(rec);

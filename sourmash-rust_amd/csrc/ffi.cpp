@@ -939,6 +939,8 @@ void smh_compare_last_stats(SmhCompareStats* out) {
   out->lds_overflow_steps = st.lds_overflow_steps;
   out->frequent_hashes = st.frequent_hashes;
   out->pipelined = st.pipelined;
+  out->span_halvings = st.span_halvings;
+  out->prefetched_after_halving = st.prefetched_after_halving;
 }
 void smh_compare_get_tuning(SmhCompareTuning* out) {
   if (!out) return;

@@ -196,6 +196,8 @@ struct CompareStats {                      // of the last block compare
   uint64_t lds_overflow_steps = 0;         // tiled: (tile, range) steps merged from global memory instead of LDS
   uint32_t frequent_hashes = 0;            // hashes set aside as frequent (decided from per-sketch positions, not walked)
   uint32_t pipelined = 0;                  // tiled: k_compare_tiled_pf walked the tiles
+  uint32_t span_halvings = 0;              // pipelined kernel: stretches rebuilt with a halved span (their speculative span did not fit LDS)
+  uint32_t prefetched_after_halving = 0;   // ... tables built from prefetched crossings later in a tile that had such a rebuild
 };
 void compare_set_tuning(const CompareTuning& t);
 CompareTuning compare_get_tuning();

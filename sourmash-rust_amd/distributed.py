@@ -298,6 +298,83 @@ def compare_matrix_sharded(local_sigs, n_total, num, want=("jaccard",), engine=N
     return out
 
 
+def sample_row_stretches(lo, hi, k_rows, seed=0):
+    """Stretches [a, b) of a rank's rows [lo, hi) that verify_exchange recomputes: the first and the last rows of the block
+    (where the ownership rule changes hands between neighbouring ranks) and stretches at seeded places in between;
+    about k_rows rows in all, in pieces of at most 4."""
+    n = hi - lo
+    if n <= 0 or k_rows <= 0:
+        return []
+    if n <= k_rows:
+        return [(lo, hi)]
+    piece = max(1, min(4, k_rows // 4))
+    starts = {lo, hi - piece}
+    rng = np.random.RandomState(seed * 7919 + lo)
+    while len(starts) * piece < k_rows:
+        starts.add(lo + int(rng.randint(0, n - piece + 1)))
+    return [(a, a + piece) for a in sorted(starts)]
+
+
+def verify_exchange(local_sigs, n_total, num, out, names=None, k_rows=16, engine_factory=None, group=None, seed=0):
+    """Is this rank's row block -- after the exchange of the mirrored blocks -- what the rank would have computed alone?
+    Every rank all-gathers the signatures once more, builds the dictionary of the whole collection BY ITSELF (world 1: no
+    shares, no slices), recomputes about `k_rows` sampled rows of its block with ownership 0 (every pair of the row walked
+    here, nothing mirrored, nothing received) and compares them bit for bit with the same rows of `out`; the verdict is
+    the conjunction over the ranks (all-reduce MIN).  Per pair the contract is KmerMinHash::compare / count_common
+    (reference src/lib.rs:470-508, 428-436).  What a wrong mirror exchange, a wrong ownership rule or a wrong sliced
+    dictionary would change, this catches on the first real RCCL run; it costs one extra dictionary per rank and is never
+    inside a timed region.  -> {"ok": bool, "rows_checked": int (this rank), "names": [...]}"""
+    import torch
+    comm = _Comm(group)
+    world, rank = comm.world, comm.rank
+    lo, hi, per = shard_range(n_total, world, rank)
+    names = [k for k in (names or out.keys()) if k != "containment" or "containment" in out]
+    allsigs = comm.all_gather(local_sigs.contiguous())
+    eng = (engine_factory or HipEngine)()
+    eng.begin(allsigs, n_total, 1, 0)
+    eng.finish(None)
+    ok, rows = True, 0
+    for a, b in sample_row_stretches(lo, hi, k_rows, seed):
+        alone = eng.compare(a, b, num, tuple(names), 0)
+        for k in names:
+            mine = out[k][a - lo:b - lo]
+            same = (alone[k] == mine) | ((alone[k] != alone[k]) & (mine != mine))      # NaN == NaN (containment of an empty row)
+            ok = ok and bool(same.all().item())
+        rows += b - a
+    eng.close()
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cpu" if comm.stage or not local_sigs.is_cuda else local_sigs.device)
+    if comm.on and world > 1:
+        comm.dist.all_reduce(flag, op=comm.dist.ReduceOp.MIN, group=group)
+    return {"ok": bool(flag.item()), "rows_checked": rows, "names": list(names)}
+
+
+def verify_union(mh, uni):
+    """Does the united sketch `uni` hold every hash of this rank's partial sketch `mh`, with a count at least this rank's?
+    Checked where both live, in HBM (searchsorted on the exported arrays; nothing is copied to the host but the verdict).
+    KmerMinHash::merge of scaled sketches is a set union whose abundances add (reference src/lib.rs:307-403)."""
+    import torch
+    track = mh.track_abundance
+    n_own, n_uni = mh.export_dev(), uni.export_dev()
+    if n_own == 0:
+        return True
+    if n_uni < n_own:
+        return False
+
+    def arrays(s, n):
+        m = torch.empty(n, dtype=torch.int64, device="cuda")
+        a = torch.empty(n, dtype=torch.int64, device="cuda") if track else None
+        s.export_dev(m, a)
+        return m ^ (-1 << 63), a            # unsigned order as signed order
+
+    om, oa = arrays(mh, n_own)
+    um, ua = arrays(uni, n_uni)
+    at = torch.searchsorted(um, om).clamp_(max=n_uni - 1)
+    ok = bool((um[at] == om).all().item())
+    if ok and track:
+        ok = bool((ua[at] >= oa).all().item())
+    return ok
+
+
 def simulate_sharded(allsigs, n_total, num, world, want=("jaccard",), engine_factory=None, symmetric=True):
     """The same steps as compare_matrix_sharded for `world` ranks run one after the other in ONE
     process (no process group): the collectives become concatenations and list shuffles, everything
@@ -343,21 +420,43 @@ def shard_records(n_records, world, rank):
 def union_across_ranks(mh, group=None, parts=None):
     """The ranks' partial SCALED sketches of one input -> one sketch, on every rank, without leaving HBM: all-gather of the
     sizes, ONE all-gather of the padded hash arrays (and one of the abundances), then the parts are united on the device
-    (smh_sketch_absorb_dev: rank arithmetic + scatters per part, no sort, no host copy).  KmerMinHash::merge semantics for
-    scaled sketches (reference src/lib.rs:307-403): set union, abundances add -- exact.
+    (smh_sketch_absorb_dev: rank arithmetic + scatters per part, no sort, no host copy).  The result is what ONE sketch
+    fed all the ranks' records would hold -- the set union of the parts, abundances added (what add_hash does hash by hash,
+    reference src/lib.rs:192-245; for two well-formed scaled sketches also what KmerMinHash::merge gives, src/lib.rs:307-403,
+    except merge's quirk Q5: merging untracked sketches leaves `abunds = Some(...)`, the union here stays untracked).
+    The parts must agree in what check_compatible compares (ksize, DNA/protein, max_hash, seed: src/lib.rs:176-190) and in
+    track_abundance: the parameters travel with the sizes in the first (small) all-gather, and a mismatch raises the
+    reference's Mismatch* error on EVERY rank before any data collective.
     `parts` (tests): a list of sketches standing in for the other ranks' (no process group needed)."""
     import torch
+    from .errors import SourmashError
     from .minhash import KmerMinHash
     assert mh.num == 0 and mh.max_hash > 0, "the device union is for scaled sketches"
     comm = _Comm(group)
     track = mh.track_abundance
     locals_ = parts if parts is not None else [mh]
-    sizes_local = [p.export_dev() for p in locals_]
+
+    def params(p):
+        # what check_compatible looks at (reference src/lib.rs:176-190), + whether abundances are tracked (it decides
+        # whether a rank takes part in the second all-gather: a mismatch there would hang the job, not fail it)
+        mx = p.max_hash
+        return [p.export_dev(), p.ksize, 1 if p.is_protein else 0, p.seed & 0xFFFFFFFF, p.seed >> 32,
+                mx & 0xFFFFFFFF, mx >> 32, 1 if p.track_abundance else 0]
+
+    table = [params(p) for p in locals_]
     if parts is None and comm.world > 1:
-        t = torch.tensor([sizes_local[0]], dtype=torch.int64, device="cuda")
-        sizes = [int(x) for x in comm.all_gather(t).cpu().tolist()]
-    else:
-        sizes = sizes_local
+        t = torch.tensor(table, dtype=torch.int64, device="cuda")
+        table = comm.all_gather(t).cpu().tolist()
+    # every rank sees the same table, so every rank raises the same error -- before any data collective
+    mine = params(mh)
+    for r, row in enumerate(table):
+        for col, code, what in ((1, 101, "ksize"), (2, 102, "DNA/protein"), (5, 103, "max_hash"), (6, 103, "max_hash"),
+                                (3, 104, "seed"), (4, 104, "seed")):
+            if row[col] != mine[col]:
+                raise SourmashError(code, "union_across_ranks: part %d differs in %s" % (r, what))
+        if row[7] != mine[7]:
+            raise SourmashError(3, "union_across_ranks: part %d differs in track_abundance" % r)
+    sizes = [int(row[0]) for row in table]
     cap = max(max(sizes), 1)
 
     def padded(p, want_ab):

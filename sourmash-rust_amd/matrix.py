@@ -31,7 +31,8 @@ def last_stats():
     names = {v: k for k, v in ROUTES.items()}
     return {"route": names.get(st.route, "none"), "rows_per_tile": st.rows_per_tile, "tiles_visited": st.tiles_visited,
             "tiles_total": st.tiles_total, "pairs_per_tile": st.pairs_per_tile, "lds_overflow_steps": st.lds_overflow_steps,
-            "frequent_hashes": st.frequent_hashes, "pipelined": st.pipelined}
+            "frequent_hashes": st.frequent_hashes, "pipelined": st.pipelined,
+            "span_halvings": st.span_halvings, "prefetched_after_halving": st.prefetched_after_halving}
 
 
 def compare_block(rows, cols, want=("jaccard",)):

@@ -63,7 +63,7 @@ class OracleEngine:
         pass
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, q, broken=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -81,8 +81,26 @@ def _worker(rank, world, port, n_total, q):
     local[: hi - lo] = synth.family_signatures(lo, hi, num=num, n_families=3, pool=300, private=60, seed=5)
     local_t = torch.from_numpy(local.view(np.int64))
 
+    if broken == "no_apply":          # the received blocks are dropped: the poisoned entries stay
+        D.mirror_apply = lambda *a, **k: None
+    elif broken == "shifted":         # every received block lands one row too low
+        good = D.mirror_apply
+
+        def shifted(out, recv, blocks, rank, n_total):
+            good(out, [torch.roll(t.reshape(blocks[rank][1] - blocks[rank][0], -1), 1, 0).reshape(-1) if t.numel() else t for t in recv],
+                 blocks, rank, n_total)
+        D.mirror_apply = shifted
     want = ("jaccard", "common", "size", "count_common", "containment")
     out = D.compare_matrix_sharded(local_t, n_total, num, want=want, engine=OracleEngine(coracle))
+    # the self-check bench.py runs at N > 1: sampled rows recomputed by this rank alone (ownership 0, its own dictionary)
+    ver = D.verify_exchange(local_t, n_total, num, out, names=("jaccard", "common", "size", "count_common"), k_rows=4,
+                            engine_factory=lambda: OracleEngine(coracle))
+    if broken:
+        q.put((rank, ver))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    assert ver["ok"] and ver["rows_checked"] >= min(4, hi - lo), ver
     # and without the symmetric split: every pair of the row block computed locally, no all-to-all
     out_ns = D.compare_matrix_sharded(local_t, n_total, num, want=("jaccard",), engine=OracleEngine(coracle), symmetric=False)
     assert bool((out_ns["jaccard"] == out["jaccard"]).all())
@@ -146,6 +164,38 @@ def test_row_sharded_matrix_and_sketch_union_gloo(world, n_total, coracle):
                 part.mins_push(int(h)); part.abunds_push(int(c))
             merged.merge(part)
         assert merged.mins == whole.mins and merged.abunds == whole.abunds
+
+
+@pytest.mark.parametrize("broken", ["no_apply", "shifted"])
+def test_a_broken_mirror_exchange_is_caught_by_verify_exchange(broken, coracle):
+    """bench.py's N > 1 self-check (distributed.verify_exchange) must say NO, on every rank, when the exchange of the
+    mirrored blocks is wrong: here mirror_apply is replaced by one that drops the received blocks, or shifts them by a row."""
+    import torch.multiprocessing as mp
+    world, n_total = 2, 12
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, broken)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1]["ok"] is False for r in res), res          # the verdict is the conjunction over the ranks
+    assert all(r[1]["rows_checked"] >= 4 for r in res)
+
+
+def test_sample_row_stretches():
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    load_package()
+    from sourmash_rust_amd import distributed as D
+    assert D.sample_row_stretches(5, 5, 16) == [] and D.sample_row_stretches(5, 9, 16) == [(5, 9)]
+    st = D.sample_row_stretches(1250, 2500, 16)
+    assert st[0][0] == 1250 and st[-1][1] == 2500 and sum(b - a for a, b in st) >= 16
+    assert all(1250 <= a < b <= 2500 for a, b in st) and st == D.sample_row_stretches(1250, 2500, 16)
 
 
 def test_pair_ownership_rule():

@@ -1,5 +1,6 @@
-"""The N>1 path of bench.py on real hardware: two ranks that share the one GPU of the test box
-(BENCH_SHARE_GPU=1) with gloo standing in for RCCL.  Exercises what the world-size-1 run never
+"""The N>1 path of bench.py on real hardware.  On the 1-GPU test box: ranks that share the one GPU
+(BENCH_SHARE_GPU=1) with gloo standing in for RCCL; on a box with at least as many GPUs as ranks the same tests run
+over `nccl` (= RCCL), one GPU per rank (`_multi_gpu_env`).  Exercises what the world-size-1 run never
 reaches: record sharding by rank, the all-gather of the signatures, row-block compare against the
 gathered columns, the cross-rank reductions of the timing and of the per-rank diagonal check."""
 import json
@@ -22,8 +23,17 @@ def _free_port():
     return port
 
 
+def _multi_gpu_env(world):
+    """RCCL and one GPU per rank when the box has the GPUs; else every rank on cuda:0 and gloo.  (device_count() does not
+    initialise the GPU in this process.)"""
+    import torch
+    if torch.cuda.device_count() >= world:
+        return dict(os.environ)
+    return dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+
+
 def test_bench_two_ranks_sharing_the_gpu(pkg):
-    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+    env = _multi_gpu_env(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
            "--gb", "0.2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--compare-n", "601"]
@@ -39,7 +49,11 @@ def test_bench_two_ranks_sharing_the_gpu(pkg):
     assert d["cpu_baseline"] is None                                      # reported at N=1 only
     # the ranks' partial sketches united on the device, timed on its own (never part of `value`)
     u = d["union_across_ranks"]
-    assert u["parts"] == 2 and u["hashes"] > d["config"]["retained_hashes"] and u["union_ms"] > 0
+    assert u["parts"] == 2 and u["hashes"] > d["config"]["retained_hashes"] and u["union_ms"] > 0 and u["verified"] is True
+    # the self-check of the exchange: sampled rows recomputed by every rank alone, equal bit for bit (distributed.verify_exchange)
+    assert c["exchange_verified"] is True
+    for key in ("families", "one_component", "one_family"):
+        assert c[key]["exchange_verified"] is True and c[key]["verified_rows_rank0"] >= 16
     assert "strong" in c["scaling"] and "used" in c["symmetry"]
     assert set(c["families"]["rank0_phase_ms"]) >= {"all_gather_signatures", "dictionary_slice", "all_gather_shares", "compare", "exchange_mirrors"}
 
@@ -47,7 +61,7 @@ def test_bench_two_ranks_sharing_the_gpu(pkg):
 def test_bench_gpus_2_with_no_launcher_around_it(pkg):
     """`python bench.py --gpus 2` exactly as typed (no torchrun wrapper): bench.py starts its own two
     ranks as child processes before anything touches the GPU and relays rank 0's single JSON line."""
-    env = dict(os.environ, BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo")
+    env = _multi_gpu_env(2)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--gb", "0.1", "--steps", "1", "--warmup", "0", "--compare-n", "300"]
@@ -57,7 +71,7 @@ def test_bench_gpus_2_with_no_launcher_around_it(pkg):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["compare"]["self_jaccard_is_1"] is True
-    assert d["compare"]["one_component"]["self_jaccard_is_1"] is True
+    assert d["compare"]["one_component"]["self_jaccard_is_1"] is True and d["compare"]["exchange_verified"] is True
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -75,7 +89,8 @@ def test_sharded_matrix_over_a_real_process_group(world, pkg):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sharded check ok" in r.stdout and "DIFFERENT" not in r.stdout
-    assert r.stdout.count("equal") == (13 if world == 2 else 12)
+    assert r.stdout.count("equal") == (16 if world == 2 else 15)        # 4 outputs + verify_exchange per collection (+ the union)
+    assert r.stdout.count("verify_exchange world %d: equal" % world) == 3
     if world == 2:
         # ... and the sketch side: 1 GB per rank through the protein arm with abundances, the partial sketches united across
         # the ranks on the device (one all-gather of the padded arrays) == the sketch of the 2 GB on one rank
