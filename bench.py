@@ -46,6 +46,9 @@ K = 31
 MAX_HASH = 18446744073709552       # round((2^64-1)/1000): scaled=1000
 REC_LEN = 1_000_000
 NUM = 2000                         # signature size of the compare matrix (configs[2], [3])
+PROT_K = 27                        # configs[4]: protein arm, ksize=27 = windows of 9 residues
+PROT_SEED = 5                      # generator seed of the C5 input
+PROT_WINDOWS_PER_REC = sum(2 * max(0, (REC_LEN - f) // 3 - PROT_K // 3 + 1) for f in range(3))   # six frames
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 256 * 4                    # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 VALU_CYCLES = 2.0                  # ... a wave64 VALU instruction issues over 2 cycles
@@ -87,6 +90,21 @@ def cpu_worker(argv):
             if spent >= budget:
                 break
         np.save(out_path, o.mins_np())
+        print(json.dumps({"records": done, "seconds": spent}))
+    elif kind == "protein":
+        # BASELINE configs[4], a sample of one rank's share: six-frame translation, ksize=27 (9 residues), scaled, abundances
+        first, last, budget = int(argv[2]), int(argv[3]), float(argv[4])
+        o = coracle.MinHash(0, PROT_K, True, 42, MAX_HASH, True)
+        done, spent = 0, 0.0
+        for r in range(first, last):
+            rec = bytes(coracle.synth_dna(r * REC_LEN, REC_LEN, PROT_SEED, 0))
+            t0 = time.perf_counter()
+            o.add_sequence(rec, True)
+            spent += time.perf_counter() - t0
+            done += 1
+            if spent >= budget:
+                break
+        np.save(out_path, np.stack([o.mins_np(), o.abunds_np()]))
         print(json.dumps({"records": done, "seconds": spent}))
     elif kind == "config0":
         # BASELINE configs[0]: 1 MB, k=31, num=500, compare to itself (reference tests/minhash.rs path)
@@ -141,6 +159,7 @@ def collection(kind_id, lo, hi):
 def run_workers(specs):
     """specs: list of argv lists.  Starts them all at once, returns [(parsed json, output path)]."""
     tmp = tempfile.mkdtemp(prefix="smh_cpu_")
+    TMP_DIRS.append(tmp)
     procs = []
     for i, spec in enumerate(specs):
         out = os.path.join(tmp, "w%d.npy" % i)
@@ -166,6 +185,9 @@ def run_workers(specs):
     return res
 
 
+TMP_DIRS = []          # scratch directories of the CPU-baseline workers; removed when the line has been printed
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks as fresh child
     processes (this process has not touched the GPU), relay their output, exit with their code."""
@@ -189,6 +211,7 @@ def main():
     ap.add_argument("--compare-n", type=int, default=0, help="signatures in the matrix (0 = by --gpus)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-core sketch sample (others scale with it)")
     ap.add_argument("--no-compare", action="store_true")
+    ap.add_argument("--protein-gb", type=float, default=12.5, help="GB of DNA per GPU through the protein arm (configs[4]: 100 GB / 8 GPUs; 0 = skip)")
     ap.add_argument("--host-gb", type=float, default=2.0, help="GB of the workload also timed from HOST memory (PCIe-inclusive; 0 = skip)")
     args = ap.parse_args()
 
@@ -335,6 +358,84 @@ def main():
                                                    "label": "VALU issue time of the kernel's instruction mix at the measured issue rates "
                                                             "(profiles/r02_instr_rates.txt); what is left is attributed in DESIGN.md section 7"}
 
+    # ---------------------------------------------------------------- protein arm (configs[4], one rank's share)
+    protein, pseq, poffsets = None, None, None
+    if args.protein_gb > 0:
+        pn_rec = max(1, int(round(args.protein_gb * 1e9 / REC_LEN)))
+        ptotal = pn_rec * REC_LEN
+        pseq = torch.empty(ptotal, dtype=torch.uint8, device="cuda")
+        assert L.smh_synth_dna_dev(C.c_void_p(pseq.data_ptr()), rank * ptotal, ptotal, PROT_SEED, 0, C.c_void_p(stream)) == 0
+        poffsets = np.arange(pn_rec + 1, dtype=np.uint64) * np.uint64(REC_LEN)
+
+        def protein_step():
+            m = pkg.KmerMinHash(0, PROT_K, True, 42, MAX_HASH, True)
+            m.add_sequences_dev(pseq.data_ptr(), ptotal, poffsets, True, stream)
+            return m
+
+        for _ in range(max(1, args.warmup)):
+            protein_step()
+        L.smh_profile_reset()
+        L.smh_profile_enable(1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pmh = protein_step()
+        barrier()
+        pdt = max_over_ranks(time.perf_counter() - t0)
+        L.smh_profile_enable(0)
+        pms, plaunch = C.c_double(), C.c_uint64()
+        L.smh_profile_get(b"protein_fused", C.byref(pms), C.byref(plaunch))
+        pk_ms = pms.value / max(1, plaunch.value)
+        p_retained = len(pmh)
+        windows_per_step = pn_rec * PROT_WINDOWS_PER_REC
+        # algorithmic bytes: 1 B read per base = 0.5 B per window, + 8 B per candidate hash written
+        p_bytes = ptotal + 8.0 * p_retained
+        p_ach = p_bytes / (pk_ms * 1e-3) / 1e9 if pk_ms > 0 else 0.0
+        ppmc = None
+        for name in ("r04_pmc_protein_fused.json", "r03_pmc_protein_fused.json"):
+            try:
+                ppmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                ppmc["_file"] = name
+                break
+            except Exception:
+                continue
+        p_valu = None
+        if ppmc and pk_ms > 0 and abs(ptotal - 12.5e9) < 1 and plaunch.value == args.steps:
+            vi = ppmc["valu_insts_per_64_positions"]
+            floor = ptotal / 64.0 * vi * VALU_CYCLES / (SIMDS * MAX_CLOCK_HZ) * 1e3
+            p_valu = {"valu_insts_per_64_positions": vi, "floor_ms": floor, "frac": floor / pk_ms,
+                      "label": "VALU issue floor (2 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz) for the kernel's measured "
+                               "instruction count: two murmur hashes per position (forward and reverse-complement window)",
+                      "source": "profiles/%s (separate rocprofv3 --pmc passes, committed; not measured in this run)" % ppmc["_file"]}
+        p_union = None
+        if world > 1:
+            from sourmash_rust_amd import distributed as D
+            barrier()
+            t0 = time.perf_counter()
+            puni = D.union_across_ranks(pmh)
+            barrier()
+            pu_s = max_over_ranks(time.perf_counter() - t0)
+            vt = torch.tensor([1 if D.verify_union(pmh, puni) else 0], dtype=torch.int64, device="cuda")
+            dist.all_reduce(vt, op=dist.ReduceOp.MIN)
+            p_union = {"union_ms": pu_s * 1e3, "hashes": len(puni), "parts": world, "verified": bool(vt.item()),
+                       "what": "configs[4]'s last step: the %d ranks' partial sketches (hashes + abundances) -> ONE signature on every "
+                               "rank, in HBM (distributed.union_across_ranks).  Not part of `value`" % world}
+            del puni
+        protein = {"metric": "protein windows hashed/sec (six-frame translation, ksize=%d, scaled=1000, abundance)" % PROT_K,
+                   "value": world * windows_per_step * args.steps / pdt, "unit": "windows/s", "ms_per_step": pdt / args.steps * 1e3,
+                   "bases_per_s": world * ptotal * args.steps / pdt, "scaling": "weak",
+                   "config": {"workload": "BASELINE configs[4], one rank's share of the 100 GB: %.1f GB synthetic DNA per GPU, %d records x 1 MB, "
+                                          "is_protein, ksize=%d (windows of %d residues, 6 frames), num=0, max_hash=%d, track_abundance, "
+                                          "force=true, inputs resident in HBM" % (ptotal / 1e9, pn_rec, PROT_K, PROT_K // 3, MAX_HASH),
+                              "retained_hashes": p_retained, "windows_per_step": windows_per_step},
+                   "roofline": {"bound": "hbm", "achieved": p_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": p_ach / HBM_PEAK_GBS,
+                                "traffic": ppmc.get("hbm_bytes_per_launch") if p_valu else None,
+                                "kernel": "k_protein_fused<%d,512>" % (PROT_K // 3), "kernel_ms_avg": pk_ms,
+                                "launches_per_step": plaunch.value / max(1, args.steps), "algorithmic_bytes_per_launch": p_bytes,
+                                "valu_bound": p_valu,
+                                "note": "0.5 B per window: like the DNA arm, integer-VALU bound, not HBM bound (reference src/lib.rs:275-302)"},
+                   "union_across_ranks": p_union, "cpu_baseline": None}
+
     # ---------------------------------------------------------------- compare matrix (secondary)
     compare = None
     cmp_outs = {}
@@ -384,12 +485,12 @@ def main():
             # recomputed by that rank ALONE (its own world-1 dictionary, ownership 0: every pair of the row walked locally,
             # nothing mirrored or received) and compared bit for bit -- so that the first run over real RCCL says by itself
             # whether the sliced dictionary, the ownership rule and the exchange of the mirrored blocks were right
+            st = MX.last_stats()             # (of the timed configuration: the check below runs small blocks of its own)
             names = ("jaccard", "common", "size", "count_common", "containment")
             full = D.compare_matrix_sharded(mine, n_sig, NUM, want=names)
             same_again = bool((full["jaccard"] == out["jaccard"]).all().item()) if hi > lo else True
             ver = D.verify_exchange(mine, n_sig, NUM, full, names=names, k_rows=16)
             del full
-            st = MX.last_stats()
             walked = min(st["tiles_visited"] * st["pairs_per_tile"], (hi - lo) * n_sig)   # pairs walked on this rank
             kname = "compare_tiled" if st["route"] == "tiled" else "compare_comp"
             kms = kern[kname][0] / max(1, kern[kname][1])
@@ -410,19 +511,23 @@ def main():
             for key, kind_id in (("families", 0), ("one_component", 1), ("one_family", 2)):
                 out, rec = time_collection(n_sig, kind_id)
                 per_size[n_sig][key] = rec
-                if world == 1 and n_sig == min(sizes):
-                    cmp_outs[key] = out                      # kept for the CPU-baseline check below (the smaller block)
+                if world == 1 and rank == 0 and args.cpu_seconds > 0:
+                    # rows of the first 1 000-row block, on the host: what the CPU baseline's rows are compared with
+                    cmp_outs.setdefault(n_sig, {})[key] = out["jaccard"][: min(n_sig, 1000)].cpu().numpy()
                 del out
         head = per_size[sizes[0]]
         dense = head["one_family"]
         # roofline of the matrix kernel on the collection where every pair is walked (rank 0's kernel, HIP events)
         cmp_roof = None
         if dense["rank0_kernel_ms"] > 0 and dense["route"] == "tiled":
-            pmc = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_compare_tiled.json")))
-            except Exception:
-                pass
+            pmc, pmc_file = None, None
+            for name in ("r04_pmc_compare_tiled.json", "r03_pmc_compare_tiled.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    pmc_file = name
+                    break
+                except Exception:
+                    continue
             walked, kms = dense["rank0_pairs_walked"], dense["rank0_kernel_ms"]
             lds_bytes = pmc.get("lds_bytes_per_walked_pair") * walked if pmc and pmc.get("lds_bytes_per_walked_pair") else None
             lds_achieved = lds_bytes / (kms * 1e-3) / 1e12 if lds_bytes else None
@@ -430,8 +535,8 @@ def main():
                         "kernel_ms_avg": kms, "pairs_walked": walked, "n_signatures": sizes[0],
                         "achieved": lds_achieved, "frac": lds_achieved / LDS_READ_B32_PEAK_TBS if lds_achieved else None,
                         "lds_bytes": lds_bytes,
-                        "lds_bytes_source": ("profiles/r03_pmc_compare_tiled.json (SQ_INSTS_LDS of a separate rocprofv3 --pmc pass of %s "
-                                             "x 64 lanes x 4 B per walked pair; committed, not measured in this run)" % pmc.get("kernel", "the kernel")) if lds_bytes else None,
+                        "lds_bytes_source": ("profiles/%s (SQ_INSTS_LDS of a separate rocprofv3 --pmc pass of %s "
+                                             "x 64 lanes x 4 B per walked pair; committed, not measured in this run)" % (pmc_file, pmc.get("kernel", "the kernel"))) if lds_bytes else None,
                         "effective_bytes": walked * ((NUM + NUM) * 8 + 8),
                         "effective_TBps": walked * ((NUM + NUM) * 8 + 8) / (kms * 1e-3) / 1e12,
                         "compulsory_hbm_bytes": sizes[0] * NUM * 8 + D.shard_range(sizes[0], world, 0)[2] * sizes[0] * 8,
@@ -442,16 +547,18 @@ def main():
                                 "N*16 KB in + rows*N*8 B out"}
         if cmp_roof and pmc and pmc.get("valu_wave_insts_per_64_pairs"):
             # the binding resource (like the sketch kernel's): VALU issue.  Wave instructions per 64 walked pairs from the
-            # committed PMC pass, priced at the guide's 2 cycles per wave64 instruction and at the 4 cycles the counters show
-            # (SQ_ACTIVE_INST_VALU x 4 cycles / SIMDs = the kernel's duration)
+            # committed PMC pass, priced at the guide's 2 cycles per wave64 instruction
             vi = pmc["valu_wave_insts_per_64_pairs"]
             floor2 = cmp_roof["pairs_walked"] / 64.0 * vi * VALU_CYCLES / (SIMDS * MAX_CLOCK_HZ) * 1e3
             cmp_roof["valu_bound"] = {"valu_wave_insts_per_64_pairs": vi, "floor_ms_at_2_cycles": floor2,
                                       "frac_at_2_cycles": floor2 / cmp_roof["kernel_ms_avg"],
-                                      "floor_ms_at_4_cycles": 2 * floor2, "frac_at_4_cycles": 2 * floor2 / cmp_roof["kernel_ms_avg"],
                                       "per_merge_step": pmc.get("per_merge_step")}
         compare = {"metric": "signature pairs compared/sec (ordered pairs delivered, num=%d)" % NUM, "value": head["families"]["pairs_per_s"],
                    "unit": "pairs/s", "n_signatures": sizes[0], "seconds": head["families"]["seconds"],
+                   "value_every_pair_walked": head["one_family"]["pairs_per_s"],
+                   "value_note": "`value` is the family collection of SURVEY.md 8d, where 98 % of the pairs share nothing and are filled "
+                                 "without being walked; `value_every_pair_walked` is the ONE-family collection (every pair walked): the "
+                                 "kernel's own rate, and the figure to compare kernels by",
                    "scaling": "strong: N = %d signatures at every world size (the %d x %d matrix of BASELINE configs[3])" % (sizes[0], sizes[0], sizes[0]),
                    "symmetry": "used: all signatures have one num, so the union walk is symmetric; row i owns the pairs (i, j) with "
                                "(j - i) mod N < N/2, every rank walks the pairs its rows own and the mirrored blocks are exchanged "
@@ -541,32 +648,59 @@ def main():
                "config0": {"workload": "BASELINE configs[0]: 1 MB synthetic DNA, k=31, num=500, compare to itself",
                            "sketch_kmers_per_s": r0["kmers"] / r0["sketch_seconds"], "compare_pairs_per_s": 1.0 / r0["compare_seconds"],
                            "self_compare": r0["self_compare"], "cores": 1, "gpu_sketch_equal": True}}
+        if protein is not None:
+            (rp, pp), = run_workers([["protein", 0, len(poffsets) - 1, 5.0 * scale]])
+            gp = pkg.KmerMinHash(0, PROT_K, True, 42, MAX_HASH, True)
+            gp.add_sequences_dev(pseq.data_ptr(), rp["records"] * REC_LEN, poffsets[: rp["records"] + 1], True, stream)
+            ref = np.load(pp)
+            assert (gp.mins_np() == ref[0]).all() and (gp.abunds_np() == ref[1]).all(), "GPU protein sketch differs from the CPU oracle"
+            ppw = max(1, min((len(poffsets) - 1) // max(1, cores), 400))
+            pw = run_workers([["protein", w * ppw, (w + 1) * ppw, 4.0 * scale] for w in range(cores) if (w + 1) * ppw <= len(poffsets) - 1])
+            for w, (r, p_) in enumerate(pw):
+                gw = pkg.KmerMinHash(0, PROT_K, True, 42, MAX_HASH, True)
+                gw.add_sequences_dev(pseq.data_ptr() + w * ppw * REC_LEN, r["records"] * REC_LEN, poffsets[: r["records"] + 1], True, stream)
+                refw = np.load(p_)
+                assert (gw.mins_np() == refw[0]).all() and (gw.abunds_np() == refw[1]).all(), "GPU protein sketch differs from the CPU oracle (worker %d)" % w
+            protein["cpu_baseline"] = {
+                "value": rp["records"] * PROT_WINDOWS_PER_REC / rp["seconds"], "unit": "windows/s", "cores": 1, "kind": "port",
+                "sample": "first %d record(s) (1 MB each) of the same workload through the C oracle's protein arm (to_aa on six frames + "
+                          "add_word per window, reference src/lib.rs:275-302); hashes and abundances equal to the GPU's" % rp["records"],
+                "all_cores": {"value": sum(r["records"] for r, _ in pw) * PROT_WINDOWS_PER_REC / max(r["seconds"] for r, _ in pw),
+                              "cores": len(pw), "host_cores": cores,
+                              "sample": "%d workers, one stretch of records each (%d records in all); every sketch equal to the GPU's"
+                                        % (len(pw), sum(r["records"] for r, _ in pw))}}
         if compare is not None and cmp_outs:
-            n_sig = min(sizes)
             tmpd = tempfile.mkdtemp(prefix="smh_sigs_")
-            for key, kind_id in (("families", 0), ("one_component", 1), ("one_family", 2)):
-                gj = cmp_outs[key]["jaccard"].cpu().numpy()
-                path = os.path.join(tmpd, "sigs%d.npy" % kind_id)
-                np.save(path, collection(kind_id, 0, n_sig))
-                (rc1, pc1), = run_workers([["compare", n_sig, 0, n_sig, 2.0 * scale, kind_id, path]])
-                j1 = np.load(pc1)
-                assert (gj[: j1.shape[0]] == j1).all(), "GPU matrix differs from the CPU oracle (%s, 1-core rows)" % key
-                per_w = max(1, n_sig // cores)
-                cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, 2.0 * scale, kind_id, path] for w in range(cores)
-                                  if (w + 1) * per_w <= n_sig])
-                for w, (r, p) in enumerate(cw):
-                    jw = np.load(p)
-                    assert (gj[w * per_w: w * per_w + jw.shape[0]] == jw).all(), "GPU matrix differs from the CPU oracle (%s, worker %d)" % (key, w)
-                target = compare[key] if n_sig == sizes[0] else compare["block_%d" % n_sig][key]
-                target["cpu_baseline"] = {
-                    "value": rc1["rows"] * n_sig / rc1["seconds"], "unit": "pairs/s", "cores": 1, "kind": "port", "n_signatures": n_sig,
-                    "sample": "rows 0..%d x all %d columns through the C oracle's compare (two merges + two intersections per "
-                              "pair, reference src/lib.rs:470-508); equal to the GPU's rows" % (rc1["rows"] - 1, n_sig),
-                    "all_cores": {"value": sum(r["rows"] for r, _ in cw) * n_sig / max(r["seconds"] for r, _ in cw),
-                                  "cores": len(cw), "host_cores": cores,
-                                  "sample": "%d workers, one row block each (%d rows in all), equal to the GPU's rows"
-                                            % (len(cw), sum(r["rows"] for r, _ in cw))}}
-                os.remove(path)
+            TMP_DIRS.append(tmpd)
+            for n_sig in sorted(cmp_outs):
+                # the CPU sample: every row of the 1 000 x 1 000 block (bounded by the budget); of the 10 000 x 10 000 matrix its
+                # first 1 000-row block -- all of it on all cores for the family collection, a few seconds'
+                # worth for the other two
+                block = min(n_sig, 1000)
+                for key, kind_id in (("families", 0), ("one_component", 1), ("one_family", 2)):
+                    gj = cmp_outs[n_sig][key]
+                    path = os.path.join(tmpd, "sigs%d_%d.npy" % (n_sig, kind_id))
+                    np.save(path, collection(kind_id, 0, n_sig))
+                    (rc1, pc1), = run_workers([["compare", n_sig, 0, block, 2.0 * scale, kind_id, path]])
+                    j1 = np.load(pc1)
+                    assert (gj[: j1.shape[0]] == j1).all(), "GPU matrix differs from the CPU oracle (%s, 1-core rows)" % key
+                    per_w = max(1, block // cores)
+                    budget = (24.0 if (n_sig > 1000 and kind_id == 0) else 2.0) * scale
+                    cw = run_workers([["compare", n_sig, w * per_w, (w + 1) * per_w, budget, kind_id, path] for w in range(cores)
+                                      if (w + 1) * per_w <= block])
+                    for w, (r, p) in enumerate(cw):
+                        jw = np.load(p)
+                        assert (gj[w * per_w: w * per_w + jw.shape[0]] == jw).all(), "GPU matrix differs from the CPU oracle (%s, worker %d)" % (key, w)
+                    target = compare[key] if n_sig == sizes[0] else compare["block_%d" % n_sig][key]
+                    target["cpu_baseline"] = {
+                        "value": rc1["rows"] * n_sig / rc1["seconds"], "unit": "pairs/s", "cores": 1, "kind": "port", "n_signatures": n_sig,
+                        "sample": "rows 0..%d x all %d columns through the C oracle's compare (two merges + two intersections per "
+                                  "pair, reference src/lib.rs:470-508); equal to the GPU's rows" % (rc1["rows"] - 1, n_sig),
+                        "all_cores": {"value": sum(r["rows"] for r, _ in cw) * n_sig / max(r["seconds"] for r, _ in cw),
+                                      "cores": len(cw), "host_cores": cores,
+                                      "sample": "%d workers, one stretch of rows of the first %d-row block each (%d rows x %d columns in all), "
+                                                "equal to the GPU's rows" % (len(cw), block, sum(r["rows"] for r, _ in cw), n_sig)}}
+                    os.remove(path)
 
     if rank == 0:
         line = {
@@ -587,16 +721,22 @@ def main():
             "cpu_baseline": cpu,
             "host_input": host_input,
             "union_across_ranks": union,
+            "protein": protein,
             "compare": compare,
         }
         print(json.dumps(line))
         sys.stdout.flush()
+    import shutil
+    for d in TMP_DIRS:
+        shutil.rmtree(d, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
     # a matrix that fails its own check is not a result: the line above says which check, the exit code says so too
     if compare is not None and rank == 0 and not (compare["exchange_verified"] and compare["self_jaccard_is_1"]):
         sys.exit(3)
     if union is not None and rank == 0 and not union["verified"]:
+        sys.exit(3)
+    if protein is not None and protein["union_across_ranks"] is not None and rank == 0 and not protein["union_across_ranks"]["verified"]:
         sys.exit(3)
 
 

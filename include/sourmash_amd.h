@@ -7,7 +7,12 @@
  * a reference symbol.  Plain pointers and sizes only; `stream` is a hipStream_t passed as
  * void*.  NULL = the library's own stream, which is first ordered after everything already queued
  * on the legacy default stream (where a caller without streams of its own produced the inputs);
- * every entry point returns with its device work complete.  "dev" pointers are HIP device pointers.
+ * every entry point returns with its device work complete -- with two stated exceptions,
+ * smh_collection_begin with world == 1 and smh_collection_finish without a gathered buffer (a single
+ * owner's dictionary, which only later calls of this library use): their work is left queued, and
+ * EVERY later entry point, on whatever stream it is given, is first ordered behind it (an event
+ * recorded behind the open work; the library's shared scratch buffers are never rewritten under it).
+ * "dev" pointers are HIP device pointers.
  *
  * Error convention: same thread-local slot as sourmash.h; functions returning int return 0 on
  * success and the SourmashErrorCode otherwise.
@@ -71,8 +76,11 @@ int smh_intersection(const KmerMinHash *ptr, const KmerMinHash *other, uint64_t 
 /* The union of partial SCALED sketches without leaving HBM -- what folds the per-GPU partial sketches of one input into one
  * signature (KmerMinHash::merge, reference src/lib.rs:307-403, for scaled sketches: set union, abundances add).
  * smh_sketch_export_dev copies the sketch's ascending hashes (and, when it tracks them and abunds_dev is not NULL, their
- * abundances) into the caller's device buffers of `capacity` entries; *n_out = the number of hashes (call with capacity 0 to
- * ask).  smh_sketch_absorb_dev unites `ptr` with n_parts sorted, distinct parts lying in ONE device buffer (part k =
+ * abundances) into the caller's device buffers of `capacity` entries; *n_out = the number of hashes (call with mins_dev NULL
+ * to ask; with a buffer, capacity < *n_out is an error -- Internal -- and nothing is written).  Side effect: a sketch whose
+ * state is on the host is MOVED to HBM by the call (its host vectors are emptied; accessors bring it back on demand); a sketch
+ * whose abundance vector does not match its hashes (quirks Q5/Q6 after a merge) has no device form and is refused.
+ * smh_sketch_absorb_dev unites `ptr` with n_parts sorted, distinct parts lying in ONE device buffer (part k =
  * mins_dev[part_starts[k] .. + part_lens[k]), e.g. the output of an all-gather of padded exports): each part is merged by rank
  * arithmetic and two scatters, no sort, no host copy.  A sketch that tracks abundances needs abunds_dev. */
 int smh_sketch_export_dev(KmerMinHash *ptr, uint64_t *mins_dev, uint64_t *abunds_dev, uint64_t capacity, uint64_t *n_out,
@@ -170,7 +178,12 @@ uint32_t smh_index_len(const SmhIndex *index);
 int smh_index_find(SmhIndex *index, const KmerMinHash *query, double threshold, bool containment,
                    uint32_t *out_indices, uint32_t *out_count);
 int smh_index_most_common(SmhIndex *index, const KmerMinHash *leaf, uint32_t *best_pos, uint64_t *best_common);
-/* rows x cols block between two resident sets (rows' num truncates); host outputs, any may be NULL */
+/* rows x cols block between two resident sets (rows' num truncates); host outputs, any may be NULL.  An index compared with
+ * ITSELF keeps the dictionary of its collection (dense ranks at 4 B per hash, component roots, the per-sketch partition table
+ * of n x (ranges + 1) x 4 B -- ~330 MB for 10 000 long scaled sketches) so that later all-vs-all calls skip the pre-pass;
+ * smh_index_drop_dictionary gives that memory back (the next such call rebuilds it), and so does smh_release_workspace()
+ * for every live index. */
+void smh_index_drop_dictionary(SmhIndex *index);
 int smh_index_compare(SmhIndex *rows, SmhIndex *cols, double *jaccard, uint64_t *common, uint64_t *size,
                       uint64_t *count_common, double *containment);
 
@@ -198,6 +211,9 @@ typedef struct SmhCompareTuning {
   uint32_t split_frequent;    /* default 1: hashes held by more than a quarter of the sketches (at most 64 of them) do not
                                  connect sketches; pairs that share only such hashes are decided from per-sketch records
                                  instead of being walked */
+  uint32_t dictionary;        /* how the pooled hashes of the collection dictionary are sorted: 0 = default (four radix passes over the
+                                 32 most significant bits that vary, then the few keys that tie there are put in order), 1 = all
+                                 eight byte passes (what the default falls back to; A/B and parity tests: same matrix either way) */
 } SmhCompareTuning;
 void smh_compare_get_tuning(SmhCompareTuning *out);
 int smh_compare_set_tuning(const SmhCompareTuning *tuning);   /* NULL restores the defaults; process-wide */
@@ -214,7 +230,7 @@ typedef struct SmhCompareStats {
   uint32_t frequent_hashes;     /* hashes set aside as frequent in this block (0 = none, or too many to set aside) */
   uint32_t pipelined;           /* tiled: 1 = the software-pipelined kernel walked the tiles (blocks that do not fill the chip for long) */
   uint32_t span_halvings;       /* pipelined kernel: stretches whose speculatively grown span did not fit LDS and was rebuilt, halved */
-  uint32_t prefetched_after_halving; /* ... tables built from prefetched boundary crossings later in a tile that had such a rebuild */
+  uint32_t prefetched_after_halving; /* ... tiles in which prefetched boundary crossings were used after such a rebuild */
 } SmhCompareStats;
 void smh_compare_last_stats(SmhCompareStats *out);
 

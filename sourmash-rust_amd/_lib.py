@@ -19,7 +19,7 @@ class SourmashStr(C.Structure):
 
 class SmhCompareTuning(C.Structure):
     _fields_ = [("route", C.c_uint32), ("visit_all_tiles", C.c_uint32), ("use_symmetry", C.c_uint32),
-                ("comp_pairs_limit", C.c_uint64), ("split_frequent", C.c_uint32)]
+                ("comp_pairs_limit", C.c_uint64), ("split_frequent", C.c_uint32), ("dictionary", C.c_uint32)]
 
 
 class SmhCompareStats(C.Structure):
@@ -120,6 +120,7 @@ _SIGS = {
     "smh_most_common": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), u64p]),
     "smh_index_new": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_uint32]),
     "smh_index_free": (None, [C.c_void_p]),
+    "smh_index_drop_dictionary": (None, [C.c_void_p]),
     "smh_index_len": (C.c_uint32, [C.c_void_p]),
     "smh_index_find": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_bool, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "smh_index_most_common": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), u64p]),

@@ -21,12 +21,14 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <memory>
 #include <mutex>
 #include <vector>
 #include <cstdlib>
 
+#include "block_sort.hpp"
 #include "device.hpp"
 #include "kernels.hpp"
 
@@ -400,7 +402,7 @@ struct PlanState {
   uint32_t next_tile[8];         // tiled: tiles handed out so far, per XCD stretch of the list
   uint32_t pf;                   // tiled: the software-pipelined kernel walks the tiles (k_compare_tiled_pf), not the plain one
   uint32_t halvings;             // pipelined kernel: stretches whose speculative span did not fit and was rebuilt, halved, with plain loads
-  uint32_t pf_after_halving;     // ... tables built from PREFETCHED boundary crossings later in a tile that had such a rebuild
+  uint32_t pf_after_halving;     // ... tiles in which a table was built from PREFETCHED boundary crossings after such a rebuild
   uint32_t bad_tables;           // a segment that would end before it starts (never, unless a table was built from crossings of the wrong boundary)
 };
 // What the owner of one slice of hash space finds in it (see "collection dictionary" below)
@@ -409,6 +411,9 @@ struct RangeState {
   uint32_t nfreq_seen;           // runs longer than the frequency threshold
   uint32_t nfreq;                // frequent hashes set aside (0 when there were more than the slice's share of kMaxFreq)
   uint32_t freq_run[64];         // their run ids, ascending (= ascending hash) once k_freq_finalize has run
+  uint32_t overflow;             // the four-pass sort gave up (keys that tie in the sorted bits and could not be put in order by
+                                 // k_tie_fix / k_tie_sort): the slice is built again with all eight passes
+  uint32_t sort_shift;           // the four-pass sort: its lowest bit (k_key_span)
 };
 constexpr uint32_t kMaxFreq = 64;
 
@@ -919,7 +924,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   __builtin_amdgcn_s_waitcnt(0x0f70);
   __syncthreads();
   uint32_t s0 = 0, s1 = 1, s2 = 2;
-  bool halved = false;    // (this tile had a stretch rebuilt with a halved span: for the record only)
+  uint32_t n_halved = 0;    // (stretches of this tile rebuilt with a halved span, and whether prefetched crossings were used
+  bool pf_after = false;    //  after one: for the record only, added to the plan's counters once per tile)
 
   while (true) {
     // ---- here: table s0 = stretch `it` (its ranks in stage it & 1, unless ovf0), table s1 = the next one (mt1 != 0), the
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       // where a row or column crosses boundary b is a function of b alone, so `raw_at == r2 + mt2` is exact whatever route
       // (spans grown, halved, rebuilt) led to r2 and mt2; a table that ends anywhere else reads its ends with plain loads
       const bool use_raw = raw_at == r2 + mt2;
-      if (halved && use_raw && tid == 0) atomicAdd(&ka.st->pf_after_halving, 1u);
+      pf_after = pf_after || (n_halved && use_raw);
       build_table(s2, s1, r2, mt2, false, use_raw ? raw + raw_slot * 128 : nullptr);
       if (r2 + mt2 < R) {
         uint32_t c2 = cool;
@@ -985,8 +991,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       __syncthreads();
       mt2 >>= 1; cool = 16;
       ovf2 = settle_table(s2, s1, r2, mt2, false, cool);
-      if (tid == 0) atomicAdd(&ka.st->halvings, 1u);
-      halved = true;
+      n_halved++;
     }
     it++;
     r0 = r1; mt0 = mt1; ovf0 = ovf1;
@@ -1000,16 +1005,14 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     if (row != kNone && col_ok)
       tiled_write_pair<WantCC>(ka, row, col, nrowL[w * kRowsPerWave + q], ucount[q], common[q], WantCC ? cc[q] : 0u);
   }
+  if (tid == 0 && n_halved) {
+    atomicAdd(&ka.st->halvings, n_halved);
+    if (pf_after) atomicAdd(&ka.st->pf_after_halving, 1u);
+  }
   }   // tiles of this workgroup
 }
 
 // ---- pre-pass kernels ---------------------------------------------------------------------
-// local dense rank of every element of a slice, back in slice order: rank[origin[i]] = run of sorted position i
-__global__ __launch_bounds__(256) void k_rank_scatter(const uint32_t* __restrict__ runid, const uint32_t* __restrict__ origin,
-                                                      uint64_t n, uint32_t* __restrict__ rank) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) rank[origin[i]] = runid[i];
-}
 // Range boundaries of the tiled kernel, as HASH values: out[0] = first hash value of the slice, out[k] = the hash at
 // sorted position k*n/Rg of the slice's pool -- Rg ranges with equal shares of the pooled elements.
 __global__ void k_hbounds(const uint32_t* __restrict__ starts, const uint64_t* __restrict__ uniq, const RangeState* __restrict__ rs,
@@ -1113,7 +1116,8 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
                                                       const uint32_t* __restrict__ spart, uint32_t G, uint32_t g,
                                                       const uint32_t* __restrict__ segoff_g, uint32_t n,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ node) {
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ node, uint32_t* __restrict__ parent) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsk; i += gridDim.x * blockDim.x) parent[i] = i;   // (the union-find forest's start)
   // a lane takes 8 consecutive slice positions: one search for the sketch of the first, then a walk (the sort numbers the keys)
   const uint32_t t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
   if (t0 >= n) return;
@@ -1137,7 +1141,10 @@ __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict
 }
 // world == 1: the one slice is the collection itself, in its own order (the sort reads it in place and numbers it); what is
 // left to make is node[t] = the sketch of element t.  A lane takes 8 consecutive elements: one search, then a walk.
-__global__ __launch_bounds__(256) void k_whole_nodes(const uint64_t* __restrict__ off, uint32_t nsk, uint32_t n, uint32_t* __restrict__ node) {
+// (and what else the pre-pass needs before its first real kernel: the union-find forest's start, parent[i] = i)
+__global__ __launch_bounds__(256) void k_whole_nodes(const uint64_t* __restrict__ off, uint32_t nsk, uint32_t n, uint32_t* __restrict__ node,
+                                                     uint32_t* __restrict__ parent) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsk; i += gridDim.x * blockDim.x) parent[i] = i;
   const uint32_t t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
   if (t0 >= n) return;
   uint32_t lo = 0, hi = nsk;   // last s with off[s] <= t0
@@ -1161,32 +1168,181 @@ __global__ __launch_bounds__(256) void k_whole_nodes(const uint64_t* __restrict_
     for (uint32_t j = 0; j < t1 - t0; j++) node[t0 + j] = v[j];
   }
 }
+
+// where the segments (sketches) of a slice start inside its key array: the collection's own offsets (one owner) or the
+// slice's table (k_slice_scan)
+struct BkSeg { const uint64_t* off64; const uint32_t* off32; };
+__device__ __forceinline__ uint32_t bk_seg(const BkSeg& g, uint32_t s) { return g.off64 ? (uint32_t)g.off64[s] : g.off32[s]; }
+
+// ---- the pooled sort in four passes instead of eight -------------------------------------------------------------------
+// The order of the pooled hashes is all the dictionary needs, and 32 bits decide it for all but a few of them: N keys
+// uniform over a span leave ~N^2 / 2^33 pairs that tie in their 32 most significant VARYING bits (2 M keys: ~500 pairs;
+// 20 M: ~50 000).  So the LSD sort runs over those 32 bits only -- bits [s0, s0 + 32), s0 = (bits below the first one in
+// which the smallest and the largest key differ) - 32, found on the device by k_key_span and read by the sort's kernels
+// from there -- and k_tie_fix puts the ties in order: the passes are stable, so keys that tie sit next to each other in
+// their original order; the lane at the head of a group of at most 4 sorts it in registers, runs of EQUAL keys need nothing,
+// and a longer group that is out of order raises rs->overflow -- the slice is then sorted again with all eight passes
+// (never seen on hashed keys; keys crafted to differ only in their low bits pay for it).
+__global__ __launch_bounds__(1024) void k_key_span(const uint64_t* __restrict__ keys, BkSeg seg, uint32_t nsk, RangeState* rs) {
+  __shared__ unsigned long long red[2][16];
+  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+  unsigned long long mn = ~0ull, mx = 0ull;
+  for (uint32_t s = t; s < nsk; s += 1024) {       // a segment is sorted: its ends are its extremes
+    const uint32_t a = bk_seg(seg, s), b = bk_seg(seg, s + 1);
+    if (b > a) { mn = min(mn, (unsigned long long)keys[a]); mx = max(mx, (unsigned long long)keys[b - 1]); }
+  }
+  for (int off = 32; off; off >>= 1) {
+    mn = min(mn, (unsigned long long)__shfl_xor(mn, off));
+    mx = max(mx, (unsigned long long)__shfl_xor(mx, off));
+  }
+  if (lane == 0) { red[0][w] = mn; red[1][w] = mx; }
+  __syncthreads();
+  if (t == 0) {
+    for (int ww = 0; ww < 16; ww++) { mn = min(mn, red[0][ww]); mx = max(mx, red[1][ww]); }
+    const uint32_t hb = (mx > mn) ? 64u - (uint32_t)__builtin_clzll(mn ^ mx) : 0u;    // bits below the common prefix
+    rs->sort_shift = hb > 32u ? hb - 32u : 0u;
+  }
+}
+// first / one-past-last sorted position whose key has the bits above `sh` of `p`
+__device__ __forceinline__ uint32_t tie_lower(const uint64_t* keys, uint32_t n, uint32_t sh, uint64_t p) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((keys[mid] >> sh) < p) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+constexpr uint32_t kTieListMax = 1u << 16;
+struct TieList { uint32_t n; uint32_t pad; uint32_t at[kTieListMax]; };
+// Phase 1, a lane per sorted position.  Head of a group of at most 4: sorts it in registers.  Inside a longer group and out
+// of order with its predecessor (a run of equal hashes -- the same hash in many sketches -- with a different key that ties
+// with it in the sorted bits): the group goes on the list of k_tie_sort, once (a bit per group start).
+__global__ __launch_bounds__(256) void k_tie_fix(uint64_t* __restrict__ keys, uint32_t* __restrict__ org, uint32_t n, RangeState* rs,
+                                                 uint32_t* __restrict__ seen, TieList* __restrict__ list) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const uint32_t sh = rs->sort_shift;
+  if (sh == 0) return;                                    // the passes covered every bit
+  const uint64_t k0 = keys[e];
+  const uint64_t p = k0 >> sh;
+  const bool with_prev = e && (keys[e - 1] >> sh) == p;
+  if (with_prev) {
+    if (keys[e - 1] > k0) {
+      uint32_t lo = e - 1, hi = e + 1;
+      while (lo > 0 && e - lo < 4 && (keys[lo - 1] >> sh) == p) lo--;
+      while (hi < n && hi - lo < 5 && (keys[hi] >> sh) == p) hi++;
+      if (hi - lo > 4) {                                  // (a short group is put in order by the lane at its head)
+        // the group's first position: galloping back from here (groups are short next to the array), then bisecting
+        uint32_t step = 4, hi_b = lo;                        // (keys[lo] has the prefix)
+        while (hi_b >= step && (keys[hi_b - step] >> sh) == p) { hi_b -= step; step <<= 1; }
+        const uint32_t from = hi_b >= step ? hi_b - step : 0u;
+        const uint32_t a = from + tie_lower(keys + from, hi_b - from, sh, p);
+        if ((atomicOr(&seen[a >> 5], 1u << (a & 31u)) >> (a & 31u) & 1u) == 0) {
+          const uint32_t q = atomicAdd(&list->n, 1u);
+          if (q < kTieListMax) list->at[q] = a; else rs->overflow = 1;
+        }
+      }
+    }
+    return;
+  }
+  uint64_t k[4] = {k0, 0, 0, 0};
+  uint32_t g = 1;
+  while (g < 4 && e + g < n && (keys[e + g] >> sh) == p) { k[g] = keys[e + g]; g++; }
+  if (g == 1 || (g == 4 && e + 4 < n && (keys[e + 4] >> sh) == p)) return;     // alone, or a long group (its members look for themselves)
+  bool sorted = true;
+#pragma unroll
+  for (uint32_t i = 1; i < 4; i++) sorted = sorted && (i >= g || k[i - 1] <= k[i]);
+  if (sorted) return;
+  uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) if (i < g) v[i] = org[e + i];
+#pragma unroll
+  for (uint32_t i = 1; i < 4; i++)
+#pragma unroll
+    for (uint32_t j = i; j > 0; j--)
+      if (i < g && k[j] < k[j - 1]) {
+        const uint64_t tk = k[j]; k[j] = k[j - 1]; k[j - 1] = tk;
+        const uint32_t tv = v[j]; v[j] = v[j - 1]; v[j - 1] = tv;
+      }
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) if (i < g) { keys[e + i] = k[i]; org[e + i] = v[i]; }
+}
+// Phase 2: the listed groups, one workgroup each, sorted in LDS (up to 8192 keys; the passes whose byte is the same for
+// every key of the group skip themselves).  A longer group gives up: rs->overflow.
+__global__ __launch_bounds__(kBsThreads) void k_tie_sort(uint64_t* __restrict__ keys, uint32_t* __restrict__ org, uint32_t n, RangeState* rs,
+                                                         const TieList* __restrict__ list) {
+  __shared__ BlockSortLds<kBlockSortMax, true, uint32_t> L;
+  __shared__ uint32_t ends[2];
+  const uint32_t t = threadIdx.x, sh = rs->sort_shift;
+  const uint32_t m = min(list->n, kTieListMax);
+  for (uint32_t q = blockIdx.x; q < m; q += gridDim.x) {
+    __syncthreads();
+    const uint32_t a = list->at[q];
+    if (t == 0) ends[0] = 0xffffffffu;
+    __syncthreads();
+    {
+      // where the group ends: every lane looks at a few positions behind the start, the first one with another prefix wins
+      const uint64_t p = keys[a] >> sh;
+      uint32_t first = 0xffffffffu;
+      for (uint32_t i = t; i <= (uint32_t)kBlockSortMax; i += kBsThreads) {
+        const uint32_t pos = a + i;
+        if (pos >= n || (keys[pos] >> sh) != p) { first = i; break; }
+      }
+      if (first != 0xffffffffu) atomicMin(&ends[0], first);
+    }
+    __syncthreads();
+    const uint32_t g = ends[0];
+    if (g > (uint32_t)kBlockSortMax) { if (t == 0) rs->overflow = 1; continue; }
+    if (g <= 64) {
+      // a short group (the usual one: a run of a few equal hashes and a stranger): one wave, a key per lane, every key's
+      // place = the keys before it in (key, arrival) order, counted with 64 broadcasts
+      if (t < 64) {
+        const bool in = t < g;
+        const uint64_t k = in ? keys[a + t] : ~0ull;
+        const uint32_t v = in ? org[a + t] : 0u;
+        uint32_t place = 0;
+        for (uint32_t j = 0; j < g; j++) {
+          const uint64_t kj = __shfl(k, (int)j);
+          place += (kj < k || (kj == k && j < t)) ? 1u : 0u;
+        }
+        if (in) { keys[a + place] = k; org[a + place] = v; }
+      }
+      continue;
+    }
+    const uint32_t items = (g + kBsThreads - 1) / kBsThreads;
+    for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) {
+      L.sk[i] = i < g ? keys[a + i] : ~0ull;
+      L.si[i] = i < g ? org[a + i] : 0u;
+    }
+    block_sort_passes(L, g, items, 0, (int)((sh + 7u) & ~7u));       // (the bits above sh are the same in the whole group)
+    for (uint32_t i = t; i < g; i += kBsThreads) { keys[a + i] = L.sk[i]; org[a + i] = L.si[i]; }
+  }
+}
+
 // What an owner publishes about its slice.  The share is [SliceHeader][roots: nsk u32][hbound: Rg u64][ranks: nmax u32].
 struct SliceHeader {
-  uint32_t n_elems, nruns, nfreq, pad;
+  uint32_t n_elems, nruns, nfreq;
+  uint32_t id_space;             // the slice's local ranks are below this (= nruns: they are dense)
   uint64_t freq_hash[64];
 };
 struct DictState;
 __global__ __launch_bounds__(64) void k_slice_header(const RangeState* __restrict__ rs, const uint64_t* __restrict__ uniq, uint32_t n,
-                                                     SliceHeader* __restrict__ h, DictState* single_owner);
+                                                     SliceHeader* __restrict__ h, DictState* single_owner, uint32_t sparse_ids);
 // What everybody derives from the gathered headers: the rank offset of every slice, the frequent hashes (ascending)
 struct DictState {
   uint32_t nruns;              // distinct hashes of the collection
   uint32_t nfreq;              // frequent hashes set aside, over all slices (<= kMaxFreq)
   uint32_t part_built;         // the range partition table exists (k_partition, k_plan_geometry)
-  uint32_t pad;
+  uint32_t overflow;           // one owner: the four-pass sort gave up (RangeState::overflow) -- the dictionary is void and is built again
   uint32_t rbase[64];          // dense rank of the first hash of slice g
   uint64_t freq_hash[64];
 };
 // (ds: a single owner's header IS the collection's state -- one launch less)
 __global__ __launch_bounds__(64) void k_slice_header(const RangeState* __restrict__ rs, const uint64_t* __restrict__ uniq, uint32_t n,
-                                                     SliceHeader* __restrict__ h, DictState* ds) {
+                                                     SliceHeader* __restrict__ h, DictState* ds, uint32_t sparse_ids) {
   const uint32_t k = threadIdx.x;
   const uint64_t f = k < rs->nfreq ? uniq[rs->freq_run[k]] : 0ull;
-  if (k == 0) { h->n_elems = n; h->nruns = rs->nruns; h->nfreq = rs->nfreq; h->pad = 0; }
+  if (k == 0) { h->n_elems = n; h->nruns = rs->nruns; h->nfreq = rs->nfreq; h->id_space = sparse_ids ? n : rs->nruns; }
   h->freq_hash[k] = f;
   if (ds) {
-    if (k == 0) { ds->nruns = rs->nruns; ds->nfreq = rs->nfreq; ds->part_built = 0; ds->pad = 0; }
+    if (k == 0) { ds->nruns = rs->nruns; ds->nfreq = rs->nfreq; ds->part_built = 0; ds->overflow = rs->overflow; }
     ds->rbase[k] = 0;
     ds->freq_hash[k] = f;
   }
@@ -1197,12 +1353,13 @@ __global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t shar
   for (uint32_t g = 0; g < G; g++) {
     const SliceHeader* h = reinterpret_cast<const SliceHeader*>(gathered + (size_t)g * share_bytes);
     ds->rbase[g] = base;
-    base += h->nruns;
+    base += h->id_space;
     for (uint32_t k = 0; k < h->nfreq && nf < 64; k++) ds->freq_hash[nf++] = h->freq_hash[k];
   }
   ds->nruns = base;
   ds->nfreq = nf;
   ds->part_built = 0;
+  ds->overflow = 0;
 }
 // rank of every element of the collection, in collection order, from the slices' local ranks: a workgroup per sketch
 // (its slice boundaries and the slices' segment starts sit in LDS; no search per element)
@@ -1609,7 +1766,7 @@ __global__ __launch_bounds__(256) void k_flag_tiles(TileTest t, uint32_t wpb, ui
 // temporaries of building a dictionary and of planning one block compare: process-wide, grow-only, used under the device mutex
 struct TiledScratch {
   DeviceBuffer keys0, keys1, org0, org1, uniq, starts, node, parent, tiles, work, plan, pk0, pk1, pk2, pk3, rng, cnt, runid, isfreq,
-      sample0, sample1, rstate, cat, wroots;
+      sample0, sample1, rstate, cat, wroots, ties;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -1659,7 +1816,7 @@ void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.node, &T.parent, &T.tiles, &T.work, &T.plan,
                           &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt, &T.runid, &T.isfreq, &T.sample0, &T.sample1, &T.rstate,
-                          &T.cat, &T.wroots})
+                          &T.cat, &T.wroots, &T.ties})
     b->release();
   release_implicit_dict();
 }
@@ -1691,6 +1848,7 @@ struct CollectionDict {
   uint32_t n_mine = 0, n_max = 0;     // elements of this owner's slice / of the largest slice
   uint64_t roots_at = 0, hbound_at = 0, ranks_at = 0, share_bytes = 0;
   bool finished = false, split = false;
+  bool force_radix = false;           // the pooled sort with all eight passes (the four-pass sort + tie fix gave up on this collection, or the tuning asks)
   // where compare reads them: buffers of their own, or -- one owner -- straight inside the share
   const uint32_t* rank_ptr = nullptr;
   const uint32_t* root_ptr = nullptr;
@@ -1702,7 +1860,9 @@ struct CollectionDict {
 static inline uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
 
 static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev, const uint64_t* offsets_dev, const uint64_t* offsets_host,
-                                  uint32_t n, uint32_t world, uint32_t rank, Device& dev, hipStream_t s) {
+                                  uint32_t n, uint32_t world, uint32_t rank, Device& dev, hipStream_t s, bool full_sort = false) {
+  // (the four-pass sort is tried afresh for every collection; a rebuild, or the tuning, asks for all eight passes)
+  D.force_radix = full_sort || compare_get_tuning().dictionary == 1;
   if (world == 0 || world > 64 || rank >= world) throw_internal("collection: world must be 1..64 and rank < world");
   if (n == 0) throw_internal("collection: no sketches");
   D.finished = false;
@@ -1716,12 +1876,12 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   for (uint32_t i = 0; i < n; i++) D.max_len = std::max<uint32_t>(D.max_len, (uint32_t)(offsets_host[i + 1] - offsets_host[i]));
   // offsets relative to the first element (a copy the dictionary owns: the caller's array may be reused)
   D.off.ensure((size_t)(n + 1) * 8);
-  if (offsets_dev && base == 0) HIP_CHECK(hipMemcpyAsync(D.off.ptr, offsets_dev, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, s));
-  else {
-    D.rel_off.resize((size_t)n + 1);      // (a member: the copy may read it after this function has returned)
+  if (offsets_host != D.rel_off.data()) {
+    D.rel_off.resize((size_t)n + 1);      // (a member: the copy may read it after this function has returned; a rebuild reads it)
     for (uint32_t i = 0; i <= n; i++) D.rel_off[i] = offsets_host[i] - base;
-    HIP_CHECK(hipMemcpyAsync(D.off.ptr, D.rel_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
   }
+  if (offsets_dev && base == 0) HIP_CHECK(hipMemcpyAsync(D.off.ptr, offsets_dev, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, s));
+  else HIP_CHECK(hipMemcpyAsync(D.off.ptr, D.rel_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
   const uint64_t* off = D.off.as<uint64_t>();
   const uint32_t G = world;
   // ranges of the tiled kernel: about 24 pooled elements per sketch per range, granularity from the LONGEST sketch
@@ -1774,43 +1934,59 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   // ---- my slice: gather, sort (hash, place), runs of equal hashes = local dense ranks + document frequencies
   const size_t ne = std::max<uint32_t>(nm, 1);
   T.keys0.ensure(ne * 8); T.keys1.ensure(ne * 8); T.org0.ensure(ne * 4); T.org1.ensure(ne * 4); T.node.ensure(ne * 4);
-  T.uniq.ensure(ne * 8); T.starts.ensure((ne + 1) * 4); T.runid.ensure(ne * 4);
+  T.uniq.ensure(ne * 8); T.starts.ensure((ne + 1) * 4); T.runid.ensure(ne * 4); T.parent.ensure((size_t)n * 4);
   uint64_t* sk = T.keys0.as<uint64_t>();
   uint32_t* so = T.org0.as<uint32_t>();
+  D.split = compare_get_tuning().split_frequent != 0 && n >= 32;
+  const uint32_t threshold = std::max<uint32_t>(16u, n / 4);
   if (nm) {
-    // hashes are uniform 64-bit values: every byte differs, all eight passes run (no histogram read-back)
+    // hashes are uniform over their span: the 32 most significant bits that vary decide the order of all but a few of them
+    // (four passes, then k_tie_fix); all eight passes only when that has failed once for this collection
     int cur;
+    const uint32_t mask = D.force_radix ? 0xffu : 0x0fu;
+    const uint32_t* shift_dev = D.force_radix ? nullptr : &rs->sort_shift;
     if (G == 1) {
-      hipLaunchKernelGGL(k_whole_nodes, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, off, n, nm, T.node.as<uint32_t>());
+      hipLaunchKernelGGL(k_whole_nodes, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, off, n, nm, T.node.as<uint32_t>(), T.parent.as<uint32_t>());
+      if (shift_dev) hipLaunchKernelGGL(k_key_span, dim3(1), dim3(1024), 0, s, D.hashes, BkSeg{off, nullptr}, n, rs);
       cur = radix_sort_u64_place(D.hashes, T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
-                                 dev.scratch, s, 0xffu);
+                                 dev.scratch, s, mask, shift_dev);
     } else {
       hipLaunchKernelGGL(k_slice_gather, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
-                         D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>());
+                         D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>(), T.parent.as<uint32_t>());
+      if (shift_dev)
+        hipLaunchKernelGGL(k_key_span, dim3(1), dim3(1024), 0, s, T.keys0.as<uint64_t>(),
+                           BkSeg{nullptr, D.segoff.as<uint32_t>() + (size_t)rank * (n + 1)}, n, rs);
       // (the first pass reads keys0 and writes keys1: keys0 is input and work buffer at once)
       cur = radix_sort_u64_place(T.keys0.as<uint64_t>(), T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(),
-                                 T.org1.as<uint32_t>(), nm, dev.scratch, s, 0xffu);
+                                 T.org1.as<uint32_t>(), nm, dev.scratch, s, mask, shift_dev);
     }
     if (cur) { sk = T.keys1.as<uint64_t>(); so = T.org1.as<uint32_t>(); }
+    if (shift_dev) {
+      const size_t seen_bytes = ((size_t)nm / 32 + 2) * 4;
+      T.ties.ensure(seen_bytes + sizeof(TieList));
+      HIP_CHECK(hipMemsetAsync(T.ties.ptr, 0, seen_bytes + 8, s));      // the bitmap and the list's counter
+      uint32_t* seen = T.ties.as<uint32_t>();
+      TieList* list = reinterpret_cast<TieList*>(T.ties.as<uint8_t>() + seen_bytes);
+      hipLaunchKernelGGL(k_tie_fix, dim3((nm + 255) / 256), dim3(256), 0, s, sk, so, nm, rs, seen, list);
+      hipLaunchKernelGGL(k_tie_sort, dim3((unsigned)dev.cu_count()), dim3(kBsThreads), 0, s, sk, so, nm, rs, list);
+    }
   }
-  run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, nullptr, nullptr, &rs->nruns,
-                              nullptr, T.runid.as<uint32_t>());
+  // (with the ranks: rank[origin[i]] = run of sorted position i goes out with the runs)
+  run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so,
+                              reinterpret_cast<uint32_t*>(share + D.ranks_at), &rs->nruns, nullptr, T.runid.as<uint32_t>());
   // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
-  D.split = compare_get_tuning().split_frequent != 0 && n >= 32;
   const uint8_t* isfreq = nullptr;
   if (D.split && nm) {
     T.isfreq.ensure(ne);
     HIP_CHECK(hipMemsetAsync(T.isfreq.ptr, 0, ne, s));
-    const uint32_t threshold = std::max<uint32_t>(16u, n / 4);
     hipLaunchKernelGGL(k_freq_mark, dim3((unsigned)std::min<uint64_t>((nm + 255) / 256, 2048)), dim3(256), 0, s, T.starts.as<uint32_t>(),
                        nm, threshold, rs);
     hipLaunchKernelGGL(k_freq_finalize, dim3(1), dim3(64), 0, s, rs, T.isfreq.as<uint8_t>(), std::max<uint32_t>(1u, kMaxFreq / G));
     isfreq = T.isfreq.as<uint8_t>();
   }
   // ---- components of the "shares a hash" graph within my slice (lock-free union-find over the runs of equal hashes)
-  T.parent.ensure((size_t)n * 4);
   uint32_t* roots = reinterpret_cast<uint32_t*>(share + D.roots_at);
-  hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);
+  if (!nm) hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);   // (else: k_whole_nodes / k_slice_gather did)
   if (nm) {
     // A sample of the neighbour pairs first.  A small pool (at most kUfLdsNodes sketches, 4 M hashes): 1/64 of the pairs, in LDS forests of a few
     // workgroups (k_uf_runs_lds; ~8 K pairs each) that k_uf_merge unites -- the contended unions happen in LDS, the global
@@ -1822,7 +1998,8 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       // (one rank's slice of the dense 10 000-sketch collection at 1/64: 207 us there), what they see costs LDS time
       int shift = 8;
       while (shift > 4 && ((uint64_t)nm >> shift) < 6ull * n) shift--;
-      const uint32_t W = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nm >> shift) / 8192));
+      // (~2 K sampled pairs per forest: a lane's pairs are chains of dependent loads, two of them take as long as one)
+      const uint32_t W = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nm >> shift) / 2048));
       T.wroots.ensure((size_t)W * n * 4);
 #define SMH_UF(S_)                                                                                                            \
   if (shift == S_)                                                                                                            \
@@ -1855,13 +2032,21 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   // ---- what the slice publishes: header, roots (written above), range boundaries, local ranks in slice order
   D.dstate.ensure(sizeof(DictState));
   hipLaunchKernelGGL(k_slice_header, dim3(1), dim3(64), 0, s, rs, T.uniq.as<uint64_t>(), nm, reinterpret_cast<SliceHeader*>(share),
-                     G == 1 ? D.dstate.as<DictState>() : (DictState*)nullptr);
+                     G == 1 ? D.dstate.as<DictState>() : (DictState*)nullptr, 0u);
   hipLaunchKernelGGL(k_hbounds, dim3((D.Rg + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), T.uniq.as<uint64_t>(), rs, nm, D.Rg,
                      D.splitters.as<uint64_t>() + rank, reinterpret_cast<uint64_t*>(share + D.hbound_at));   // (slice's lower end: by pointer)
-  if (nm)
-    hipLaunchKernelGGL(k_rank_scatter, dim3((nm + 255) / 256), dim3(256), 0, s, T.runid.as<uint32_t>(), so, (uint64_t)nm,
-                       reinterpret_cast<uint32_t*>(share + D.ranks_at));
   HIP_CHECK(hipGetLastError());
+  if (!D.force_radix && G > 1) {
+    // a share goes to the other owners next (the caller waits for it anyway): it must not be a void one.  (One owner: the
+    // flag travels in the dictionary's state and is looked at where the block compare synchronises, collection_compare.)
+    uint32_t ovf = 0;
+    HIP_CHECK(hipMemcpyAsync(&ovf, &rs->overflow, 4, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (ovf) {
+      dev.count("dictionary_rebuilt");
+      collection_begin_into(D, D.hashes, nullptr, D.rel_off.data(), n, world, rank, dev, s, true);
+    }
+  }
 }
 
 CollectionDict* collection_begin(const uint64_t* hashes_dev, const uint64_t* offsets_dev, const uint64_t* offsets_host, uint32_t n,
@@ -1941,6 +2126,14 @@ static void release_implicit_dict() {
   D.finished = false;
 }
 
+// one owner, and the four-pass sort of the pooled hashes gave up: the dictionary again, with all eight passes (rare: the
+// caller's call takes twice as long)
+static void collection_rebuild(CollectionDict& D, Device& dev, hipStream_t s) {
+  collection_begin_into(D, D.hashes, nullptr, D.rel_off.data(), D.n, D.world, D.rank, dev, s, true);
+  collection_finish(&D, nullptr, dev, s);
+  dev.count("dictionary_rebuilt");
+}
+
 // rows [row_lo, row_hi) x columns [col_lo, col_hi) of the collection's all-vs-all matrix; outputs row-major
 // (row_hi - row_lo) x (col_hi - col_lo).  own_mode: see PairScope (1 needs rows == columns == everything, 2 needs
 // columns == everything; both need one num).
@@ -1976,17 +2169,13 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
   // (800 MB at 10 000 x 10 000), so it runs on the library's second stream beside the plan's small launches and is
   // waited for before the first compare kernel.
   const uint64_t np = (uint64_t)nrows * ncols;
-  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;       // (under the device mutex, one device per process)
+  const hipEvent_t ev_fork = dev.fork_event(), ev_join = dev.join_event();     // (the device's own pair; under its mutex)
   bool fill_pending = false;
   struct FillGuard {            // an error on the way out must not leave the fill writing into the caller's buffers
     bool& pending; hipStream_t s2;
     ~FillGuard() { if (pending) (void)hipStreamSynchronize(s2); }
   } fill_guard{fill_pending, dev.copy_stream()};
   if (!(tune.visit_all_tiles && tune.route == kRouteTiled)) {
-    if (!ev_fork) {
-      HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    }
     // (a small block's fill is a few microseconds: not worth two events)
     const bool beside = np >= (4ull << 20);
     hipStream_t s2 = beside ? dev.copy_stream() : s;
@@ -2187,10 +2376,16 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
 
   // ---- the one synchronisation of the call: what the plan decided, for the record
   PlanState h;
-  uint32_t hd[2] = {0, 0};   // DictState: nruns, nfreq
+  uint32_t hd[4] = {0, 0, 0, 0};   // DictState: nruns, nfreq, part_built, overflow
   HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(PlanState), hipMemcpyDeviceToHost, s));
-  HIP_CHECK(hipMemcpyAsync(hd, D.dstate.ptr, 8, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipMemcpyAsync(hd, D.dstate.ptr, 16, hipMemcpyDeviceToHost, s));
   HIP_CHECK(hipStreamSynchronize(s));
+  if (hd[3] && D.world == 1 && !D.force_radix) {
+    // the dictionary was void (keys that tie in the sorted bits were left out of order: equal hashes may carry different
+    // ranks): what the kernels compared was rubbish, though nothing of it was used as an address.  Again, with the full sort.
+    collection_rebuild(D, dev, s);
+    return collection_compare(Dp, row_lo, row_hi, col_lo, col_hi, num, row_nums, own_mode, out, dev, s);
+  }
   CompareStats rec;
   rec.route = h.route;
   if (h.route == kRouteComponents) {

@@ -21,8 +21,10 @@ void throw_hip(hipError_t e, const char* what, const char* file, int line) {
 //    capped -- 1 GiB by default, SOURMASH_AMD_POOL_MB=<MiB> (0 = no pooling) or smh_pool_set_limit()
 //    change it -- and smh_release_workspace() hands everything back.
 //  * A block freed with sync=false may be handed out again at once.  That is safe for the one caller
-//    that does it (DeviceMirror) because every entry point of the library returns with its device
-//    work complete (include/sourmash_amd.h): no kernel of a finished call can still be reading it.
+//    that does it (DeviceMirror) because every entry point that reads a mirror returns with its device
+//    work complete (include/sourmash_amd.h; the two entry points that leave work open -- a single owner's
+//    collection dictionary, Device::leave_open -- read no mirror): no kernel of a finished call can still
+//    be reading it.
 namespace {
 std::mutex g_pool_mu;
 std::map<std::pair<int, size_t>, std::vector<void*>> g_pool;
@@ -157,13 +159,31 @@ Device::Device() {
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&fence_, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&open_event_, hipEventDisableTiming));
+}
+
+void Device::leave_open(hipStream_t s) {
+  std::lock_guard<std::recursive_mutex> lock(mu_);
+  HIP_CHECK(hipEventRecord(open_event_, s));
+  open_stream_ = s;
+  open_ = true;
+}
+
+void Device::order_after_open(hipStream_t s) {
+  std::lock_guard<std::recursive_mutex> lock(mu_);
+  if (!open_) return;
+  if (hipEventQuery(open_event_) == hipSuccess) { open_ = false; return; }
+  if (s != open_stream_) HIP_CHECK(hipStreamWaitEvent(s, open_event_, 0));
 }
 
 hipStream_t Device::user_stream(void* given) {
-  if (given) return (hipStream_t)given;
   std::lock_guard<std::recursive_mutex> lock(mu_);
+  if (given) { order_after_open((hipStream_t)given); return (hipStream_t)given; }
   HIP_CHECK(hipEventRecord(fence_, nullptr));
   HIP_CHECK(hipStreamWaitEvent(stream_, fence_, 0));
+  order_after_open(stream_);
   return stream_;
 }
 

@@ -72,8 +72,20 @@ class Device {
 
   int id() const { return device_; }
   int cu_count() const { return cus_; }
-  hipStream_t stream() const { return stream_; }
-  hipStream_t copy_stream() const { return copy_stream_; }   // host->device chunks that overlap the hashing
+  // the library's own stream (ordered after work an earlier entry point left open on another stream, see leave_open)
+  hipStream_t stream() { order_after_open(stream_); return stream_; }
+  hipStream_t copy_stream() const { return copy_stream_; }   // host->device chunks that overlap the hashing; the block compare's fill
+  // the pair of events with which a call forks work onto copy_stream() and joins it again (under mutex())
+  hipEvent_t fork_event() const { return ev_fork_; }
+  hipEvent_t join_event() const { return ev_join_; }
+  // Every entry point returns with its device work complete -- except the few that say so (smh_collection_begin with
+  // world == 1, smh_collection_finish without a gathered buffer: a single owner's dictionary is only ever used by later
+  // calls of this library).  Those call leave_open(s) last: an event is recorded behind their work, and EVERY later entry
+  // point, whatever stream it works on, first makes its stream wait for that event (order_after_open, called by stream()
+  // and user_stream()).  So the library's shared scratch buffers (tiled_scratch(), scratch) are never rewritten by a call
+  // on stream B while the open work on stream A still reads them; calls on the same stream are ordered anyway.
+  void leave_open(hipStream_t s);
+  void order_after_open(hipStream_t s);
   // The stream an entry point with a `void *stream` argument works on.  Non-null: the caller's.
   // Null: the library's own (non-blocking) stream, first ordered after everything already queued
   // on the legacy default stream -- a caller whose "current stream" is the default one (torch's
@@ -102,6 +114,10 @@ class Device {
   hipStream_t stream_ = nullptr;
   hipStream_t copy_stream_ = nullptr;
   hipEvent_t fence_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t open_event_ = nullptr;
+  hipStream_t open_stream_ = nullptr;
+  bool open_ = false;
   std::recursive_mutex mu_;
   bool profiling_ = false;
   struct Pending { std::string name; hipEvent_t a, b; };

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "../../include/sourmash_amd.h"
@@ -604,7 +605,15 @@ struct SmhIndex {
   // of the index with itself and kept: later ones skip the pre-pass (the nodes of an index never change)
   smh::CollectionDict* dict = nullptr;
   uint32_t dict_split = 0;      // the frequent-hash setting the dictionary was built under
-  ~SmhIndex() { if (dict) smh::collection_free(dict); }
+  SmhIndex() { std::lock_guard<std::mutex> g(registry_mu()); registry().insert(this); }
+  ~SmhIndex() {
+    { std::lock_guard<std::mutex> g(registry_mu()); registry().erase(this); }
+    if (dict) smh::collection_free(dict);
+  }
+  void drop_dict() { if (dict) { smh::collection_free(dict); dict = nullptr; } }
+  // the live indexes: smh_release_workspace() drops their cached dictionaries (memory no other allocator can see)
+  static std::set<SmhIndex*>& registry() { static auto* r = new std::set<SmhIndex*>(); return *r; }
+  static std::mutex& registry_mu() { static auto* m = new std::mutex(); return *m; }
 };
 
 SmhIndex* smh_index_new(KmerMinHash* const* nodes, uint32_t n_nodes) {
@@ -634,6 +643,13 @@ SmhIndex* smh_index_new(KmerMinHash* const* nodes, uint32_t n_nodes) {
 }
 
 void smh_index_free(SmhIndex* index) { delete index; }
+void smh_index_drop_dictionary(SmhIndex* index) {
+  if (!index) return;
+  (void)pad_code([&] {
+    std::lock_guard<std::recursive_mutex> lock(smh::Device::get().mutex());
+    index->drop_dict();
+  });
+}
 uint32_t smh_index_len(const SmhIndex* index) { return index ? index->n : 0; }
 
 namespace {
@@ -764,10 +780,18 @@ int smh_sketch_export_dev(KmerMinHash* ptr, uint64_t* mins_dev, uint64_t* abunds
     auto& dev = smh::Device::get();
     std::lock_guard<std::recursive_mutex> lock(dev.mutex());
     hipStream_t s = dev.user_stream(stream);
+    if (!(ptr->num == 0 && ptr->max_hash > 0)) smh::throw_internal("smh_sketch_export_dev: only scaled sketches (num == 0, max_hash > 0)");
+    ptr->flush_pending();
+    if (!ptr->dev && ptr->has_abunds && ptr->abunds.size() != ptr->mins.size())
+      smh::throw_internal("smh_sketch_export_dev: the sketch's abundance vector does not match its hashes (a state the reference's merge can "
+                          "leave behind, quirks Q5/Q6); it has no device form");
     ptr->to_device_state();
     const uint64_t n = ptr->dev ? ptr->dev->n : 0;
     *n_out = n;
-    if (n == 0 || capacity < n || !mins_dev) return;
+    if (n == 0 || !mins_dev) return;
+    // a buffer sized from an earlier query, and hashes added since: say so (n_out holds the size needed) -- success with an
+    // unfilled buffer would be taken for an empty part
+    if (capacity < n) smh::throw_internal("smh_sketch_export_dev: capacity is smaller than the sketch (*n_out holds the size needed)");
     smh::DeviceSketch& S = *ptr->dev;
     HIP_CHECK(hipMemcpyAsync(mins_dev, S.uniq.ptr, n * 8, hipMemcpyDeviceToDevice, s));
     if (abunds_dev && ptr->has_abunds) {
@@ -812,8 +836,10 @@ SmhCollection* smh_collection_begin(const uint64_t* hashes_dev, const uint64_t* 
     std::unique_ptr<SmhCollection> c(new SmhCollection());
     c->d = smh::collection_begin(hashes_dev, nullptr, offsets, n, world, rank, dev, s);
     // the share is complete when the call returns (the caller all-gathers it next); a single owner has nobody to hand it
-    // to: its calls are only ordered on the stream
+    // to: its work is left open on the stream, and every later entry point -- on any stream -- is ordered behind it
+    // (Device::leave_open: the shared scratch buffers it still reads are not rewritten under it)
     if (world > 1) HIP_CHECK(hipStreamSynchronize(s));
+    else dev.leave_open(s);
     out = c.release();
   });
   return out;
@@ -846,6 +872,7 @@ int smh_collection_finish(SmhCollection* c, const void* gathered_dev, void* stre
     hipStream_t s = dev.user_stream(stream);
     smh::collection_finish(c->d, gathered_dev, dev, s);
     if (gathered_dev) HIP_CHECK(hipStreamSynchronize(s));   // the gathered buffer may be released by the caller now
+    else dev.leave_open(s);                                  // (a single owner: ordered, not waited for -- see smh_collection_begin)
   });
 }
 int smh_collection_compare(SmhCollection* c, uint32_t row_lo, uint32_t row_hi, uint32_t num, uint32_t ownership,
@@ -946,7 +973,7 @@ void smh_compare_get_tuning(SmhCompareTuning* out) {
   if (!out) return;
   const smh::CompareTuning t = smh::compare_get_tuning();
   out->route = t.route; out->visit_all_tiles = t.visit_all_tiles; out->use_symmetry = t.use_symmetry;
-  out->comp_pairs_limit = t.comp_pairs_limit; out->split_frequent = t.split_frequent;
+  out->comp_pairs_limit = t.comp_pairs_limit; out->split_frequent = t.split_frequent; out->dictionary = t.dictionary;
 }
 int smh_compare_set_tuning(const SmhCompareTuning* in) {
   return pad_code([&] {
@@ -955,6 +982,8 @@ int smh_compare_set_tuning(const SmhCompareTuning* in) {
       if (in->route > smh::kRouteTiled) smh::throw_internal("smh_compare_set_tuning: unknown route");
       t.route = in->route; t.visit_all_tiles = in->visit_all_tiles; t.use_symmetry = in->use_symmetry;
       t.comp_pairs_limit = in->comp_pairs_limit; t.split_frequent = in->split_frequent;
+      if (in->dictionary > 1) smh::throw_internal("smh_compare_set_tuning: unknown dictionary build");
+      t.dictionary = in->dictionary;
     }
     smh::compare_set_tuning(t);
   });
@@ -962,7 +991,16 @@ int smh_compare_set_tuning(const SmhCompareTuning* in) {
 
 // test hook (host only, no device): the compare block's tile planning
 int smh_release_workspace(void) {
-  return pad_code([&] { smh::Engine::get().release_workspace(); });
+  return pad_code([&] {
+    {
+      // the dictionaries resident indexes cached for their all-vs-all compares (ranks, roots, the partition table: up to
+      // hundreds of MB for 10 000 long sketches); the next smh_index_compare of an index with itself rebuilds its own
+      std::lock_guard<std::recursive_mutex> lock(smh::Device::get().mutex());
+      std::lock_guard<std::mutex> g(SmhIndex::registry_mu());
+      for (SmhIndex* i : SmhIndex::registry()) i->drop_dict();
+    }
+    smh::Engine::get().release_workspace();
+  });
 }
 
 void smh_pool_set_limit(uint64_t bytes) { (void)pad_code([&] { smh::device_pool_set_limit((size_t)bytes); }); }

@@ -119,8 +119,10 @@ int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, s
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask);
 // keys[0 .. n) (read only) sorted into k0 or k1 (the return value says which), v0 / v1 alongside = where every sorted key
 // was in `keys`: the first pass reads `keys` and numbers them itself -- no copy of the keys, no index array.  pass_mask != 0.
+// shift_dev (nullable): a device word added to every pass's shift -- pass p sorts by bits [*shift_dev + 8 p, + 8): the caller's
+// passes start at a bit only the device knows (the low end of the 32 most significant bits that vary, see k_key_span).
 int radix_sort_u64_place(const uint64_t* keys, uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                         hipStream_t s, uint32_t pass_mask);
+                         hipStream_t s, uint32_t pass_mask, const uint32_t* shift_dev = nullptr);
 // run_length_encode_u64 without its read-back: *nruns_dev (device) receives the number of runs;
 // skip (device, nullable): non-zero = the launches do nothing
 void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
@@ -186,6 +188,7 @@ struct CompareTuning {
   uint32_t visit_all_tiles = 0;            // 1: launch every tile, not only those that can hold sharing pairs
   uint32_t use_symmetry = 1;               // all-vs-all with one num: compute the upper triangle, mirror the rest
   uint32_t split_frequent = 1;             // hashes held by a large share of the sketches do not make components
+  uint32_t dictionary = 0;                 // 1: the pooled sort of the dictionary with all eight byte passes (default: four + tie fix)
   uint64_t comp_pairs_limit = 96ull << 10;  // at most this many sharing pairs: per-component pair kernel, else tiled (the pair kernel
                                            // takes ~3.7 ns per pair of num = 2000 sketches, one round of tiles ~0.45 ms: profiles/r03_tile_shape.txt)
 };
@@ -197,7 +200,7 @@ struct CompareStats {                      // of the last block compare
   uint32_t frequent_hashes = 0;            // hashes set aside as frequent (decided from per-sketch positions, not walked)
   uint32_t pipelined = 0;                  // tiled: k_compare_tiled_pf walked the tiles
   uint32_t span_halvings = 0;              // pipelined kernel: stretches rebuilt with a halved span (their speculative span did not fit LDS)
-  uint32_t prefetched_after_halving = 0;   // ... tables built from prefetched crossings later in a tile that had such a rebuild
+  uint32_t prefetched_after_halving = 0;   // ... tiles in which prefetched crossings were used after such a rebuild
 };
 void compare_set_tuning(const CompareTuning& t);
 CompareTuning compare_get_tuning();

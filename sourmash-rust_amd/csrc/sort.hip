@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <stdint.h>
 
+#include "block_sort.hpp"
 #include "device.hpp"
 #include "kernels.hpp"
 
@@ -26,11 +27,6 @@ constexpr int kSortThreads = 256;   // one thread per digit value in the count /
 constexpr int kSortItems = 8;                        // keys per thread per tile (16 KB LDS stage: 6 workgroups per CU)
 constexpr int kSortTile = kSortThreads * kSortItems;  // 2048 keys per workgroup
 constexpr int kWaves = kSortThreads / 64;
-
-__device__ __forceinline__ uint64_t lanemask_lt() {
-  uint32_t lane = __lane_id();
-  return lane == 0 ? 0ull : (~0ull >> (64 - lane));
-}
 
 // ---------------------------------------------------------------------------------
 // all eight digit histograms in one read of the keys (decides which passes can be skipped)
@@ -51,11 +47,13 @@ __global__ __launch_bounds__(256) void k_hist_all(const uint64_t* __restrict__ k
 }
 
 // per-workgroup histogram of one digit; layout digit-major so one scan orders everything
+// (shift_add, nullable: a device word added to the shift -- the caller's passes start at a bit only the device knows)
 __global__ __launch_bounds__(kSortThreads) void k_radix_count(const uint64_t* __restrict__ keys,
                                                               size_t n, int shift,
                                                               uint32_t* __restrict__ blockhist,
-                                                              uint32_t nblocks) {
+                                                              uint32_t nblocks, const uint32_t* __restrict__ shift_add) {
   __shared__ uint32_t h[256];
+  if (shift_add) shift += (int)*shift_add;
   if (threadIdx.x < 256) h[threadIdx.x] = 0;
   __syncthreads();
   size_t base = (size_t)blockIdx.x * kSortTile;
@@ -177,8 +175,9 @@ template <int VB>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
     const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout, const void* __restrict__ vin_,
     void* __restrict__ vout_, size_t n, int shift, const uint32_t* __restrict__ scanned,
-    uint32_t nblocks, const uint32_t* __restrict__ digit_tot) {
+    uint32_t nblocks, const uint32_t* __restrict__ digit_tot, const uint32_t* __restrict__ shift_add) {
   __shared__ uint32_t wcount[kWaves][256];
+  if (shift_add) shift += (int)*shift_add;
   __shared__ uint32_t wtot2[kWaves];
   __shared__ uint32_t lbase[kWaves][256];   // position in the digit-ordered tile of (wave, digit)'s first key
   __shared__ uint32_t dexcl[256];           // first position of digit d in the digit-ordered tile
@@ -297,92 +296,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(
 }
 
 // ---------------------------------------------------------------------------------
-// Up to 8192 keys: the radix passes inside ONE workgroup, keys and their places in LDS, one launch instead of twenty-one.
-// Same ranking as k_radix_scatter (lanes holding the same digit found with eight ballots, per-wave digit counters); a
-// pass reads every key into registers and -- after the barriers -- writes it back to the same array at its new place.
-// One bacterial genome per call (5 Mbp -> 5 059 candidates at scaled=1000) spent 150 of its 245 us in those launches.
-constexpr int kBlockSortMax = 8192;                // with the keys' places (payload): 64 + 16 KB of LDS
-constexpr int kBsThreads = 1024, kBsWaves = kBsThreads / 64;   // (16 waves hide the LDS latency of a pass better than 8: -4..8 %)
-template <int CAP, bool WithIdx>
-struct BlockSortLds {
-  uint64_t sk[CAP];
-  uint16_t si[WithIdx ? CAP : 1];
-  uint16_t wcount[kBsWaves][256];   // (16 bits are enough: at most CAP keys)
-  uint16_t lbase[kBsWaves][256];
-  uint32_t wtot[kBsWaves];
-  uint32_t skip;
-};
-// the eight passes over L.sk[0 .. items * 512) (and L.si, the keys' original places, when WithIdx); ends on a barrier
-template <int CAP, bool WithIdx>
-__device__ __forceinline__ void block_sort_passes(BlockSortLds<CAP, WithIdx>& L, uint32_t n, uint32_t items) {
-  constexpr int kBsItems = CAP / kBsThreads;
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const uint32_t covered = items * kBsThreads;
-  const uint64_t lt = lanemask_lt();
-  const uint32_t wbase = (uint32_t)w * items * 64;
-  for (int shift = 0; shift < 64; shift += 8) {
-    for (int i = t; i < kBsWaves * 256; i += kBsThreads) (&L.wcount[0][0])[i] = 0;
-    static_assert(CAP <= 65535 + 1, "16-bit counters");
-    if (t == 0) L.skip = 0;
-    __syncthreads();
-    uint64_t key[kBsItems];
-    uint32_t meta[kBsItems];   // digit << 16 | rank among the wave's keys with that digit
-    uint16_t idx[kBsItems];
-#pragma unroll
-    for (int i = 0; i < kBsItems; i++) {
-      key[i] = 0; meta[i] = 0; idx[i] = 0;
-      if ((uint32_t)i < items) {
-        const uint32_t pos = wbase + (uint32_t)i * 64 + lane;
-        const uint64_t k = L.sk[pos];
-        const uint32_t d = (uint32_t)(k >> shift) & 255u;
-        key[i] = k;
-        if (WithIdx) idx[i] = L.si[pos];
-        uint64_t m = ~0ull;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-          const uint64_t bal = __ballot((d >> b) & 1);
-          m &= ((d >> b) & 1) ? bal : ~bal;
-        }
-        const uint32_t prior = L.wcount[w][d];
-        const uint32_t below = (uint32_t)__popcll(m & lt);
-        meta[i] = (d << 16) | (prior + below);
-        if (below == 0) L.wcount[w][d] = (uint16_t)(prior + (uint32_t)__popcll(m));
-      }
-    }
-    __syncthreads();
-    uint32_t tot = 0, incl = 0;
-    if (t < 256) {   // thread d: the keys with digit d
-#pragma unroll
-      for (int ww = 0; ww < kBsWaves; ww++) tot += L.wcount[ww][t];
-      // every real key has this digit (the pads -- all ones, always at the end -- count under digit 255): identity
-      if (tot - (t == 255 ? covered - n : 0u) == n) L.skip = 1;
-      incl = tot;
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
-      if (lane == 63) L.wtot[w] = incl;
-    }
-    __syncthreads();
-    if (t < 256) {   // where digit d starts, and inside it where each wave's keys go
-      uint32_t run = incl - tot;
-      for (int ww = 0; ww < w; ww++) run += L.wtot[ww];
-#pragma unroll
-      for (int ww = 0; ww < kBsWaves; ww++) { L.lbase[ww][t] = (uint16_t)run; run += L.wcount[ww][t]; }
-    }
-    __syncthreads();
-    if (!L.skip) {
-#pragma unroll
-      for (int i = 0; i < kBsItems; i++)
-        if ((uint32_t)i < items) {
-          const uint32_t np = L.lbase[w][meta[i] >> 16] + (meta[i] & 0xFFFFu);
-          L.sk[np] = key[i];
-          if (WithIdx) L.si[np] = idx[i];
-        }
-    }
-    __syncthreads();
-  }
-}
 template <int VB>
 __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __restrict__ kin, uint64_t* __restrict__ kout,
                                                            const void* __restrict__ vin_, void* __restrict__ vout_, uint32_t n) {
@@ -393,7 +306,7 @@ __global__ __launch_bounds__(kBsThreads) void k_block_sort(const uint64_t* __res
     L.sk[i] = i < n ? kin[i] : ~0ull;                                // pads sort last (after a real ~0 key: they come later)
     L.si[i] = (uint16_t)i;
   }
-  block_sort_passes<kBlockSortMax, true>(L, n, items);
+  block_sort_passes(L, n, items);
   for (uint32_t i = t; i < n; i += kBsThreads) {
     kout[i] = L.sk[i];
     if (VB == 8) static_cast<uint64_t*>(vout_)[i] = static_cast<const uint64_t*>(vin_)[L.si[i]];
@@ -419,7 +332,7 @@ __global__ __launch_bounds__(kBsThreads) void k_small_fold(const uint64_t* __res
   const uint32_t n = (uint32_t)n64;
   const uint32_t items = (n + kBsThreads - 1) / kBsThreads;
   for (uint32_t i = t; i < items * kBsThreads; i += kBsThreads) L.sk[i] = i < n ? kin[i] : ~0ull;
-  if (n) block_sort_passes<CAP, false>(L, n, items);
+  if (n) block_sort_passes(L, n, items);
   __syncthreads();
   // run heads: thread t owns slots [t * items, (t + 1) * items)
   const uint32_t lo = t * items;
@@ -491,11 +404,25 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
                                                            const uint32_t* __restrict__ origin,
                                                            uint32_t* __restrict__ rank_out,
                                                            const uint32_t* __restrict__ skip,
-                                                           uint32_t* __restrict__ runid_out) {
+                                                           uint32_t* __restrict__ runid_out,
+                                                           uint32_t self_sum_blocks = 0, uint32_t* __restrict__ nruns_out = nullptr) {
   constexpr int NW = kRleThreads / 64;
   static_assert(kRleItems * NW <= 64, "k_rle_write: one wave scans the per-row, per-wave head counts");
   __shared__ uint32_t wcnt[kRleItems * NW];
+  __shared__ uint32_t before_all[NW];
   if (skip && *skip) return;
+  // self_sum_blocks != 0: bscan holds the blocks' head COUNTS, not their scan -- a few thousand of them at most: every
+  // workgroup adds up the ones before its own (two launches less than scanning them first), the last one also the total
+  uint32_t mine_before = 0;
+  if (self_sum_blocks) {
+    uint32_t acc = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kRleThreads) acc += bscan[i];
+    for (int off = 32; off; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) before_all[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    for (int i = 0; i < NW; i++) mine_before += before_all[i];
+    if (nruns_out && blockIdx.x + 1 == self_sum_blocks && threadIdx.x == 0) *nruns_out = mine_before + bscan[blockIdx.x];
+  }
   const size_t tile0 = (size_t)blockIdx.x * kRleTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -523,7 +450,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
     if (threadIdx.x < kRleItems * NW) wcnt[threadIdx.x] = incl - v;
   }
   __syncthreads();
-  const uint32_t o0 = bscan[blockIdx.x];
+  const uint32_t o0 = self_sum_blocks ? mine_before : bscan[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < kRleItems; i++) {
     const size_t idx = tile0 + (size_t)i * kRleThreads + threadIdx.x;
@@ -616,7 +543,8 @@ static size_t scan_tmp_entries(size_t m) { return (m + kScanChunk - 1) / kScanCh
 // the payload (vbytes 4) starts as every key's index in first_in -- the caller's array stays untouched and no index array is made.
 static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int vbytes, size_t n,
                            DeviceBuffer& scratch, hipStream_t s, int first_pass, int last_pass, uint32_t pass_mask = 0,
-                           const uint64_t* first_in = nullptr) {
+                           const uint64_t* first_in = nullptr, const uint32_t* shift_dev = nullptr) {
+  if (shift_dev && !pass_mask) throw_internal("radix_sort: a device-side shift needs a pass mask");
   if (first_in && (!pass_mask || vbytes != 4 || !v0)) throw_internal("radix_sort: first_in needs a pass mask and a 32-bit payload");
   if (n < 2) {
     if (first_in && n == 1) {
@@ -666,7 +594,7 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
         if (hh[p * 256 + d] == n) { trivial = true; break; }
     if (trivial) continue;  // every key has the same digit: the pass is the identity
     if (src_first) {        // the first pass that runs reads the caller's keys and numbers them
-      hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, src_first, n, 8 * p, blockhist, nblocks);
+      hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, src_first, n, 8 * p, blockhist, nblocks, shift_dev);
       const uint32_t* dt = nullptr;
       if (nblocks <= kRowScanMax) {
         hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, blockhist, nblocks, scan_tmp);
@@ -675,14 +603,14 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
         exclusive_scan_u32(blockhist, (size_t)256 * nblocks, nullptr, scan_tmp, s);
       }
       hipLaunchKernelGGL(k_radix_scatter<4>, dim3(nblocks), dim3(kSortThreads), 0, s, src_first, kk[cur ^ 1], nullptr, vv[cur ^ 1], n, 8 * p,
-                         blockhist, nblocks, dt);
+                         blockhist, nblocks, dt, shift_dev);
       HIP_CHECK(hipGetLastError());
       src_first = nullptr;
       cur ^= 1;
       continue;
     }
     hipLaunchKernelGGL(k_radix_count, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur], n, 8 * p,
-                       blockhist, nblocks);
+                       blockhist, nblocks, shift_dev);
     const uint32_t* dtot = nullptr;
     if (nblocks <= kRowScanMax) {
       hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, blockhist, nblocks, scan_tmp);
@@ -692,13 +620,13 @@ static int radix_sort_impl(uint64_t* k0, uint64_t* k1, void* v0, void* v1, int v
     }
     if (v0 && vbytes == 8)
       hipLaunchKernelGGL(k_radix_scatter<8>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot);
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot, shift_dev);
     else if (v0 && vbytes == 4)
       hipLaunchKernelGGL(k_radix_scatter<4>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot);
+                         kk[cur ^ 1], vv[cur], vv[cur ^ 1], n, 8 * p, blockhist, nblocks, dtot, shift_dev);
     else
       hipLaunchKernelGGL(k_radix_scatter<0>, dim3(nblocks), dim3(kSortThreads), 0, s, kk[cur],
-                         kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks, dtot);
+                         kk[cur ^ 1], nullptr, nullptr, n, 8 * p, blockhist, nblocks, dtot, shift_dev);
     HIP_CHECK(hipGetLastError());
     cur ^= 1;
   }
@@ -725,8 +653,8 @@ int radix_sort_u64_v32(uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, s
   return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask);
 }
 int radix_sort_u64_place(const uint64_t* keys, uint64_t* k0, uint64_t* k1, uint32_t* v0, uint32_t* v1, size_t n, DeviceBuffer& scratch,
-                         hipStream_t s, uint32_t pass_mask) {
-  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask, keys);
+                         hipStream_t s, uint32_t pass_mask, const uint32_t* shift_dev) {
+  return radix_sort_impl(k0, k1, v0, v1, 4, n, scratch, s, 0, 8, pass_mask, keys, shift_dev);
 }
 int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scratch, hipStream_t s, uint32_t pass_mask) {
   return radix_sort_impl(k0, k1, nullptr, nullptr, 0, n, scratch, s, 0, 8, pass_mask);
@@ -743,9 +671,16 @@ void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq,
   scratch.ensure((size_t)(nblocks + 1 + scan_tmp_entries(nblocks)) * sizeof(uint32_t));
   auto* bc = (uint32_t*)scratch.ptr;
   hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, n, bc, skip);
+  if (nblocks <= 4096 && !skip) {
+    // (launch-bound sizes: the write kernel adds up the block counts itself and leaves the total -- two launches instead of five)
+    hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, (uint64_t*)nullptr, n, bc,
+                       uniq, starts, origin, rank_out, skip, runid_out, nblocks, nruns_dev);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, (uint64_t*)nullptr, n, bc,
-                     uniq, starts, origin, rank_out, skip, runid_out);
+                     uniq, starts, origin, rank_out, skip, runid_out, 0u, (uint32_t*)nullptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(nruns_dev, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 }
@@ -761,7 +696,7 @@ uint32_t run_length_encode_u64(const uint64_t* keys, size_t n, uint64_t* uniq, u
   hipLaunchKernelGGL(k_rle_count, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, n, bc, (const uint32_t*)nullptr);
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, key2, key2_shift, uniq2, n, bc, uniq,
-                     starts, origin, rank_out, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                     starts, origin, rank_out, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
   HIP_CHECK(hipGetLastError());
   uint32_t nruns = 0;
   HIP_CHECK(hipMemcpyAsync(&nruns, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

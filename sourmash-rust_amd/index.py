@@ -50,6 +50,10 @@ class ResidentIndex:
     def __len__(self):
         return self._L.smh_index_len(self._h)
 
+    def drop_dictionary(self):
+        """gives back the dictionary an all-vs-all compare of the index with itself cached (smh_index_drop_dictionary)"""
+        self._L.smh_index_drop_dictionary(self._h)
+
     def find(self, query, threshold, containment=False):
         out = (C.c_uint32 * max(len(self.nodes), 1))()
         cnt = C.c_uint32()

@@ -11,13 +11,15 @@ from ._lib import SmhCompareStats, SmhCompareTuning, f64p, lib, u64p
 from .errors import call
 
 ROUTES = {"auto": 0, "wave": 1, "few": 2, "components": 3, "tiled": 4}
+DICTIONARIES = {"auto": 0, "full": 1}
 
 
 @contextlib.contextmanager
-def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=96 << 10, split_frequent=True):
+def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=96 << 10, split_frequent=True, dictionary="auto"):
     """Pins which kernel serves the block compares inside the `with` (additive ABI
     smh_compare_set_tuning; results never depend on it), then restores the defaults."""
-    t = SmhCompareTuning(ROUTES[route], int(visit_all_tiles), int(use_symmetry), comp_pairs_limit, int(split_frequent))
+    t = SmhCompareTuning(ROUTES[route], int(visit_all_tiles), int(use_symmetry), comp_pairs_limit, int(split_frequent),
+                         DICTIONARIES[dictionary])
     call(lib().smh_compare_set_tuning, C.byref(t))
     try:
         yield

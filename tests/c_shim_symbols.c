@@ -90,6 +90,43 @@ int main(void) {
     (void)smh_index_len; (void)smh_index_find;
   }
   sourmash_err_clear();
+
+  /* the reference's own known answers through the legacy symbols, on the device (reference tests/minhash.rs:18-51: two
+   * sketches fed two strings each, merged -> eight exact hashes; tests/minhash.rs:54-83: compare == 1.0 / >= 0.3;
+   * tests/minhash.rs:5-16: 'R' is refused) */
+  if (gpu) {
+    KmerMinHash *x = kmerminhash_new(20, 10, false, 42, 0, false), *y = kmerminhash_new(20, 10, false, 42, 0, false);
+    kmerminhash_add_sequence(x, "TGCCGCCCAGCA", false);
+    kmerminhash_add_sequence(y, "TGCCGCCCAGCA", false);
+    kmerminhash_add_sequence(x, "GTCCGCCCAGTGA", false);
+    kmerminhash_add_sequence(y, "GTCCGCCCAGTGG", false);
+    kmerminhash_merge(x, y);
+    CHECK(sourmash_err_get_last_code() == 0);
+    const uint64_t want[8] = {2996412506971915891ULL, 4448613756639084635ULL, 8373222269469409550ULL, 9390240264282449587ULL,
+                              11085758717695534616ULL, 11668188995231815419ULL, 11760449009842383350ULL, 14682565545778736889ULL};
+    CHECK(kmerminhash_get_mins_size(x) == 8);
+    const uint64_t *got = kmerminhash_get_mins(x);
+    for (int i = 0; i < 8; i++) CHECK(got[i] == want[i]);
+    free((void *)got);
+    kmerminhash_free(x); kmerminhash_free(y);
+    const char *s1 = "TGCCGCCCAGCACCGGGTGACTAGGTTGAGCCATGATTAACCTGCAATGA", *s2 = "GATTGGTGCACACTTAACTGGGTGCCGCGCTGGTGCTGATCCATGAAGTT";
+    x = kmerminhash_new(20, 10, false, 42, 0, false); y = kmerminhash_new(20, 10, false, 42, 0, false);
+    kmerminhash_add_sequence(x, s1, false);
+    kmerminhash_add_sequence(y, s1, false);
+    CHECK(kmerminhash_compare(x, y) == 1.0 && kmerminhash_compare(y, x) == 1.0);
+    kmerminhash_add_sequence(y, s1, false);
+    CHECK(kmerminhash_compare(x, y) == 1.0 && kmerminhash_compare(y, x) == 1.0);
+    kmerminhash_add_sequence(y, s2, false);
+    CHECK(kmerminhash_compare(x, y) >= 0.3 && kmerminhash_compare(y, x) >= 0.3 && kmerminhash_compare(x, y) < 1.0);
+    CHECK(sourmash_err_get_last_code() == 0);
+    kmerminhash_free(x); kmerminhash_free(y);
+    x = kmerminhash_new(1, 4, false, 42, 0, false);
+    kmerminhash_add_sequence(x, "ATGR", false);
+    CHECK(sourmash_err_get_last_code() == SOURMASH_ERROR_CODE_INVALID_D_N_A);
+    sourmash_err_clear();
+    CHECK(hash_murmur("ACG", 42) == 1731421407650554201ULL);       /* reference tests/test.rs:5 */
+    kmerminhash_free(x);
+  }
   kmerminhash_free(a); kmerminhash_free(b); kmerminhash_free(c);
   printf("c shim symbols ok (%s)\n", gpu ? "gpu" : "no gpu");
   return 0;

@@ -23,6 +23,9 @@ ROUTES = [
     pytest.param(dict(route="tiled", visit_all_tiles=True, use_symmetry=False), "tiled", id="tiled-all-tiles-nosym"),
     pytest.param(dict(split_frequent=False), None, id="auto-no-frequent-split"),
     pytest.param(dict(route="tiled", split_frequent=False), "tiled", id="tiled-no-frequent-split"),
+    # the pooled sort of the dictionary with all eight byte passes instead of four + the tie fix
+    pytest.param(dict(dictionary="full"), None, id="auto-full-sort-dictionary"),
+    pytest.param(dict(route="tiled", dictionary="full"), "tiled", id="tiled-full-sort-dictionary"),
 ]
 
 
@@ -204,6 +207,161 @@ def test_tiled_block_edge_cases(tune, expect, pkg, coracle):
     out2 = routed(pkg, tune, expect, lambda: pkg.matrix.compare_block(row_mh, col_mh, want=("jaccard", "common", "size")))
     assert (out2["jaccard"] == out["jaccard"]).all() and (out2["common"] == out["common"]).all()
     assert (out2["size"] == out["size"]).all()
+
+
+@pytest.mark.parametrize("num", [0, 400])
+def test_halved_span_ahead_of_a_prefetched_crossing(num, pkg, coracle):
+    """The shape that made the pipelined tiled kernel fault on a development build of round 3 ("The fault of
+    round 3"): sketches that are sparse over most of rank space -- the span of a stretch doubles while its segments fit the
+    LDS stage, and the boundary crossings of the stretch after the next are requested ahead -- and then hold a burst of
+    consecutive pool values, so that a stretch does NOT fit at the span it tried and is rebuilt with halved spans while
+    crossings requested for the boundary it would have had are in flight.  Bursts at jittered places, so that the rebuild
+    meets the prefetch at every alignment; rows and columns with bursts at the same and at different places.  Every pair
+    against the oracle; the stats say that spans were halved and that prefetched crossings were used afterwards."""
+    import torch
+    rng = np.random.RandomState(5)
+    pool = np.unique(rng.randint(0, 1 << 62, size=64000, dtype=np.int64).astype(np.uint64))[:60000]
+    starts = np.arange(700, 59000, 1900) + rng.randint(0, 600, size=len(np.arange(700, 59000, 1900)))
+
+    def sketch(k_sparse, burst_ids, every):
+        idx = set(rng.choice(len(pool), k_sparse, replace=False).tolist())
+        for b in burst_ids:
+            idx.update(range(int(starts[b]), int(starts[b]) + 80 * every, every))
+        return pool[np.array(sorted(idx))]
+
+    rows, cols = [], []
+    for i in range(70):
+        kind = i % 5
+        if kind == 0:
+            rows.append(sketch(150, [], 1))                                   # sparse only: spans grow to 64 ranges
+        elif kind == 4 and i == 4:
+            rows.append(np.sort(rng.choice(pool, 4800, replace=False)))       # the longest sketch sets the range granularity
+        else:
+            rows.append(sketch(120 + 40 * kind, rng.choice(len(starts), 3 + kind, replace=False), 1 + kind % 3))
+    for j in range(150):
+        kind = j % 4
+        cols.append(sketch(100 + 100 * kind, rng.choice(len(starts), 2 * kind, replace=False) if kind else [], 1 + j % 4))
+    rf, ro = pkg.matrix.csr_from_sketches(rows)
+    cf, co = pkg.matrix.csr_from_sketches(cols)
+    tr, tc = torch.from_numpy(rf.view(np.int64)).cuda(), torch.from_numpy(cf.view(np.int64)).cuda()
+    ocommon, osize, ojac = coracle.compare_matrix(rows, cols, num, 21, 0)
+    occ = np.array([[len(np.intersect1d(a, b, assume_unique=True)) for b in cols] for a in rows], dtype=np.int64)
+    halvings = after = 0
+    for tune in (dict(route="tiled"), dict(route="tiled", visit_all_tiles=True)):
+        with pkg.matrix.tuning(**tune):
+            out = pkg.matrix.compare_block_dev(tr, ro, tc, co, num, want=("jaccard", "common", "size", "count_common"))
+            st = pkg.matrix.last_stats()
+        assert st["route"] == "tiled" and st["pipelined"] == 1, st
+        halvings += st["span_halvings"]; after += st["prefetched_after_halving"]
+        assert (out["jaccard"].cpu().numpy() == ojac).all()
+        assert (out["common"].cpu().numpy().view(np.uint64) == ocommon).all()
+        assert (out["size"].cpu().numpy().view(np.uint64) == osize).all()
+        assert (out["count_common"].cpu().numpy() == occ).all()
+    assert halvings > 50 and after > 50, (halvings, after)
+
+
+def _profile_count(pkg, name):
+    import ctypes as C
+    ms, k = C.c_double(), C.c_uint64()
+    pkg.lib().smh_profile_get(name, C.byref(ms), C.byref(k))
+    return k.value
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_four_pass_dictionary_equals_the_full_sort_dictionary(seed, pkg, coracle):
+    """The pooled hashes of the dictionary are sorted by the 32 most significant bits that vary, and the keys that tie there
+    are put in order afterwards (k_tie_fix, k_tie_sort); on request, or when that gives up, by all eight byte passes.
+    Ragged random collections -- empty sketches, one long sketch, hashes that are small integers (no high bits: the span
+    comes from the data), hashes near 2^64, hashes held by most sketches (runs of equal keys that tie with other keys) --
+    must give the same matrix both ways, on the default route and on the tiled one, and the oracle's on sampled rows."""
+    import torch
+    rng = np.random.RandomState(100 + seed)
+    n = [37, 700, 2500][seed - 1]
+    shift = [0, 20, 44][seed - 1]
+    pool = np.unique(rng.randint(1, 1 << 20, size=30000, dtype=np.int64).astype(np.uint64)) << np.uint64(shift)
+    if seed == 3:
+        pool = np.concatenate([pool, np.uint64(0xFFFFFFFFFFFFFFFF) - np.arange(50, dtype=np.uint64)[::-1]])
+    common = pool[rng.choice(len(pool), 5, replace=False)]
+    sk = []
+    for i in range(n):
+        k = int(rng.choice([0, 1, 3, 40, 200, 600]))
+        if i == 5:
+            k = 4000
+        h = rng.choice(pool, k, replace=False) if k else np.zeros(0, np.uint64)
+        if i % 3 and k:
+            h = np.concatenate([h, common])               # five hashes held by two thirds of the sketches
+        sk.append(np.unique(h))
+    flat, off = pkg.matrix.csr_from_sketches(sk)
+    t = torch.from_numpy(flat.view(np.int64)).cuda()
+    num = [0, 150, 25][seed - 1]
+    names = ("jaccard", "common", "size", "count_common", "containment")
+    outs = {}
+    for key, tune in (("b", dict()), ("r", dict(dictionary="full")), ("bt", dict(route="tiled")), ("rt", dict(route="tiled", dictionary="full")),
+                      ("bn", dict(split_frequent=False))):
+        with pkg.matrix.tuning(**tune):
+            outs[key] = pkg.matrix.compare_block_dev(t, off, t, off, num, want=names)
+    for key in ("r", "bt", "rt", "bn"):
+        for name in names:
+            a, b = outs["b"][name], outs[key][name]
+            assert bool(((a == b) | ((a != a) & (b != b))).all()), (key, name)
+    rows = sorted(set(rng.choice(n, min(n, 12), replace=False).tolist() + [5]))
+    ocommon, osize, ojac = coracle.compare_matrix([sk[i] for i in rows], sk, num, 21, 0)
+    idx = torch.tensor(rows, device="cuda")
+    assert (outs["b"]["jaccard"][idx].cpu().numpy() == ojac).all()
+    assert (outs["b"]["common"][idx].cpu().numpy().view(np.uint64) == ocommon).all()
+    assert (outs["b"]["size"][idx].cpu().numpy().view(np.uint64) == osize).all()
+
+
+def test_a_tie_group_too_long_for_lds_sends_the_dictionary_to_the_full_sort(pkg, coracle):
+    """3 000 sketches that all hold the same four neighbouring hashes: 12 000 keys that tie in the 32 sorted bits and arrive
+    interleaved -- more than k_tie_sort's LDS sort takes.  The build raises its overflow flag, the block compare notices
+    where it synchronises anyway, rebuilds the dictionary with all eight passes and runs again: same results as the oracle,
+    and the rebuild is on record.  Sharded over two owners (a share must not leave a rank void) as well."""
+    import torch
+    from sourmash_rust_amd import distributed as D
+    rng = np.random.RandomState(9)
+    n = 3000
+    shared = np.array([1 << 40, (1 << 40) + 1, (1 << 40) + 2, (1 << 40) + 5], dtype=np.uint64)
+    pool = np.unique(rng.randint(1, 1 << 62, size=200000, dtype=np.int64).astype(np.uint64))
+    sk = [np.unique(np.concatenate([shared, rng.choice(pool, int(rng.randint(5, 60)), replace=False)])) for _ in range(n)]
+    flat, off = pkg.matrix.csr_from_sketches(sk)
+    t = torch.from_numpy(flat.view(np.int64)).cuda()
+    before = _profile_count(pkg, b"dictionary_rebuilt")
+    out = pkg.matrix.compare_block_dev(t, off, t, off, 30, want=("jaccard", "common", "size"))
+    assert _profile_count(pkg, b"dictionary_rebuilt") == before + 1
+    rows = [0, 1, 1500, 2999]
+    ocommon, osize, ojac = coracle.compare_matrix([sk[i] for i in rows], sk, 30, 21, 0)
+    idx = torch.tensor(rows, device="cuda")
+    assert (out["jaccard"][idx].cpu().numpy() == ojac).all()
+    assert (out["common"][idx].cpu().numpy().view(np.uint64) == ocommon).all()
+    assert (out["size"][idx].cpu().numpy().view(np.uint64) == osize).all()
+    outs = D.simulate_sharded((t, off), n, 30, 2, want=("jaccard",))
+    assert bool((torch.cat([o["jaccard"] for o in outs]) == out["jaccard"]).all())
+
+
+def test_keys_that_differ_only_in_their_low_bits_are_sorted_in_lds(pkg, coracle):
+    """The pooled sort of the dictionary looks at the 32 most significant bits that vary and puts the few keys that tie there
+    in order afterwards (k_tie_fix) -- good for hashes.  These are not: a span of 2^63 with thousands of distinct keys packed
+    into 2^13 values at its top.  They tie in the sorted bits and arrive out of order from their sketches: one group of
+    ~8 000 keys, which k_tie_sort sorts in LDS (no rebuild).  Same numbers as the oracle."""
+    import torch
+    rng = np.random.RandomState(77)
+    top = (np.uint64(1) << np.uint64(63)) + np.arange(8192, dtype=np.uint64)
+    low = np.unique(rng.randint(1, 1 << 40, size=3000, dtype=np.int64).astype(np.uint64))
+    n = 70
+    sk = [np.unique(np.concatenate([rng.choice(top, int(rng.randint(20, 100)), replace=False), rng.choice(low, 30, replace=False)]))
+          for _ in range(n)]                      # (at most 7 000 keys in the group: it fits the LDS sort)
+    flat, off = pkg.matrix.csr_from_sketches(sk)
+    t = torch.from_numpy(flat.view(np.int64)).cuda()
+    before = _profile_count(pkg, b"dictionary_rebuilt")
+    out = pkg.matrix.compare_block_dev(t, off, t, off, 60, want=("jaccard", "common", "size", "count_common"))
+    assert _profile_count(pkg, b"dictionary_rebuilt") == before
+    ocommon, osize, ojac = coracle.compare_matrix(sk, sk, 60, 21, 0)
+    assert (out["jaccard"].cpu().numpy() == ojac).all()
+    assert (out["common"].cpu().numpy().view(np.uint64) == ocommon).all()
+    assert (out["size"].cpu().numpy().view(np.uint64) == osize).all()
+    occ = np.array([[len(np.intersect1d(a, b, assume_unique=True)) for b in sk] for a in sk], dtype=np.int64)
+    assert (out["count_common"].cpu().numpy() == occ).all()
 
 
 def _oracle_rows(coracle, sigs, rows, num):

@@ -36,7 +36,7 @@ def test_bench_two_ranks_sharing_the_gpu(pkg):
     env = _multi_gpu_env(2)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
-           "--gb", "0.2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--compare-n", "601"]
+           "--gb", "0.2", "--protein-gb", "0.2", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--compare-n", "601"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -54,6 +54,10 @@ def test_bench_two_ranks_sharing_the_gpu(pkg):
     assert c["exchange_verified"] is True
     for key in ("families", "one_component", "one_family"):
         assert c[key]["exchange_verified"] is True and c[key]["verified_rows_rank0"] >= 16
+    # configs[4]'s share through the protein arm, then ONE signature from the ranks' partial sketches (abundances added)
+    pr = d["protein"]
+    assert pr["value"] > 0 and pr["unit"] == "windows/s" and pr["roofline"]["kernel_ms_avg"] > 0
+    assert pr["union_across_ranks"]["verified"] is True and pr["union_across_ranks"]["hashes"] > pr["config"]["retained_hashes"]
     assert "strong" in c["scaling"] and "used" in c["symmetry"]
     assert set(c["families"]["rank0_phase_ms"]) >= {"all_gather_signatures", "dictionary_slice", "all_gather_shares", "compare", "exchange_mirrors"}
 
@@ -64,7 +68,7 @@ def test_bench_gpus_2_with_no_launcher_around_it(pkg):
     env = _multi_gpu_env(2)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "bench.py", "--gpus", "2", "--gb", "0.1", "--steps", "1", "--warmup", "0", "--compare-n", "300"]
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--gb", "0.1", "--protein-gb", "0.1", "--steps", "1", "--warmup", "0", "--compare-n", "300"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -187,3 +187,75 @@ def test_collection_degenerate_shapes(world, pkg, coracle):
                 outs = D.simulate_sharded((t, off), n, num, world, want=("common", "jaccard"))
                 got = torch.cat([o["common"] for o in outs]).cpu().numpy().view(np.uint64)
                 assert (got == common).all(), (name, world, num)
+
+
+def test_open_dictionary_work_is_ordered_before_calls_on_other_streams(pkg):
+    """smh_collection_begin (world 1) and smh_collection_finish (no gathered buffer) return with their kernels still queued
+    on the caller's stream A.  A call that follows on ANOTHER stream B rewrites the library's shared pre-pass scratch; it
+    must be ordered behind the open work (Device::leave_open / order_after_open), or the first dictionary is silently
+    corrupt.  A large collection on stream A (milliseconds of dictionary work), at once a block compare of a different
+    collection on stream B, then the first collection's matrix: equal to the one computed with nothing in between."""
+    import torch
+    from sourmash_rust_amd import synth
+    num, n = 2000, 6000
+    sigs = synth.family_signatures(0, n, num=num, seed=41)
+    other = synth.family_signatures(0, 900, num=num, n_families=1, seed=43)
+    t = torch.from_numpy(sigs.view(np.int64)).cuda()
+    to = torch.from_numpy(other.view(np.int64)).cuda()
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(num)
+    offo = np.arange(901, dtype=np.uint64) * np.uint64(num)
+    rows = (2950, 3050)
+    quiet = pkg.matrix.Collection(t, off)
+    quiet.finish(None)
+    want = quiet.compare(rows[0], rows[1], num, want=("jaccard", "common"))
+    ref_other = pkg.matrix.compare_block_dev(to, offo, to, offo, num, want=("jaccard",))["jaccard"].clone()
+    quiet.close()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        coll = pkg.matrix.Collection(t, off, stream=sa.cuda_stream)       # returns at once: work open on stream A
+        coll.finish(None)
+        got_other = pkg.matrix.compare_block_dev(to, offo, to, offo, num, want=("jaccard",), stream=sb.cuda_stream)["jaccard"]
+        got = coll.compare(rows[0], rows[1], num, want=("jaccard", "common"))
+        assert bool((got["jaccard"] == want["jaccard"]).all()) and bool((got["common"] == want["common"]).all())
+        assert bool((got_other == ref_other).all())
+        coll.close()
+
+
+def test_export_dev_says_so_when_the_buffer_is_too_small(pkg):
+    import torch
+    from sourmash_rust_amd.errors import SourmashError
+    mh = pkg.KmerMinHash(0, 21, False, 42, (1 << 64) // 20, True)
+    mh.add_many(np.arange(1, 5000, dtype=np.uint64) * np.uint64(1 << 40))
+    n = mh.export_dev()
+    assert n == len(mh) > 100
+    small = torch.full((n - 1,), -1, dtype=torch.int64, device="cuda")
+    with pytest.raises(SourmashError) as e:
+        mh.export_dev(small, None)
+    assert e.value.code == 2 and "capacity" in e.value.message and bool((small == -1).all())
+    m = torch.empty(n, dtype=torch.int64, device="cuda")
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    assert mh.export_dev(m, a) == n and (m.cpu().numpy().view(np.uint64) == mh.mins_np()).all()
+    num_sketch = pkg.KmerMinHash(10, 21)
+    with pytest.raises(SourmashError):
+        num_sketch.export_dev()
+
+
+def test_resident_index_dictionary_can_be_dropped(pkg, coracle):
+    from sourmash_rust_amd import synth
+    sigs = synth.family_signatures(0, 200, num=300, n_families=3, pool=600, private=150, seed=3)
+    nodes = []
+    for i in range(200):
+        g = pkg.KmerMinHash(300, 31)
+        g.add_many(sigs[i])
+        nodes.append(g)
+    idx = pkg.index.ResidentIndex(nodes)
+    a = idx.compare(idx, want=("jaccard",))["jaccard"].copy()
+    idx.drop_dictionary()
+    b = idx.compare(idx, want=("jaccard",))["jaccard"].copy()       # rebuilt
+    assert pkg.lib().smh_release_workspace() == 0                    # drops it again, with the workspace
+    c = idx.compare(idx, want=("jaccard",))["jaccard"]
+    assert (a == b).all() and (a == c).all()
+    rows = [sigs[i] for i in range(200)]
+    _, _, jac = coracle.compare_matrix(rows[:20], rows, 300, 31, 0)
+    assert (a[:20] == jac).all()

@@ -20,6 +20,8 @@ if mode == "components":
     tune = dict(route="components")
 if os.environ.get("PROF_FORCE_TILED"):
     tune = dict(tune, route="tiled")
+if os.environ.get("PROF_DICT"):
+    tune = dict(tune, dictionary=os.environ["PROF_DICT"])
 if os.environ.get("PROF_COMP_LIMIT"):
     tune = dict(tune, comp_pairs_limit=int(os.environ["PROF_COMP_LIMIT"]))
 import ctypes as C
@@ -34,10 +36,10 @@ with pkg.matrix.tuning(**tune):
         torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
 L.smh_profile_enable(0)
 kern = {}
-for name in ("compare_tiled", "compare_comp", "compare_fill"):
+for name in ("compare_tiled", "compare_comp", "compare_fill", "dictionary_rebuilt"):
     ms, k = C.c_double(), C.c_uint64()
     L.smh_profile_get(name.encode(), C.byref(ms), C.byref(k))
     if k.value:
-        kern[name] = round(ms.value / k.value, 4)
+        kern[name] = round(ms.value / k.value, 4) if name != "dictionary_rebuilt" else k.value
 dt = sorted(times[2:] or times)[len(times[2:] or times) // 2]
 print("n=%d %s: median %.3f ms per matrix (min %.3f; %.1f M pairs/s) kernels ms %s %s" % (n, mode, dt * 1e3, min(times) * 1e3, n * n / dt / 1e6, kern, pkg.matrix.last_stats()))
