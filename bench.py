@@ -321,7 +321,7 @@ def main():
     # (profiles/), NOT from this run: HBM bytes per launch (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and
     # VALU wave-instructions per 64 k-mers (SQ_INSTS_VALU / wave steps).
     traffic, traffic_src, valu, half_share = None, None, None, None
-    for name in ("r03_pmc_dna_rolling.json", "r02_pmc_dna_rolling.json", "r01_pmc_dna_rolling.json"):
+    for name in ("r04_pmc_dna_rolling.json", "r03_pmc_dna_rolling.json", "r02_pmc_dna_rolling.json", "r01_pmc_dna_rolling.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

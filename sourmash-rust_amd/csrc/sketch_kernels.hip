@@ -313,9 +313,17 @@ __device__ __forceinline__ void murmur_kmer_pre(const W2 (&M)[2 * L], int K, uin
 // per base.  One unsigned compare tells (g_span), and only groups that are not clean -- the first
 // one of a run, the ones around a record boundary or a non-ACGT byte, the last one -- take the
 // per-base path below, which produces a 4-bit mask of the windows that may be emitted.
-template <int KT, int THREADS, int HB, int L, bool PR = false>
-__global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
-                                                         int logR, uint32_t stage_cap) {
+//
+// PK: the tile is staged PACKED -- two bits per base (the 2-bit code the rolling needs anyway: the upper-casing, the
+// encoding and the validity check are done once, by the lane that stages the bytes, 16 at a time) plus one "dirty" bit per
+// source dword that holds a byte other than ACGT.  A lane's run of 128 bases is 32 bytes of LDS instead of 128: a 512-lane
+// workgroup needs ~28 KB instead of ~73 KB, so FOUR workgroups share a CU (8 waves per SIMD instead of 4: the kernel waits
+// on its own dependent murmur chains in a third of its wave cycles), and the hot path reads one LDS dword per
+// 16 bases and decodes nothing.  Dirty dwords end the lane's window of clean groups like a record boundary does; the group
+// then re-reads its four bytes from global memory (rare) and takes the per-base path with the same conditions as ever.
+template <int KT, int THREADS, int HB, int L, bool PR = false, bool PK = false, int MINW = (PK ? 8 : 4)>
+__global__ __launch_bounds__(THREADS, MINW) void k_dna_rolling(SeqBatch b, HashParams hp, CandSink sink,
+                                                                     int logR, uint32_t stage_cap) {
   // LDS: static: the product tables (6.8 KiB; a compile-time address, so a table read is one
   // ds_read with the table's base as its immediate offset); dynamic: [staged candidates: count,
   // hashes, positions][sequence tile]
@@ -392,15 +400,40 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     const uintptr_t g0 = (uintptr_t)(b.seq + T0);
     const uintptr_t ga = g0 & ~(uintptr_t)15;
     const uint32_t m = (uint32_t)(g0 - ga);
-    const uint32_t nchunks = (m + (uint32_t)TILE + 16 * L + 8 + 15) >> 4;  // last lane reads < m+TILE+K+7
+    const uint32_t nchunks = (m + (uint32_t)TILE + 16 * L + 8 + 15 + (PK ? 32u : 0u)) >> 4;  // last lane reads < m+TILE+K+7 (PK: a dword ahead)
+    const uint32_t nchunks_cap = (15u + (uint32_t)TILE + 16 * L + 8 + 15 + 32u) >> 4;     // (the same for the largest m: where the dirty bits start)
     __syncthreads();  // tables ready / previous tile fully consumed
+    uint32_t* dirty = tile + (nchunks_cap + (nchunks_cap >> (logR - 4)) + 2);     // PK: one bit per source dword, behind the codes
+    if (PK) {
+      for (uint32_t c = tid; c < (nchunks >> 3) + 3; c += THREADS) dirty[c] = 0;
+      if (tid == 0) st_ctl[1] = 0;                                   // "some dword of this tile is dirty"
+      __syncthreads();
+    }
     for (uint32_t c = tid; c < nchunks; c += THREADS) {
       uintptr_t addr = ga + ((uintptr_t)c << 4);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (addr < gend) v = *reinterpret_cast<const uint4*>(addr);
-      uint32_t x = c << 4;
-      uint32_t o = (x >> 2) + (x >> logR);
-      tile[o] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+      if (PK) {
+        // 16 bases -> 32 bits of codes (base j of the chunk in bits 2j, 2j+1) + 4 dirty bits
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        uint32_t codes = 0, bad = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t u4 = w4[q] & 0xDFDFDFDFu;
+          const uint32_t c2 = (u4 >> 1) & 0x03030303u;
+          const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
+          const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
+          bad |= (u4 != exp4) ? (1u << q) : 0u;
+          const uint32_t pk = code4 | (code4 >> 6);                   // bytes 0,1 -> bits 0..3; bytes 2,3 -> bits 16..19
+          codes |= ((pk & 0xfu) | ((pk >> 12) & 0xf0u)) << (8 * q);
+        }
+        tile[c + (c >> (logR - 4))] = codes;                         // one pad dword per run: lane-strided reads hit distinct banks
+        if (bad) { atomicOr(&dirty[c >> 3], bad << (4u * (c & 7u))); st_ctl[1] = 1; }
+      } else {
+        uint32_t x = c << 4;
+        uint32_t o = (x >> 2) + (x >> logR);
+        tile[o] = v.x; tile[o + 1] = v.y; tile[o + 2] = v.z; tile[o + 3] = v.w;
+      }
     }
     __syncthreads();
 
@@ -422,8 +455,25 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     uint32_t vstart = 0;      // first base of the run of valid bases that reaches the current base
     // clean groups: g_lo <= i0 < g_lo + g_span  (see the kernel comment)
     uint32_t g_lo = 0, g_span = 0;
-    auto set_clean_window = [&](bool warm) {
-      const uint32_t lim2 = warm ? lim : (lim < hi_ok ? lim : hi_ok);
+    // PK: bit g = group g of my run touches a source dword that holds a byte other than ACGT (dirty bits of the tile,
+    // one per aligned dword of the input; a group whose bases straddle two dwords looks at both)
+    uint64_t dmask = 0;
+    if (PK && st_ctl[1]) {
+      const uint32_t b0 = (m + ((uint32_t)tid << logR)) >> 2;
+      const uint32_t* dw = reinterpret_cast<const uint32_t*>(tile) + (nchunks_cap + (nchunks_cap >> (logR - 4)) + 2);
+      const uint32_t i = b0 >> 5, sft = b0 & 31u;
+      const uint64_t lo64 = ((uint64_t)dw[i + 1] << 32) | dw[i];
+      const uint32_t d2 = dw[i + 2];
+      dmask = (lo64 >> sft) | (sft ? ((uint64_t)d2 << (64 - sft)) : 0ull);
+      if (m & 3u) dmask |= (dmask >> 1) | ((uint64_t)((d2 >> sft) & 1u) << 63);
+    }
+    auto set_clean_window = [&](bool warm, uint32_t from_i) {
+      uint32_t lim2 = warm ? lim : (lim < hi_ok ? lim : hi_ok);
+      if (PK) {
+        const uint32_t g = from_i >> 2;
+        const uint64_t rem = g < 64 ? (dmask >> g) : 0ull;
+        if (rem) lim2 = min(lim2, (g + (uint32_t)__builtin_ctzll(rem)) * 4u);      // clean groups end before the next dirty one
+      }
       g_lo = warm ? vstart : vstart + (uint32_t)K - 1;   // warm-up groups emit nothing: only validity matters
       g_span = lim2 >= g_lo + 4 ? lim2 - 3 - g_lo : 0u;
     };
@@ -435,7 +485,12 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     uint32_t ta = xu + ((uint32_t)tid << logR);
     ta = ta + ((ta >> logR) << 2);                                   // byte offset in the padded tile
     const uint32_t sh = m & 3u;
-    uint32_t cur = tile[ta >> 2];
+    uint32_t cur = PK ? 0u : tile[ta >> 2];
+    // PK: the codes of my run: chunk (16 bases, one dword) cq holds my base 16 * (cq - cq0) - (m & 15); w = the 16 bases of
+    // the current quad of groups, aligned (base j of the quad in bits 2j), wc = their complements; both move down 8 bits per group
+    uint32_t cq = (m >> 4) + ((uint32_t)tid << (logR - 4));
+    const uint32_t sh2 = (m & 15u) * 2u;
+    uint32_t pcur = PK ? tile[cq + (cq >> (logR - 4))] : 0u, w = 0, wc = 0;
     // two rolled windows of 2-bit digits in L limbs.  fle: the forward k-mer, first base least
     // significant.  cf: the COMPLEMENT of the forward k-mer, first base most significant -- which is
     // the reverse complement with ITS first base least significant.  Both candidates for the hashed
@@ -450,22 +505,46 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
     // one group of four bases; hashing = false for the warm-up groups
     auto group = [&](uint32_t i0, auto hashing) {
       constexpr bool kHash = decltype(hashing)::value;
-      const uint32_t xn = xu + i0 + 4;                               // uniform: byte index of the next dword
-      ta += (xn & (R - 1)) == 0 ? 8u : 4u;
-      const uint32_t nxt = tile[ta >> 2];
-      const uint32_t d = __builtin_amdgcn_alignbyte(nxt, cur, sh);
-      cur = nxt;
-      // four bases at once: upper-case, 2-bit code (A0 C1 G2 T3), validity by re-encoding
-      const uint32_t u4 = d & 0xDFDFDFDFu;
-      const uint32_t c2 = (u4 >> 1) & 0x03030303u;
-      const uint32_t code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
-      const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
-      const uint32_t diff4 = u4 ^ exp4;
-      const uint32_t ccode4 = code4 ^ 0x03030303u;                   // complement digits
+      uint32_t code4 = 0, ccode4 = 0, diff4 = 0;
+      if (PK) {
+        if ((i0 & 12u) == 0) {                                       // uniform: a new dword of codes every 16 bases
+          cq += 1;
+          const uint32_t pnxt = tile[cq + (cq >> (logR - 4))];
+          w = __builtin_amdgcn_alignbit(pnxt, pcur, sh2);
+          pcur = pnxt;
+          wc = ~w;
+        }
+      } else {
+        const uint32_t xn = xu + i0 + 4;                             // uniform: byte index of the next dword
+        ta += (xn & (R - 1)) == 0 ? 8u : 4u;
+        const uint32_t nxt = tile[ta >> 2];
+        const uint32_t d = __builtin_amdgcn_alignbyte(nxt, cur, sh);
+        cur = nxt;
+        // four bases at once: upper-case, 2-bit code (A0 C1 G2 T3), validity by re-encoding
+        const uint32_t u4 = d & 0xDFDFDFDFu;
+        const uint32_t c2 = (u4 >> 1) & 0x03030303u;
+        code4 = c2 ^ ((c2 >> 1) & 0x01010101u);
+        const uint32_t exp4 = __builtin_amdgcn_perm(0u, 0x54474341u, code4);
+        diff4 = u4 ^ exp4;
+        ccode4 = code4 ^ 0x03030303u;                                // complement digits
+      }
       uint32_t okmask = 0xFu;                                        // windows ending at base q that may be emitted
       uint64_t tq[4];                                                // PR only: the threshold in force at each base
       if (PR) { tq[0] = lthr; tq[1] = lthr; tq[2] = lthr; tq[3] = lthr; }
-      if (!(diff4 == 0 && i0 - g_lo < g_span)) {
+      if (!((PK || diff4 == 0) && i0 - g_lo < g_span)) {
+        if (PK && i0 < 256u && ((dmask >> (i0 >> 2)) & 1ull)) {
+          // a dirty group: its four bytes again, from global memory, for the per-base validity below
+          uint32_t d = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const uint64_t at = p0 + i0 + (uint32_t)q;
+            if (at < b.len) d |= (uint32_t)b.seq[at] << (8 * q);
+          }
+          const uint32_t u4 = d & 0xDFDFDFDFu;
+          const uint32_t c2 = (u4 >> 1) & 0x03030303u;
+          const uint32_t cd = c2 ^ ((c2 >> 1) & 0x01010101u);
+          diff4 = u4 ^ __builtin_amdgcn_perm(0u, 0x54474341u, cd);
+        }
         // ---- not clean (rare): base by base, exactly the reference's conditions
         okmask = 0;
 #pragma unroll
@@ -490,7 +569,7 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
             if (PR) tq[q] = lthr;
           }
         }
-        set_clean_window(!kHash);
+        set_clean_window(!kHash, i0 + 4);
       }
 #pragma unroll
       for (int g0b = 0; g0b < 4; g0b += HB) {
@@ -498,8 +577,8 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
 #pragma unroll
         for (int q = 0; q < HB; q++) {
           const int bb = g0b + q;
-          const uint32_t code = (code4 >> (8 * bb)) & 3u;
-          const uint32_t ccode = (ccode4 >> (8 * bb)) & 3u;
+          const uint32_t code = PK ? (w >> (2 * bb)) & 3u : (code4 >> (8 * bb)) & 3u;
+          const uint32_t ccode = PK ? (wc >> (2 * bb)) & 3u : (ccode4 >> (8 * bb)) & 3u;
           // cf = ((cf << 2) | (3 - code)) & MASK ; fle = (fle >> 2) | code << (2K-2)   (limb-wise)
 #pragma unroll
           for (int li = L - 1; li > 0; li--) cf[li] = __builtin_amdgcn_alignbit(cf[li], cf[li - 1], 30) & MASK[li];
@@ -572,12 +651,13 @@ __global__ __launch_bounds__(THREADS) void k_dna_rolling(SeqBatch b, HashParams 
             }
         }
       }
+      if (PK) { w >>= 8; wc >>= 8; }
     };
 
-    set_clean_window(true);
+    set_clean_window(true, 0);
     uint32_t i0 = 0;
     for (; i0 < warm_end; i0 += 4) group(i0, std::false_type{});
-    set_clean_window(false);
+    set_clean_window(false, i0);
     for (; i0 < nsteps; i0 += 4) group(i0, std::true_type{});
     }  // p0 < range_hi
 
@@ -1458,15 +1538,18 @@ inline int grid_for(uint64_t items, int per_block, int cap) {
 
 // launch geometry of the rolling kernel: 512 lanes, runs of 128 positions, two hashes per block.
 // Other geometries exist only in experiment builds (-DSMH_EXPERIMENTS, SOURMASH_AMD_DNA_CFG="threads,logR,hb").
-struct DnaCfg { int threads, logR, hb; };
+struct DnaCfg { int threads, logR, hb; bool packed = true; };
 static DnaCfg dna_cfg() {
   static DnaCfg cfg = [] {
     DnaCfg c{512, 7, 2};
 #ifdef SMH_EXPERIMENTS
+    if (const char* e = std::getenv("SOURMASH_AMD_DNA_PK")) c.packed = std::atoi(e) != 0;     // 0: the byte tile (A/B)
+#endif
+#ifdef SMH_EXPERIMENTS
     if (const char* e = std::getenv("SOURMASH_AMD_DNA_CFG")) {
       int t = 0, r = 0, h = 0;
       if (sscanf(e, "%d,%d,%d", &t, &r, &h) == 3 && (t == 256 || t == 512) && r >= 5 && r <= 7 &&
-          (h == 1 || h == 2 || h == 4)) c = DnaCfg{t, r, h};
+          (h == 1 || h == 2 || h == 4)) c = DnaCfg{t, r, h, false};
     }
 #endif
     return c;
@@ -1479,14 +1562,28 @@ static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSin
                            int logR, uint32_t stage_cap, const DnaCfg& c, hipStream_t s) {
 #define SMH_LAUNCH(T, H) hipLaunchKernelGGL((k_dna_rolling<KT, T, H, L>), dim3(grid), dim3(T), lds, s, b, p, sink, logR, stage_cap)
   if (p.thr_rec) {   // per-record thresholds: default geometry only
-    hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
+    if (c.packed) hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, true, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
+    else hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
+    return;
+  }
+  if (c.packed) {    // the product geometry: 512 lanes, two hashes per block, the tile packed to two bits per base
+#ifdef SMH_EXPERIMENTS
+    if (const char* e = std::getenv("SOURMASH_AMD_DNA_PKV")) {     // "minw,hb" of the packed kernel (A/B)
+      int mw = 0, hb = 0;
+      if (sscanf(e, "%d,%d", &mw, &hb) == 2) {
+#define SMH_PKV(M_, H_) if (mw == M_ && hb == H_) { hipLaunchKernelGGL((k_dna_rolling<KT, 512, H_, L, false, true, M_>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap); return; }
+        SMH_PKV(8, 1) SMH_PKV(6, 1) SMH_PKV(6, 2) SMH_PKV(5, 2) SMH_PKV(4, 2) SMH_PKV(8, 4) SMH_PKV(6, 4)
+#undef SMH_PKV
+      }
+    }
+#endif
+    hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, false, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
     return;
   }
 #ifdef SMH_EXPERIMENTS
   if (c.threads == 512) { if (c.hb == 4) SMH_LAUNCH(512, 4); else if (c.hb == 2) SMH_LAUNCH(512, 2); else SMH_LAUNCH(512, 1); }
   else { if (c.hb == 4) SMH_LAUNCH(256, 4); else if (c.hb == 2) SMH_LAUNCH(256, 2); else SMH_LAUNCH(256, 1); }
 #else
-  (void)c;
   SMH_LAUNCH(512, 2);
 #endif
 #undef SMH_LAUNCH
@@ -1511,7 +1608,8 @@ void launch_dna_hash(const SeqBatch& b_in, const HashParams& p, const CandSink& 
   if (p.ksize >= 1 && p.ksize <= 128 && !force_generic) {
     // run length per lane: long runs amortise the k-1 warm-up bases; short inputs use short
     // runs so that the launch still covers the chip
-    const DnaCfg c = p.thr_rec ? DnaCfg{512, 7, 2} : dna_cfg();   // the per-record variant exists in one geometry
+    DnaCfg c = dna_cfg();
+    if (p.thr_rec) { c.threads = 512; c.logR = 7; c.hb = 2; }     // the per-record variant exists in one geometry
     int logR = c.logR;
     while (logR > 5 && (span >> logR) < (uint64_t)dev.cu_count() * c.threads * 2) logR--;
     const uint64_t tile = (uint64_t)c.threads << logR;
@@ -1527,8 +1625,14 @@ void launch_dna_hash(const SeqBatch& b_in, const HashParams& p, const CandSink& 
     long double expect = (long double)tile * (((long double)thr + 1.0L) / 18446744073709551616.0L);
     uint32_t stage_cap = expect * 2.0L + 64.0L > 2048.0L ? 2048u : (uint32_t)(expect * 2.0L + 64.0L);
     if (stage_cap < 128) stage_cap = 128;
-    const size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes +   // dynamic part; the tables are static LDS
-                       4 * ((x_bytes >> logR) + 2);
+    size_t lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + x_bytes +   // dynamic part; the tables are static LDS
+                 4 * ((x_bytes >> logR) + 2);
+    if (c.packed) {
+      // two bits per base + a pad dword per run + a dirty bit per source dword (the kernel's nchunks_cap)
+      const uint32_t ncap = (15u + (uint32_t)tile + 16u * (uint32_t)limbs + 8u + 15u + 32u) >> 4;
+      lds = 16 + (size_t)stage_cap * 8 * (sink.pos ? 2 : 1) + 4 * (size_t)(ncap + (ncap >> (logR - 4)) + 2) + 4 * (size_t)((ncap >> 3) + 8);
+    }
+    // 8 workgroups per CU may be resident with the packed tile: keep a few tiles per workgroup
     if (p.ksize == 31) launch_rolling<31, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     else if (p.ksize == 21) launch_rolling<21, 2>(b, p, sink, grid, lds, logR, stage_cap, c, s);
     else if (p.ksize == 51) launch_rolling<51, 4>(b, p, sink, grid, lds, logR, stage_cap, c, s);
