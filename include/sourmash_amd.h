@@ -214,6 +214,9 @@ typedef struct SmhCompareTuning {
   uint32_t dictionary;        /* how the pooled hashes of the collection dictionary are sorted: 0 = default (four radix passes over the
                                  32 most significant bits that vary, then the few keys that tie there are put in order), 1 = all
                                  eight byte passes (what the default falls back to; A/B and parity tests: same matrix either way) */
+  uint32_t no_range_masks;    /* 1 = the tiled kernel walks every pair from the first range of rank space on; default 0: per-range
+                                 bit masks of the shared hashes tell it where a pair's union reaches its cut, and it walks only
+                                 from there (same matrix either way) */
 } SmhCompareTuning;
 void smh_compare_get_tuning(SmhCompareTuning *out);
 int smh_compare_set_tuning(const SmhCompareTuning *tuning);   /* NULL restores the defaults; process-wide */

@@ -19,7 +19,8 @@ class SourmashStr(C.Structure):
 
 class SmhCompareTuning(C.Structure):
     _fields_ = [("route", C.c_uint32), ("visit_all_tiles", C.c_uint32), ("use_symmetry", C.c_uint32),
-                ("comp_pairs_limit", C.c_uint64), ("split_frequent", C.c_uint32), ("dictionary", C.c_uint32)]
+                ("comp_pairs_limit", C.c_uint64), ("split_frequent", C.c_uint32), ("dictionary", C.c_uint32),
+                ("no_range_masks", C.c_uint32)]
 
 
 class SmhCompareStats(C.Structure):

@@ -417,6 +417,14 @@ struct RangeState {
 };
 constexpr uint32_t kMaxFreq = 64;
 
+// what k_mask_layout decided about the range masks of a collection (see "range masks" further down)
+struct MaskInfo {
+  uint32_t ok;          // the masks exist (few enough words)
+  uint32_t wtot;        // words per sketch
+  uint32_t shared;      // shared hashes in all
+  uint32_t pad;
+};
+
 struct TiledArgs {
   const uint32_t* rrank; const uint64_t* roff; const uint32_t* rpart; uint32_t nrows;
   const uint32_t* crank; const uint64_t* coff; const uint32_t* cpart; uint32_t ncols;
@@ -432,6 +440,9 @@ struct TiledArgs {
   uint32_t capA, capBt;  // LDS dwords for the row pool / the transposed column tile
   unsigned long long* ovf_steps;   // = &st->ovf_steps
   CompareOut out;
+  // range masks (nullptr: none -- the walk starts at the first range): see "range masks" further down.  Word-major /
+  // range-major tables over ALL nsk sketches of the collection; a row or column of the block is sketch scope.*_base + index
+  const unsigned long long* masks; const uint32_t* partT; const uint32_t* woff; const uint32_t* wn; const MaskInfo* minfo; uint32_t nsk;
 };
 
 // One row against the 64 staged columns (lane = column) over one staged stretch of rank space: A = the row's la ranks +
@@ -508,6 +519,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {      // the minimum, in every lane's return value
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x111, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x112, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x114, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x118, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // the maximum, in every lane's return value
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
@@ -902,10 +922,108 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     if (WantCC) cc[q] = 0;
   }
 
+  // ---- range masks: where every pair's union reaches its cut, without walking (see "range masks" further down).
+  // Pass 1, range by range: matches so far = popcounts of the ANDed words; union so far = the two sketches' crossings of the
+  // range's upper boundary minus the matches; the first range in which that reaches the row's cut is the pair's.  The tile
+  // starts walking at the earliest such range of its pairs (pass 2: the matches before it, for the walk's counters); pairs
+  // that never reach a cut are final as they are.
+  const bool use_masks = ka.masks != nullptr && ka.minfo->ok != 0;      // (uniform)
+  uint32_t first_r = 0;                 // the first range the tile walks (R: none)
+  uint32_t mtot[kRowsPerWave];          // matches over all ranges
+  uint32_t nocut = 0;                   // bit q: the pair (my q-th row, my column) needs no walk
+  if (use_masks) {
+    const uint32_t nsk = ka.nsk;
+    const uint32_t gcol = col_ok ? ka.scope.col_base + col : 0u;
+    uint32_t grow[kRowsPerWave], nq[kRowsPerWave], rstar[kRowsPerWave];
+    uint32_t self = 0;                  // bit q: the pair is a sketch with ITSELF -- everything matches, also what nobody else holds
+    uint32_t samec[kRowsPerWave];       // all ones: row and column are of one component (bits are handed out per component: a pair
+                                        // across components can only share FREQUENT hashes, which have words of their own)
+    const uint32_t ccomp = (bj * kTB + (uint32_t)lane) < ka.ncols ? (uint32_t)(ka.ckey[bj * kTB + lane] >> 32) : kNone;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+      const uint32_t row = rowid[w * kRowsPerWave + q];
+      grow[q] = row != kNone ? ka.scope.row_base + row : 0u;
+      nq[q] = (row != kNone && col_ok) ? nrowL[w * kRowsPerWave + q] : kNone;     // (no pair: never cut)
+      mtot[q] = 0; rstar[q] = R;
+      if (row != kNone && col_ok && grow[q] == gcol) self |= 1u << q;
+      const uint32_t rs = bi * kTR + (uint32_t)(w * kRowsPerWave + q);
+      samec[q] = (rs < ka.nrows && (uint32_t)(ka.rkey[rs] >> 32) == ccomp) ? 0xffffffffu : 0u;
+    }
+    const unsigned long long* mk = ka.masks;
+    const uint32_t* pT = ka.partT;
+    for (uint32_t r = 0; r < R; r++) {
+      const uint32_t w0 = ka.woff[r], w1 = ka.woff[r + 1], wf = w0 + ka.wn[r];
+      for (uint32_t wi = w0; wi < wf; wi++) {
+        const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb) & samec[q];
+      }
+      for (uint32_t wi = wf; wi < w1; wi++) {          // (the range's frequent hashes, if it has any)
+        const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb);
+      }
+      const uint32_t pb = pT[(size_t)(r + 1) * nsk + gcol];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const uint32_t pa = pT[(size_t)(r + 1) * nsk + grow[q]];
+        const uint32_t u = pa + pb - (((self >> q) & 1u) ? pa : mtot[q]);
+        if (rstar[q] == R && u >= nq[q]) rstar[q] = r;
+      }
+      // (count_common not wanted: a wave whose pairs have all found their range needs no more of the totals)
+      if (!WantCC && (r & 7u) == 7u) {
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) all = all && rstar[q] != R;
+        if (__all(all)) break;
+      }
+    }
+    uint32_t mn = R;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+      if (rstar[q] == R) nocut |= 1u << q; else mn = min(mn, rstar[q]);
+      if ((self >> q) & 1u) mtot[q] = pT[(size_t)R * nsk + grow[q]];
+    }
+    mn = wave_min_u32(mn);
+    if (tid == 0) ctl[6] = R;
+    __syncthreads();
+    if (lane == 0) atomicMin(&ctl[6], mn);
+    __syncthreads();
+    first_r = ctl[6];
+    if (first_r < R) {
+      // pass 2: matches in the ranges before the walk's first one -> the walk's counters there
+      uint32_t before[kRowsPerWave];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) before[q] = 0;
+      for (uint32_t r = 0; r < first_r; r++) {
+        const uint32_t w0 = ka.woff[r], w1 = ka.woff[r + 1], wf = w0 + ka.wn[r];
+        for (uint32_t wi = w0; wi < wf; wi++) {
+          const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
+#pragma unroll
+          for (int q = 0; q < kRowsPerWave; q++) before[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb) & samec[q];
+        }
+        for (uint32_t wi = wf; wi < w1; wi++) {
+          const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
+#pragma unroll
+          for (int q = 0; q < kRowsPerWave; q++) before[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb);
+        }
+      }
+      const uint32_t pb = pT[(size_t)first_r * nsk + gcol];
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const uint32_t pa = pT[(size_t)first_r * nsk + grow[q]];
+        if ((self >> q) & 1u) before[q] = pa;
+        common[q] = before[q];
+        ucount[q] = pa + pb - before[q];
+      }
+    }
+  }
+
   // ---- stretches 0 and 1 with plain loads; the ranks of stretch 0 and the crossings at the end of stretch 2 requested
   // (s0, s1, s2: table slots of the stretch being walked, the next, the one after; stage slot = stretch number & 1)
+  if (first_r < R) {        // (with masks: nothing to walk when no pair of the tile reaches a cut)
   uint32_t cool = 0, it = 0;
-  uint32_t r0 = 0, mt0 = next_span(1, cool, 0);
+  uint32_t r0 = first_r, mt0 = next_span(1, cool, first_r);
   bool ovf0 = settle_table(0, 0, r0, mt0, true, cool);
   if (!ovf0) issue_stage(0, 0);
   uint32_t r1 = r0 + mt0, mt1 = 0;
@@ -956,7 +1074,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; q++) {
         const int t = w * kRowsPerWave + q;
-        tiled_walk_row<WantCC>(pA + T[64 + t], pB + lane, T[t], lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
+        // (with masks count_common is their total: the walk only has to reach the cuts)
+        if (WantCC && use_masks) tiled_walk_row<false>(pA + T[64 + t], pB + lane, T[t], lb, nrowL[t], ucount[q], common[q], cc[0]);
+        else tiled_walk_row<WantCC>(pA + T[64 + t], pB + lane, T[t], lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
       }
     } else {
       // ---- rare: one range that does not fit LDS for this tile; merge from global memory
@@ -967,13 +1087,14 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       for (int q = 0; q < kRowsPerWave; q++) {
         const int t = w * kRowsPerWave + q;
         const uint32_t la = T[t];
-        tiled_merge_global_row<WantCC>(a.rrank + goff[t] + (T[128 + t] - la), la, B, lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
+        if (WantCC && use_masks) tiled_merge_global_row<false>(a.rrank + goff[t] + (T[128 + t] - la), la, B, lb, nrowL[t], ucount[q], common[q], cc[0]);
+        else tiled_merge_global_row<WantCC>(a.rrank + goff[t] + (T[128 + t] - la), la, B, lb, nrowL[t], ucount[q], common[q], cc[WantCC ? q : 0]);
       }
     }
     // ---- all pairs of the tile past their cut: the remaining ranges cannot change common or size
-    bool done = !WantCC;
+    bool done = !WantCC || use_masks;
 #pragma unroll
-    for (int q = 0; q < kRowsPerWave; q++) done = done && (ucount[q] >= nrowL[w * kRowsPerWave + q]);
+    for (int q = 0; q < kRowsPerWave; q++) done = done && (ucount[q] >= nrowL[w * kRowsPerWave + q] || ((nocut >> q) & 1u));
     // the vote with ONE barrier (__syncthreads_and takes three): a wave with a pair still short of its cut raises the flag of
     // this stretch; the flag of the stretch after the next is cleared now (the last readers of that slot -- the stretch
     // before the previous one -- have all passed a barrier since)
@@ -998,16 +1119,24 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     r1 = r2; mt1 = mt2; ovf1 = ovf2;
     const uint32_t sx = s0; s0 = s1; s1 = s2; s2 = sx;
   }
+  if (tid == 0 && n_halved) {
+    atomicAdd(&ka.st->halvings, n_halved);
+    if (pf_after) atomicAdd(&ka.st->pf_after_halving, 1u);
+  }
+  }   // first_r < R
 
 #pragma unroll
   for (int q = 0; q < kRowsPerWave; q++) {
     const uint32_t row = rowid[w * kRowsPerWave + q];
-    if (row != kNone && col_ok)
-      tiled_write_pair<WantCC>(ka, row, col, nrowL[w * kRowsPerWave + q], ucount[q], common[q], WantCC ? cc[q] : 0u);
-  }
-  if (tid == 0 && n_halved) {
-    atomicAdd(&ka.st->halvings, n_halved);
-    if (pf_after) atomicAdd(&ka.st->pf_after_halving, 1u);
+    if (row != kNone && col_ok) {
+      uint32_t uc = ucount[q], cm = common[q];
+      if (use_masks && ((nocut >> q) & 1u)) {
+        // never walked (or walked along for nothing): the union is everything, the matches are the masks' total
+        cm = mtot[q];
+        uc = (uint32_t)(ka.roff[row + 1] - ka.roff[row]) + (uint32_t)(ka.coff[col + 1] - ka.coff[col]) - cm;
+      }
+      tiled_write_pair<WantCC>(ka, row, col, nrowL[w * kRowsPerWave + q], uc, cm, WantCC ? (use_masks ? mtot[q] : cc[q]) : 0u);
+    }
   }
   }   // tiles of this workgroup
 }
@@ -1187,9 +1316,23 @@ __global__ __launch_bounds__(1024) void k_key_span(const uint64_t* __restrict__ 
   __shared__ unsigned long long red[2][16];
   const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
   unsigned long long mn = ~0ull, mx = 0ull;
-  for (uint32_t s = t; s < nsk; s += 1024) {       // a segment is sorted: its ends are its extremes
-    const uint32_t a = bk_seg(seg, s), b = bk_seg(seg, s + 1);
-    if (b > a) { mn = min(mn, (unsigned long long)keys[a]); mx = max(mx, (unsigned long long)keys[b - 1]); }
+  for (uint32_t s0 = 0; s0 < nsk; s0 += 8 * 1024) {      // a segment is sorted: its ends are its extremes
+    // (eight sketches per lane and turn, every load of a turn in flight before the first is used)
+    uint32_t a[8], b[8];
+    unsigned long long ka[8], kb[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t s = s0 + (uint32_t)j * 1024 + t;
+      a[j] = s < nsk ? bk_seg(seg, s) : 0u;
+      b[j] = s < nsk ? bk_seg(seg, s + 1) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      ka[j] = b[j] > a[j] ? keys[a[j]] : ~0ull;
+      kb[j] = b[j] > a[j] ? keys[b[j] - 1] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { mn = min(mn, ka[j]); mx = max(mx, kb[j]); }
   }
   for (int off = 32; off; off >>= 1) {
     mn = min(mn, (unsigned long long)__shfl_xor(mn, off));
@@ -1315,6 +1458,140 @@ __global__ __launch_bounds__(kBsThreads) void k_tie_sort(uint64_t* __restrict__ 
     for (uint32_t i = t; i < g; i += kBsThreads) { keys[a + i] = L.sk[i]; org[a + i] = L.si[i]; }
   }
 }
+
+
+// ---- range masks: how many hashes two sketches share in every range, without walking them --------------------------------
+// A hash held by ONE sketch of the collection can never be a match.  The hashes held by two or more (the runs of length >= 2
+// of the pooled sort) are numbered in hash order -- sid -- and every range r of the tiled kernel gets the ones that fall
+// into it as bit positions: sid - sb[r], in ceil(K_r / 64) 64-bit words.  mask[w][s] = which of them sketch s holds.  Then
+//     |A and B in range r|  =  popcount(mask[.][A] & mask[.][B])  over the range's words,
+// and with the sketches' crossings of the range boundaries (part) the size of the union up to any boundary follows without
+// touching a rank: U_r = part[A][r+1] + part[B][r+1] - matches up to r.  The tiled kernel uses that to find, for every pair
+// of a tile, the ONE range in which the union reaches the pair's cut (src/lib.rs:470-499: the walk ends after `num` union
+// elements) and starts its walk at the earliest such range of the tile, with the counts the masks give for everything
+// before -- a few stretches instead of all of them; pairs that never reach a cut (scaled sketches: num = 0) are not walked at
+// all, and count_common is the popcount over all ranges.  One family of related genomes has a few dozen shared hashes per
+// range: one word.  A component of many unrelated families would need many words per range for sparse masks: beyond
+// kMaskWordsMax words in all the masks are not built and the kernel walks as before.
+constexpr uint32_t kSidNone = 0xffffffffu;
+// Bits only have to be DISTINCT among the hashes two comparable sketches can share in a range, so they are handed out per
+// (component, range) by a counter: bit = how many shared hashes of that component and range came before (in any order).
+// Sketches of different components are never walked against each other and reuse the same bits: 50 families of 200 genomes
+// need the words of one family.  A frequent hash (set aside: it connects nothing, its holders sit in any component) gets
+// a bit of its range's "frequent" words, which every component's words are followed by.
+// rlo[k] = the first run of range k (k_hbounds's boundaries), rlo[R] = nruns
+__global__ __launch_bounds__(256) void k_range_runs(const uint32_t* __restrict__ starts, const RangeState* __restrict__ rs, uint32_t n,
+                                                    uint32_t R, uint32_t* __restrict__ rlo) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > R) return;
+  const uint32_t nruns = rs->nruns;
+  uint32_t v = 0;
+  if (k == R) v = nruns;
+  else if (k > 0 && nruns) {
+    const uint32_t pos = (uint32_t)(((uint64_t)k * n) / R);
+    uint32_t lo = 0, hi = nruns;  // last run with starts[run] <= pos
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (starts[mid] <= pos) lo = mid; else hi = mid;
+    }
+    v = lo;
+  }
+  rlo[k] = v;
+}
+// runbit[run] = the bit of a run held by two sketches or more (bit 31: one of the range's frequent bits), kSidNone for a
+// run of one.  cnt[root * R + range] / fcnt[range]: the counters.
+__global__ __launch_bounds__(256) void k_shared_bits(const uint32_t* __restrict__ starts, const RangeState* __restrict__ rs, uint32_t n,
+                                                     const uint32_t* __restrict__ origin, const uint32_t* __restrict__ node,
+                                                     const uint32_t* __restrict__ roots, const uint8_t* __restrict__ isfreq,
+                                                     const uint32_t* __restrict__ rlo, uint32_t R, uint32_t* __restrict__ cnt,
+                                                     uint32_t* __restrict__ fcnt, uint32_t* __restrict__ runbit) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nruns = rs->nruns;
+  if (r >= nruns) return;
+  const uint32_t a = starts[r], len = (r + 1 < nruns ? starts[r + 1] : n) - a;
+  if (len < 2) { runbit[r] = kSidNone; return; }
+  uint32_t lo = 0, hi = R;        // last range k with rlo[k] <= r
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (rlo[mid] <= r) lo = mid; else hi = mid;
+  }
+  if (isfreq && isfreq[r]) runbit[r] = atomicAdd(&fcnt[lo], 1u) | 0x80000000u;
+  else runbit[r] = atomicAdd(&cnt[(size_t)roots[node[origin[a]]] * R + lo], 1u);
+}
+// kmax[r] = the most shared hashes any component has in range r (few counters are not zero: one atomic each)
+__global__ __launch_bounds__(256) void k_mask_max(const uint32_t* __restrict__ cnt, uint64_t m, uint32_t R, uint32_t* __restrict__ kmax,
+                                                  uint32_t* __restrict__ total) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t v = cnt[i];
+  if (v) { atomicMax(&kmax[i % R], v); atomicAdd(total, v); }
+}
+// per range: the words its busiest component needs (wn), the frequent words behind them, the offsets; and whether the masks
+// are worth building.  One workgroup; lane per range for the maximum over the components' counters.
+__global__ __launch_bounds__(1024) void k_mask_layout(const uint32_t* __restrict__ kmax, const uint32_t* __restrict__ fcnt,
+                                                      const uint32_t* __restrict__ total, uint32_t R, uint32_t wmax,
+                                                      uint32_t* __restrict__ wn, uint32_t* __restrict__ woff, MaskInfo* __restrict__ info) {
+  __shared__ uint32_t wt[16], st[16];
+  const uint32_t per = (R + 1023) / 1024, r0 = min(threadIdx.x * per, R), r1 = min(r0 + per, R);
+  uint32_t mine = 0, shared = 0;
+  for (uint32_t r = r0; r < r1; r++) {
+    const uint32_t words = (kmax[r] + 63u) >> 6;
+    wn[r] = words;
+    mine += words + ((fcnt[r] + 63u) >> 6);
+    shared += fcnt[r];
+  }
+  const uint32_t incl = wave_incl_scan_add(mine);
+  uint32_t sh = shared;
+  for (int off = 32; off; off >>= 1) sh += __shfl_xor(sh, off);
+  if ((threadIdx.x & 63) == 63) wt[threadIdx.x >> 6] = incl;
+  if ((threadIdx.x & 63) == 0) st[threadIdx.x >> 6] = sh;
+  __syncthreads();
+  uint32_t run = incl - mine, tot = 0, stot = *total;
+  for (uint32_t ww = 0; ww < 16; ww++) { if (ww < (threadIdx.x >> 6)) run += wt[ww]; tot += wt[ww]; stot += st[ww]; }
+  for (uint32_t r = r0; r < r1; r++) { woff[r] = run; run += wn[r] + ((fcnt[r] + 63u) >> 6); }
+  if (threadIdx.x == 0) {
+    woff[R] = tot;
+    info->ok = (tot <= wmax && stot > 0) ? 1u : 0u; info->wtot = tot; info->shared = stot; info->pad = 0;
+  }
+}
+// mask[w][s] for the words of range r, and the crossings once more with the range first: partT[r][s] = part[s][r]
+// (the tiled kernel reads both with its 64 columns in consecutive lanes).  A lane per (sketch, range).
+__global__ __launch_bounds__(256) void k_build_masks(const uint32_t* __restrict__ part, const uint64_t* __restrict__ off,
+                                                     const uint32_t* __restrict__ rank, const uint32_t* __restrict__ runbit,
+                                                     const uint32_t* __restrict__ wn,
+                                                     const uint32_t* __restrict__ woff, const MaskInfo* __restrict__ info, uint32_t nsk,
+                                                     uint32_t R, unsigned long long* __restrict__ mask, uint32_t* __restrict__ partT,
+                                                     const uint32_t* __restrict__ skip, const uint32_t* __restrict__ built) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (uint64_t)nsk * (R + 1) || *skip || *built || !info->ok) return;
+  const uint32_t r = (uint32_t)(g / nsk), s = (uint32_t)(g % nsk);      // (sketch fastest: the stores of a wave are contiguous)
+  const uint32_t a = part[(size_t)s * (R + 1) + r];
+  partT[(size_t)r * nsk + s] = a;
+  if (r == R) return;
+  const uint32_t b = part[(size_t)s * (R + 1) + r + 1];
+  const uint32_t* e = rank + off[s];               // (an element's rank is the run of its hash)
+  const uint32_t w0 = woff[r], w1 = woff[r + 1], wf = w0 + wn[r];       // [w0, wf): the component's words; [wf, w1): the frequent ones
+  if (w1 - w0 == 1) {                              // (the usual case: one word, the elements' bits read once)
+    unsigned long long m = 0;
+    const uint32_t lo = w0 < wf ? 0u : 0x80000000u;
+    for (uint32_t i = a; i < b; i++) {
+      const uint32_t v = runbit[e[i]] - lo;        // (none, or a bit of the other kind: never below 64)
+      if (v < 64u) m |= 1ull << v;
+    }
+    mask[(size_t)w0 * nsk + s] = m;
+    return;
+  }
+  for (uint32_t w = w0; w < w1; w++) {
+    unsigned long long m = 0;
+    const uint32_t lo = w < wf ? ((w - w0) << 6) : (0x80000000u | ((w - wf) << 6));
+    for (uint32_t i = a; i < b; i++) {
+      const uint32_t v = runbit[e[i]] - lo;
+      if (v < 64u) m |= 1ull << v;
+    }
+    mask[(size_t)w * nsk + s] = m;
+  }
+}
+constexpr uint32_t kMaskWordsExtra = 64;       // words beyond two per range the masks may take
 
 // What an owner publishes about its slice.  The share is [SliceHeader][roots: nsk u32][hbound: Rg u64][ranks: nmax u32].
 struct SliceHeader {
@@ -1792,6 +2069,7 @@ struct TiledExperiments {
   int rpw = 0, wpb = 4, minw = 8;     // rpw 0 = chosen by the plan
   bool pf = false;                    // with rpw: the pipelined kernel
   bool xcd = true;
+  bool no_masks = false;              // the walk from the first range on (A/B of the range masks)
 };
 static const TiledExperiments& tiled_experiments() {
   static const TiledExperiments ex = [] {
@@ -1805,6 +2083,7 @@ static const TiledExperiments& tiled_experiments() {
     if (const char* v = std::getenv("SOURMASH_AMD_CMP_GEO")) sscanf(v, "%d,%d,%d", &e.rpw, &e.wpb, &e.minw);
     if (const char* v = std::getenv("SOURMASH_AMD_CMP_PF")) e.pf = std::atoi(v) != 0;
     if (std::getenv("SOURMASH_AMD_CMP_NO_XCD")) e.xcd = false;
+    if (std::getenv("SOURMASH_AMD_CMP_NO_MASKS")) e.no_masks = true;
 #endif
     return e;
   }();
@@ -1854,6 +2133,11 @@ struct CollectionDict {
   const uint32_t* root_ptr = nullptr;
   const uint64_t* hbound_ptr = nullptr;
   DeviceBuffer off, splitters, spart, segoff, share, dstate, rankv, root, fmask, fpos, hbound, part;
+  // range masks (one owner): shared number of every element, shared hashes below every range boundary, word offsets,
+  // what k_mask_layout decided, the masks and the crossings range-major (built with the partition table)
+  DeviceBuffer sid, sb, woff, minfo, masks, partT;
+  uint32_t mask_words_max = 0;
+  bool has_masks = false;
   std::vector<uint64_t> rel_off;
 };
 
@@ -2035,6 +2319,28 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
                      G == 1 ? D.dstate.as<DictState>() : (DictState*)nullptr, 0u);
   hipLaunchKernelGGL(k_hbounds, dim3((D.Rg + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), T.uniq.as<uint64_t>(), rs, nm, D.Rg,
                      D.splitters.as<uint64_t>() + rank, reinterpret_cast<uint64_t*>(share + D.hbound_at));   // (slice's lower end: by pointer)
+  // ---- range masks (one owner): a bit for every shared hash (distinct within its component and range), every element's bit,
+  // the words of every range (see "range masks")
+  D.has_masks = G == 1 && nm > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
+  if (D.has_masks) {
+    const uint32_t R = D.R;
+    T.cnt.ensure(((size_t)n * R + 3 * R + 8) * 4);    // counters per (component, range); frequent counters, maxima, total; first runs
+    uint32_t* cnt = T.cnt.as<uint32_t>();
+    uint32_t* fcnt = cnt + (size_t)n * R;
+    uint32_t* kmax = fcnt + R;
+    uint32_t* total = kmax + R;
+    uint32_t* rlo = total + 4;
+    D.sid.ensure(ne * 4);                                           // the bit of every run (an element's rank is its run)
+    D.sb.ensure((size_t)(R + 1) * 4); D.woff.ensure((size_t)(R + 2) * 4); D.minfo.ensure(sizeof(MaskInfo));
+    D.mask_words_max = 2 * R + kMaskWordsExtra;
+    HIP_CHECK(hipMemsetAsync(cnt, 0, ((size_t)n * R + 2 * R + 4) * 4, s));
+    hipLaunchKernelGGL(k_range_runs, dim3((R + 256) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, R, rlo);
+    hipLaunchKernelGGL(k_shared_bits, dim3((nm + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, so, T.node.as<uint32_t>(),
+                       roots, isfreq, rlo, R, cnt, fcnt, D.sid.as<uint32_t>());
+    hipLaunchKernelGGL(k_mask_max, dim3((unsigned)(((uint64_t)n * R + 255) / 256)), dim3(256), 0, s, cnt, (uint64_t)n * R, R, kmax, total);
+    hipLaunchKernelGGL(k_mask_layout, dim3(1), dim3(1024), 0, s, kmax, fcnt, total, R, D.mask_words_max, D.sb.as<uint32_t>(),
+                       D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>());
+  }
   HIP_CHECK(hipGetLastError());
   if (!D.force_radix && G > 1) {
     // a share goes to the other owners next (the caller waits for it anyway): it must not be a void one.  (One owner: the
@@ -2113,7 +2419,7 @@ void collection_free(CollectionDict* D) {
   if (!D) return;
   (void)hipDeviceSynchronize();    // ONE wait for whatever may still be using the buffers, then they all go back to the pool
   for (DeviceBuffer* b : {&D->off, &D->splitters, &D->spart, &D->segoff, &D->share, &D->dstate, &D->rankv, &D->root, &D->fmask, &D->fpos,
-                          &D->hbound, &D->part})
+                          &D->hbound, &D->part, &D->sid, &D->sb, &D->woff, &D->minfo, &D->masks, &D->partT})
     b->release_after_sync();
   delete D;
 }
@@ -2121,7 +2427,7 @@ static CollectionDict& implicit_dict();
 static void release_implicit_dict() {
   CollectionDict& D = implicit_dict();
   for (DeviceBuffer* b : {&D.off, &D.splitters, &D.spart, &D.segoff, &D.share, &D.dstate, &D.rankv, &D.root, &D.fmask, &D.fpos,
-                          &D.hbound, &D.part})
+                          &D.hbound, &D.part, &D.sid, &D.sb, &D.woff, &D.minfo, &D.masks, &D.partT})
     b->release();
   D.finished = false;
 }
@@ -2296,6 +2602,14 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     DictState* ds = D.dstate.as<DictState>();
     hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, D.n,
                        D.hbound_ptr, R, D.part.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
+    const bool use_masks = D.has_masks && tune.no_range_masks == 0 && !ex.no_masks;
+    if (use_masks) {
+      D.masks.ensure((size_t)D.n * D.mask_words_max * 8);
+      D.partT.ensure((size_t)D.n * (R + 1) * 4);
+      hipLaunchKernelGGL(k_build_masks, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.part.as<uint32_t>(), off,
+                         D.rank_ptr, D.sid.as<uint32_t>(), D.sb.as<uint32_t>(), D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>(), D.n, R,
+                         D.masks.as<unsigned long long>(), D.partT.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
+    }
     hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, forced_pf, fill_tiles, &ds->part_built);
     // the list: at 16 rows per tile at most every tile; shorter tiles are only chosen when fewer than
     // fill_tiles 16-row tiles are flagged (each splits into at most 4)
@@ -2317,6 +2631,8 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     a.tiles = T.tiles.as<uint32_t>(); a.tiles_cap = tiles_cap; a.rkey = rkey; a.ckey = ckey; a.st = st;
     a.use_xcd = ex.xcd ? 1u : 0u;
     a.scope = sc;
+    a.masks = use_masks ? D.masks.as<unsigned long long>() : nullptr; a.partT = D.partT.as<uint32_t>(); a.woff = D.woff.as<uint32_t>();
+    a.wn = D.sb.as<uint32_t>(); a.minfo = D.minfo.as<MaskInfo>(); a.nsk = D.n;
     // LDS budget per workgroup ~18 KB so that 8 workgroups of 4 waves fit a CU: the merge loop is a
     // dependent LDS-read -> compare -> advance chain, and occupancy is what hides its latency
     // (profiles/r01_compare_geometry.txt: 575 -> 1000 M pairs/s from 3 to 8 waves per SIMD)

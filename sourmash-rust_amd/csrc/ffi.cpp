@@ -974,6 +974,7 @@ void smh_compare_get_tuning(SmhCompareTuning* out) {
   const smh::CompareTuning t = smh::compare_get_tuning();
   out->route = t.route; out->visit_all_tiles = t.visit_all_tiles; out->use_symmetry = t.use_symmetry;
   out->comp_pairs_limit = t.comp_pairs_limit; out->split_frequent = t.split_frequent; out->dictionary = t.dictionary;
+  out->no_range_masks = t.no_range_masks;
 }
 int smh_compare_set_tuning(const SmhCompareTuning* in) {
   return pad_code([&] {
@@ -984,6 +985,7 @@ int smh_compare_set_tuning(const SmhCompareTuning* in) {
       t.comp_pairs_limit = in->comp_pairs_limit; t.split_frequent = in->split_frequent;
       if (in->dictionary > 1) smh::throw_internal("smh_compare_set_tuning: unknown dictionary build");
       t.dictionary = in->dictionary;
+      t.no_range_masks = in->no_range_masks ? 1u : 0u;
     }
     smh::compare_set_tuning(t);
   });

@@ -189,6 +189,7 @@ struct CompareTuning {
   uint32_t use_symmetry = 1;               // all-vs-all with one num: compute the upper triangle, mirror the rest
   uint32_t split_frequent = 1;             // hashes held by a large share of the sketches do not make components
   uint32_t dictionary = 0;                 // 1: the pooled sort of the dictionary with all eight byte passes (default: four + tie fix)
+  uint32_t no_range_masks = 0;             // 1: the tiled kernel walks every pair from the first range on (default: range masks)
   uint64_t comp_pairs_limit = 96ull << 10;  // at most this many sharing pairs: per-component pair kernel, else tiled (the pair kernel
                                            // takes ~3.7 ns per pair of num = 2000 sketches, one round of tiles ~0.45 ms: profiles/r03_tile_shape.txt)
 };

@@ -15,11 +15,12 @@ DICTIONARIES = {"auto": 0, "full": 1}
 
 
 @contextlib.contextmanager
-def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=96 << 10, split_frequent=True, dictionary="auto"):
+def tuning(route="auto", visit_all_tiles=False, use_symmetry=True, comp_pairs_limit=96 << 10, split_frequent=True, dictionary="auto",
+           range_masks=True):
     """Pins which kernel serves the block compares inside the `with` (additive ABI
     smh_compare_set_tuning; results never depend on it), then restores the defaults."""
     t = SmhCompareTuning(ROUTES[route], int(visit_all_tiles), int(use_symmetry), comp_pairs_limit, int(split_frequent),
-                         DICTIONARIES[dictionary])
+                         DICTIONARIES[dictionary], 0 if range_masks else 1)
     call(lib().smh_compare_set_tuning, C.byref(t))
     try:
         yield

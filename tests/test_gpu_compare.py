@@ -26,6 +26,9 @@ ROUTES = [
     # the pooled sort of the dictionary with all eight byte passes instead of four + the tie fix
     pytest.param(dict(dictionary="full"), None, id="auto-full-sort-dictionary"),
     pytest.param(dict(route="tiled", dictionary="full"), "tiled", id="tiled-full-sort-dictionary"),
+    # the tiled kernel walking every pair from the first range on, instead of from where the range masks say its cut lies
+    pytest.param(dict(route="tiled", range_masks=False), "tiled", id="tiled-no-range-masks"),
+    pytest.param(dict(route="tiled", visit_all_tiles=True, range_masks=False), "tiled", id="tiled-all-tiles-no-range-masks"),
 ]
 
 
@@ -247,12 +250,15 @@ def test_halved_span_ahead_of_a_prefetched_crossing(num, pkg, coracle):
     ocommon, osize, ojac = coracle.compare_matrix(rows, cols, num, 21, 0)
     occ = np.array([[len(np.intersect1d(a, b, assume_unique=True)) for b in cols] for a in rows], dtype=np.int64)
     halvings = after = 0
-    for tune in (dict(route="tiled"), dict(route="tiled", visit_all_tiles=True)):
+    # (range_masks=False: the walk from the first range on -- with the masks a pair is walked only around its cut, or, without
+    # a cut, not at all; the last entry checks that route on the same input)
+    for tune in (dict(route="tiled", range_masks=False), dict(route="tiled", visit_all_tiles=True, range_masks=False), dict(route="tiled")):
         with pkg.matrix.tuning(**tune):
             out = pkg.matrix.compare_block_dev(tr, ro, tc, co, num, want=("jaccard", "common", "size", "count_common"))
             st = pkg.matrix.last_stats()
         assert st["route"] == "tiled" and st["pipelined"] == 1, st
-        halvings += st["span_halvings"]; after += st["prefetched_after_halving"]
+        if not tune.get("range_masks", True):
+            halvings += st["span_halvings"]; after += st["prefetched_after_halving"]
         assert (out["jaccard"].cpu().numpy() == ojac).all()
         assert (out["common"].cpu().numpy().view(np.uint64) == ocommon).all()
         assert (out["size"].cpu().numpy().view(np.uint64) == osize).all()
@@ -555,11 +561,12 @@ def test_tiled_global_merge_branch(pkg, coracle):
         cf, co = pkg.matrix.csr_from_sketches(cols)
         rt = torch.from_numpy(rf.view(np.int64)).cuda()
         ct = torch.from_numpy(cf.view(np.int64)).cuda()
-        for tune in (dict(route="tiled"), dict(route="tiled", visit_all_tiles=True)):
+        # (range_masks=False: every range walked -- with the masks a pair is only walked around its cut, which may miss the sliver)
+        for tune in (dict(route="tiled", range_masks=False), dict(route="tiled", visit_all_tiles=True, range_masks=False), dict(route="tiled")):
             with pkg.matrix.tuning(**tune):
                 out = pkg.matrix.compare_block_dev(rt, ro, ct, co, num, want=("jaccard", "common", "size", "count_common"))
                 st = pkg.matrix.last_stats()
-            assert st["route"] == "tiled" and st["lds_overflow_steps"] > 0, st
+            assert st["route"] == "tiled" and (st["lds_overflow_steps"] > 0 or tune.get("range_masks", True)), st
             assert (out["common"].cpu().numpy().view(np.uint64) == common).all()
             assert (out["size"].cpu().numpy().view(np.uint64) == size).all()
             assert (out["jaccard"].cpu().numpy() == jac).all()

@@ -22,6 +22,8 @@ if os.environ.get("PROF_FORCE_TILED"):
     tune = dict(tune, route="tiled")
 if os.environ.get("PROF_DICT"):
     tune = dict(tune, dictionary=os.environ["PROF_DICT"])
+if os.environ.get("PROF_NO_MASKS"):
+    tune = dict(tune, range_masks=False)
 if os.environ.get("PROF_COMP_LIMIT"):
     tune = dict(tune, comp_pairs_limit=int(os.environ["PROF_COMP_LIMIT"]))
 import ctypes as C

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for cfg in ${TRACE_CFGS:-"1000 one_family" "1000 families" "10000 families"}; do
+for cfg in "1000 one_family" "1000 families" "10000 families"; do
   set -- $cfg
   out=$R/gpurun_out/r4_trace_$1_$2
   rm -rf $out
