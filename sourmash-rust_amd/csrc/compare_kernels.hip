@@ -1518,6 +1518,18 @@ __global__ __launch_bounds__(256) void k_shared_bits(const uint32_t* __restrict_
   if (isfreq && isfreq[r]) runbit[r] = atomicAdd(&fcnt[lo], 1u) | 0x80000000u;
   else runbit[r] = atomicAdd(&cnt[(size_t)roots[node[origin[a]]] * R + lo], 1u);
 }
+// rank and bit of every element, in collection order, in ONE pass over the sorted positions (the runs' bits are read in
+// run order; the scatter by origin is the one the ranks need anyway -- with masks it runs here instead of inside the
+// run-length write).  ebit: the element's bit (bit 15: a frequent bit), 0xffff = none.
+__global__ __launch_bounds__(256) void k_rank_bit_scatter(const uint32_t* __restrict__ runid, const uint32_t* __restrict__ origin,
+                                                          const uint32_t* __restrict__ runbit, uint32_t n, uint32_t* __restrict__ rank,
+                                                          uint16_t* __restrict__ ebit) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t run = runid[i], o = origin[i], b = runbit[run];
+  rank[o] = run;
+  ebit[o] = b == kSidNone ? (uint16_t)0xffffu : (uint16_t)((b & 0x7fffu) | ((b >> 31) << 15));
+}
 // kmax[r] = the most shared hashes any component has in range r (few counters are not zero: one atomic each)
 __global__ __launch_bounds__(256) void k_mask_max(const uint32_t* __restrict__ cnt, uint64_t m, uint32_t R, uint32_t* __restrict__ kmax,
                                                   uint32_t* __restrict__ total) {
@@ -1533,12 +1545,16 @@ __global__ __launch_bounds__(1024) void k_mask_layout(const uint32_t* __restrict
                                                       uint32_t* __restrict__ wn, uint32_t* __restrict__ woff, MaskInfo* __restrict__ info) {
   __shared__ uint32_t wt[16], st[16];
   const uint32_t per = (R + 1023) / 1024, r0 = min(threadIdx.x * per, R), r1 = min(r0 + per, R);
+  __shared__ uint32_t wide;
+  if (threadIdx.x == 0) wide = 0;
+  __syncthreads();
   uint32_t mine = 0, shared = 0;
   for (uint32_t r = r0; r < r1; r++) {
     const uint32_t words = (kmax[r] + 63u) >> 6;
     wn[r] = words;
     mine += words + ((fcnt[r] + 63u) >> 6);
     shared += fcnt[r];
+    if (kmax[r] >= 0x7fffu || fcnt[r] >= 0x7fffu) wide = 1;         // (an element's bit is kept in 15 bits)
   }
   const uint32_t incl = wave_incl_scan_add(mine);
   uint32_t sh = shared;
@@ -1546,46 +1562,39 @@ __global__ __launch_bounds__(1024) void k_mask_layout(const uint32_t* __restrict
   if ((threadIdx.x & 63) == 63) wt[threadIdx.x >> 6] = incl;
   if ((threadIdx.x & 63) == 0) st[threadIdx.x >> 6] = sh;
   __syncthreads();
+  const uint32_t toowide = wide;
   uint32_t run = incl - mine, tot = 0, stot = *total;
   for (uint32_t ww = 0; ww < 16; ww++) { if (ww < (threadIdx.x >> 6)) run += wt[ww]; tot += wt[ww]; stot += st[ww]; }
   for (uint32_t r = r0; r < r1; r++) { woff[r] = run; run += wn[r] + ((fcnt[r] + 63u) >> 6); }
   if (threadIdx.x == 0) {
     woff[R] = tot;
-    info->ok = (tot <= wmax && stot > 0) ? 1u : 0u; info->wtot = tot; info->shared = stot; info->pad = 0;
+    info->ok = (tot <= wmax && stot > 0 && !toowide) ? 1u : 0u; info->wtot = tot; info->shared = stot; info->pad = 0;
   }
 }
 // mask[w][s] for the words of range r, and the crossings once more with the range first: partT[r][s] = part[s][r]
 // (the tiled kernel reads both with its 64 columns in consecutive lanes).  A lane per (sketch, range).
 __global__ __launch_bounds__(256) void k_build_masks(const uint32_t* __restrict__ part, const uint64_t* __restrict__ off,
-                                                     const uint32_t* __restrict__ rank, const uint32_t* __restrict__ runbit,
+                                                     const uint16_t* __restrict__ ebit,
                                                      const uint32_t* __restrict__ wn,
                                                      const uint32_t* __restrict__ woff, const MaskInfo* __restrict__ info, uint32_t nsk,
                                                      uint32_t R, unsigned long long* __restrict__ mask, uint32_t* __restrict__ partT,
                                                      const uint32_t* __restrict__ skip, const uint32_t* __restrict__ built) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (uint64_t)nsk * (R + 1) || *skip || *built || !info->ok) return;
-  const uint32_t r = (uint32_t)(g / nsk), s = (uint32_t)(g % nsk);      // (sketch fastest: the stores of a wave are contiguous)
+  // (range fastest: a wave reads 64 consecutive crossings and 64 consecutive stretches of ONE sketch's ranks; the few
+  // stores -- a word and a crossing per lane -- are the scattered side)
+  const uint32_t s = (uint32_t)(g / (R + 1)), r = (uint32_t)(g % (R + 1));
   const uint32_t a = part[(size_t)s * (R + 1) + r];
   partT[(size_t)r * nsk + s] = a;
   if (r == R) return;
   const uint32_t b = part[(size_t)s * (R + 1) + r + 1];
-  const uint32_t* e = rank + off[s];               // (an element's rank is the run of its hash)
+  const uint16_t* e = ebit + off[s];
   const uint32_t w0 = woff[r], w1 = woff[r + 1], wf = w0 + wn[r];       // [w0, wf): the component's words; [wf, w1): the frequent ones
-  if (w1 - w0 == 1) {                              // (the usual case: one word, the elements' bits read once)
-    unsigned long long m = 0;
-    const uint32_t lo = w0 < wf ? 0u : 0x80000000u;
-    for (uint32_t i = a; i < b; i++) {
-      const uint32_t v = runbit[e[i]] - lo;        // (none, or a bit of the other kind: never below 64)
-      if (v < 64u) m |= 1ull << v;
-    }
-    mask[(size_t)w0 * nsk + s] = m;
-    return;
-  }
   for (uint32_t w = w0; w < w1; w++) {
     unsigned long long m = 0;
-    const uint32_t lo = w < wf ? ((w - w0) << 6) : (0x80000000u | ((w - wf) << 6));
+    const uint32_t lo = w < wf ? ((w - w0) << 6) : (0x8000u | ((w - wf) << 6));
     for (uint32_t i = a; i < b; i++) {
-      const uint32_t v = runbit[e[i]] - lo;
+      const uint32_t v = (uint32_t)e[i] - lo;       // (none = 0xffff, or a bit of the other kind: never below 64)
       if (v < 64u) m |= 1ull << v;
     }
     mask[(size_t)w * nsk + s] = m;
@@ -2255,9 +2264,12 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       hipLaunchKernelGGL(k_tie_sort, dim3((unsigned)dev.cu_count()), dim3(kBsThreads), 0, s, sk, so, nm, rs, list);
     }
   }
-  // (with the ranks: rank[origin[i]] = run of sorted position i goes out with the runs)
-  run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, so,
-                              reinterpret_cast<uint32_t*>(share + D.ranks_at), &rs->nruns, nullptr, T.runid.as<uint32_t>());
+  // (with the ranks: rank[origin[i]] = run of sorted position i goes out with the runs -- unless the range masks are built:
+  // then the ranks leave together with the elements' bits, further down)
+  D.has_masks = G == 1 && nm > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
+  run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, D.has_masks ? nullptr : so,
+                              D.has_masks ? nullptr : reinterpret_cast<uint32_t*>(share + D.ranks_at), &rs->nruns, nullptr,
+                              T.runid.as<uint32_t>());
   // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
   const uint8_t* isfreq = nullptr;
   if (D.split && nm) {
@@ -2321,7 +2333,6 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
                      D.splitters.as<uint64_t>() + rank, reinterpret_cast<uint64_t*>(share + D.hbound_at));   // (slice's lower end: by pointer)
   // ---- range masks (one owner): a bit for every shared hash (distinct within its component and range), every element's bit,
   // the words of every range (see "range masks")
-  D.has_masks = G == 1 && nm > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
   if (D.has_masks) {
     const uint32_t R = D.R;
     T.cnt.ensure(((size_t)n * R + 3 * R + 8) * 4);    // counters per (component, range); frequent counters, maxima, total; first runs
@@ -2330,13 +2341,17 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     uint32_t* kmax = fcnt + R;
     uint32_t* total = kmax + R;
     uint32_t* rlo = total + 4;
-    D.sid.ensure(ne * 4);                                           // the bit of every run (an element's rank is its run)
+    D.sid.ensure(ne * 2);                                           // the bit of every element (u16)
+    T.pk0.ensure(ne * 4);                                           // the bit of every run (the plan's key buffer: free until the first compare)
+    uint32_t* runbit = T.pk0.as<uint32_t>();
     D.sb.ensure((size_t)(R + 1) * 4); D.woff.ensure((size_t)(R + 2) * 4); D.minfo.ensure(sizeof(MaskInfo));
-    D.mask_words_max = 2 * R + kMaskWordsExtra;
+    D.mask_words_max = 2 * R + kMaskWordsExtra;            // (a range's bits stay below 2^15 whatever it is: k_mask_layout checks)
     HIP_CHECK(hipMemsetAsync(cnt, 0, ((size_t)n * R + 2 * R + 4) * 4, s));
     hipLaunchKernelGGL(k_range_runs, dim3((R + 256) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, R, rlo);
     hipLaunchKernelGGL(k_shared_bits, dim3((nm + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, so, T.node.as<uint32_t>(),
-                       roots, isfreq, rlo, R, cnt, fcnt, D.sid.as<uint32_t>());
+                       roots, isfreq, rlo, R, cnt, fcnt, runbit);
+    hipLaunchKernelGGL(k_rank_bit_scatter, dim3((nm + 255) / 256), dim3(256), 0, s, T.runid.as<uint32_t>(), so, runbit, nm,
+                       reinterpret_cast<uint32_t*>(share + D.ranks_at), D.sid.as<uint16_t>());
     hipLaunchKernelGGL(k_mask_max, dim3((unsigned)(((uint64_t)n * R + 255) / 256)), dim3(256), 0, s, cnt, (uint64_t)n * R, R, kmax, total);
     hipLaunchKernelGGL(k_mask_layout, dim3(1), dim3(1024), 0, s, kmax, fcnt, total, R, D.mask_words_max, D.sb.as<uint32_t>(),
                        D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>());
@@ -2607,7 +2622,7 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
       D.masks.ensure((size_t)D.n * D.mask_words_max * 8);
       D.partT.ensure((size_t)D.n * (R + 1) * 4);
       hipLaunchKernelGGL(k_build_masks, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.part.as<uint32_t>(), off,
-                         D.rank_ptr, D.sid.as<uint32_t>(), D.sb.as<uint32_t>(), D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>(), D.n, R,
+                         D.sid.as<uint16_t>(), D.sb.as<uint32_t>(), D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>(), D.n, R,
                          D.masks.as<unsigned long long>(), D.partT.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
     }
     hipLaunchKernelGGL(k_plan_geometry, dim3(1), dim3(1), 0, s, st, forced_rpw, forced_pf, fill_tiles, &ds->part_built);
