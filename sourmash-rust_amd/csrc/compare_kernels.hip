@@ -520,15 +520,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {      // the minimum, in every lane's return value
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x111, 0xf, 0xf, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x112, 0xf, 0xf, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x114, 0xf, 0xf, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x118, 0xf, 0xf, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false));
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false));
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // the maximum, in every lane's return value
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
@@ -934,7 +925,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
   if (use_masks) {
     const uint32_t nsk = ka.nsk;
     const uint32_t gcol = col_ok ? ka.scope.col_base + col : 0u;
-    uint32_t grow[kRowsPerWave], nq[kRowsPerWave], rstar[kRowsPerWave];
+    uint32_t grow[kRowsPerWave], nq[kRowsPerWave], rstar[kRowsPerWave], ipre[kRowsPerWave];
     uint32_t self = 0;                  // bit q: the pair is a sketch with ITSELF -- everything matches, also what nobody else holds
     uint32_t samec[kRowsPerWave];       // all ones: row and column are of one component (bits are handed out per component: a pair
                                         // across components can only share FREQUENT hashes, which have words of their own)
@@ -944,7 +935,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       const uint32_t row = rowid[w * kRowsPerWave + q];
       grow[q] = row != kNone ? ka.scope.row_base + row : 0u;
       nq[q] = (row != kNone && col_ok) ? nrowL[w * kRowsPerWave + q] : kNone;     // (no pair: never cut)
-      mtot[q] = 0; rstar[q] = R;
+      mtot[q] = 0; rstar[q] = R; ipre[q] = 0;
       if (row != kNone && col_ok && grow[q] == gcol) self |= 1u << q;
       const uint32_t rs = bi * kTR + (uint32_t)(w * kRowsPerWave + q);
       samec[q] = (rs < ka.nrows && (uint32_t)(ka.rkey[rs] >> 32) == ccomp) ? 0xffffffffu : 0u;
@@ -953,6 +944,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     const uint32_t* pT = ka.partT;
     for (uint32_t r = 0; r < R; r++) {
       const uint32_t w0 = ka.woff[r], w1 = ka.woff[r + 1], wf = w0 + ka.wn[r];
+      uint32_t prev[kRowsPerWave];                     // matches before this range
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) prev[q] = mtot[q];
       for (uint32_t wi = w0; wi < wf; wi++) {
         const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
 #pragma unroll
@@ -968,7 +962,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       for (int q = 0; q < kRowsPerWave; q++) {
         const uint32_t pa = pT[(size_t)(r + 1) * nsk + grow[q]];
         const uint32_t u = pa + pb - (((self >> q) & 1u) ? pa : mtot[q]);
-        if (rstar[q] == R && u >= nq[q]) rstar[q] = r;
+        if (rstar[q] == R && u >= nq[q]) { rstar[q] = r; ipre[q] = prev[q]; }
       }
       // (count_common not wanted: a wave whose pairs have all found their range needs no more of the totals)
       if (!WantCC && (r & 7u) == 7u) {
@@ -978,45 +972,51 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
         if (__all(all)) break;
       }
     }
-    uint32_t mn = R;
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
-      if (rstar[q] == R) nocut |= 1u << q; else mn = min(mn, rstar[q]);
+      if (rstar[q] == R) nocut |= 1u << q;
       if ((self >> q) & 1u) mtot[q] = pT[(size_t)R * nsk + grow[q]];
     }
-    mn = wave_min_u32(mn);
-    if (tid == 0) ctl[6] = R;
-    __syncthreads();
-    if (lane == 0) atomicMin(&ctl[6], mn);
-    __syncthreads();
-    first_r = ctl[6];
-    if (first_r < R) {
-      // pass 2: matches in the ranges before the walk's first one -> the walk's counters there
-      uint32_t before[kRowsPerWave];
-#pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++) before[q] = 0;
-      for (uint32_t r = 0; r < first_r; r++) {
-        const uint32_t w0 = ka.woff[r], w1 = ka.woff[r + 1], wf = w0 + ka.wn[r];
-        for (uint32_t wi = w0; wi < wf; wi++) {
-          const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
-#pragma unroll
-          for (int q = 0; q < kRowsPerWave; q++) before[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb) & samec[q];
-        }
-        for (uint32_t wi = wf; wi < w1; wi++) {
-          const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
-#pragma unroll
-          for (int q = 0; q < kRowsPerWave; q++) before[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb);
-        }
-      }
-      const uint32_t pb = pT[(size_t)first_r * nsk + gcol];
+    // ---- the ONE range in which a pair's union reaches its cut is walked by the pair's lane alone, straight from the
+    // rank arrays: ~40 steps of two cached loads each, a wave's rows side by side (independent chains); no stage, no
+    // table, no barrier -- everything before that range is known from the masks.
+    {
+      uint32_t ai[kRowsPerWave], ae[kRowsPerWave], bi2[kRowsPerWave], be[kRowsPerWave], left[kRowsPerWave], mm[kRowsPerWave];
+      bool any = false;
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; q++) {
-        const uint32_t pa = pT[(size_t)first_r * nsk + grow[q]];
-        if ((self >> q) & 1u) before[q] = pa;
-        common[q] = before[q];
-        ucount[q] = pa + pb - before[q];
+        ai[q] = ae[q] = bi2[q] = be[q] = left[q] = mm[q] = 0;
+        if (!((nocut >> q) & 1u)) {
+          const uint32_t row = rowid[w * kRowsPerWave + q], rs = rstar[q];
+          const uint32_t pa = pT[(size_t)rs * nsk + grow[q]], pb = pT[(size_t)rs * nsk + gcol];
+          const uint32_t before = ((self >> q) & 1u) ? pa : ipre[q];
+          ai[q] = (uint32_t)ka.roff[row] + pa; ae[q] = (uint32_t)ka.roff[row] + pT[(size_t)(rs + 1) * nsk + grow[q]];
+          bi2[q] = (uint32_t)ka.coff[col] + pb; be[q] = (uint32_t)ka.coff[col] + pT[(size_t)(rs + 1) * nsk + gcol];
+          left[q] = nq[q] - (pa + pb - before);          // union elements still to go (> 0: the cut lies in this range)
+          mm[q] = before;
+          any = true;
+        }
       }
+      while (__any(any)) {
+        any = false;
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) {
+          if (left[q]) {
+            const uint32_t av = ai[q] < ae[q] ? ka.rrank[ai[q]] : kSentA;
+            const uint32_t bv = bi2[q] < be[q] ? ka.crank[bi2[q]] : kSent;
+            mm[q] += av == bv ? 1u : 0u;
+            ai[q] += av <= bv ? 1u : 0u;
+            bi2[q] += bv <= av ? 1u : 0u;
+            left[q] -= 1u;
+            any = any || left[q] != 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++)
+        if (!((nocut >> q) & 1u)) { common[q] = mm[q]; ucount[q] = nq[q]; }
     }
+    first_r = R;            // (nothing is left for the staged walk)
   }
 
   // ---- stretches 0 and 1 with plain loads; the ranks of stretch 0 and the crossings at the end of stretch 2 requested
