@@ -521,7 +521,9 @@ def main():
         cmp_roof = None
         if dense["rank0_kernel_ms"] > 0 and dense["route"] == "tiled":
             pmc, pmc_file = None, None
-            for name in ("r04_pmc_compare_tiled.json", "r03_pmc_compare_tiled.json"):
+            # (one owner's dictionary has range masks since round 4: counters of that kernel; a sliced dictionary -- N > 1 -- walks
+            # from the first range on: round 3's counters)
+            for name in (("r04_pmc_compare_tiled.json", "r03_pmc_compare_tiled.json") if world == 1 else ("r03_pmc_compare_tiled.json",)):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                     pmc_file = name
@@ -529,25 +531,40 @@ def main():
                 except Exception:
                     continue
             walked, kms = dense["rank0_pairs_walked"], dense["rank0_kernel_ms"]
+            masked = bool(pmc and pmc.get("wait_any_share_of_wave_cycles")) and world == 1
             lds_bytes = pmc.get("lds_bytes_per_walked_pair") * walked if pmc and pmc.get("lds_bytes_per_walked_pair") else None
             lds_achieved = lds_bytes / (kms * 1e-3) / 1e12 if lds_bytes else None
-            cmp_roof = {"kernel": dense["rank0_kernel"], "bound": "lds", "unit": "TB/s", "peak": LDS_READ_B32_PEAK_TBS,
-                        "kernel_ms_avg": kms, "pairs_walked": walked, "n_signatures": sizes[0],
-                        "achieved": lds_achieved, "frac": lds_achieved / LDS_READ_B32_PEAK_TBS if lds_achieved else None,
-                        "lds_bytes": lds_bytes,
-                        "lds_bytes_source": ("profiles/%s (SQ_INSTS_LDS of a separate rocprofv3 --pmc pass of %s "
-                                             "x 64 lanes x 4 B per walked pair; committed, not measured in this run)" % (pmc_file, pmc.get("kernel", "the kernel"))) if lds_bytes else None,
+            cmp_roof = {"kernel": dense["rank0_kernel"] + (" (range masks)" if masked else ""), "kernel_ms_avg": kms, "pairs_walked": walked,
+                        "n_signatures": sizes[0],
                         "effective_bytes": walked * ((NUM + NUM) * 8 + 8),
                         "effective_TBps": walked * ((NUM + NUM) * 8 + 8) / (kms * 1e-3) / 1e12,
                         "compulsory_hbm_bytes": sizes[0] * NUM * 8 + D.shard_range(sizes[0], world, 0)[2] * sizes[0] * 8,
-                        "valu_bound": None,
-                        "note": "integer compare/indexing, no MFMA.  'effective' = SURVEY.md 8d's (|A|+|B|)*8+8 B per walked pair, "
-                                "served from LDS/L2 (may exceed the HBM peak: it is not HBM traffic); 'achieved' = actual ds_read "
-                                "bytes against the guide's ds_read_b32 aggregate (~75 TB/s); compulsory HBM traffic is "
-                                "N*16 KB in + rows*N*8 B out"}
+                        "counters_source": "profiles/%s (separate rocprofv3 --pmc passes of %s, committed; not measured in this run)"
+                                           % (pmc_file, pmc.get("kernel", "the kernel")) if pmc else None,
+                        "valu_bound": None}
+            if masked:
+                # one owner's dictionary carries range masks: per pair the range of its cut comes from popcounts and only that
+                # range is walked -- next to no LDS traffic, 13.7 x fewer VALU instructions; what bounds the kernel is the latency
+                # of its (L2-served) loads
+                cmp_roof.update({"bound": "memory latency (L2 round trips)", "unit": None, "peak": None, "achieved": None, "frac": None,
+                                 "wait_any_share_of_wave_cycles": pmc["wait_any_share_of_wave_cycles"],
+                                 "vmem_loads_per_64_pairs": pmc.get("vmem_loads_per_64_pairs"),
+                                 "memory_side_bytes": pmc.get("memory_side_bytes_per_launch"),
+                                 "note": "integer compare/indexing, no MFMA.  The union of a pair is cut after `num` elements (reference "
+                                         "src/lib.rs:470-499); where that happens follows from per-range bit masks of the shared hashes "
+                                         "(DESIGN.md 3.4 'range masks'), so a pair costs ~2 000 VALU wave-instructions per 64 pairs instead "
+                                         "of ~27 000 and a wave spends most of its cycles waiting for loads.  'effective' = SURVEY.md 8d's "
+                                         "(|A|+|B|)*8+8 B per compared pair over the kernel time (not traffic: most of those bytes are never read)"})
+            else:
+                cmp_roof.update({"bound": "lds", "unit": "TB/s", "peak": LDS_READ_B32_PEAK_TBS,
+                                 "achieved": lds_achieved, "frac": lds_achieved / LDS_READ_B32_PEAK_TBS if lds_achieved else None,
+                                 "lds_bytes": lds_bytes,
+                                 "note": "integer compare/indexing, no MFMA.  'effective' = SURVEY.md 8d's (|A|+|B|)*8+8 B per walked pair, "
+                                         "served from LDS/L2 (may exceed the HBM peak: it is not HBM traffic); 'achieved' = actual ds_read "
+                                         "bytes against the guide's ds_read_b32 aggregate (~75 TB/s); compulsory HBM traffic is "
+                                         "N*16 KB in + rows*N*8 B out"})
         if cmp_roof and pmc and pmc.get("valu_wave_insts_per_64_pairs"):
-            # the binding resource (like the sketch kernel's): VALU issue.  Wave instructions per 64 walked pairs from the
-            # committed PMC pass, priced at the guide's 2 cycles per wave64 instruction
+            # VALU issue: wave instructions per 64 compared pairs from the committed PMC pass at the guide's 2 cycles per wave64 instruction
             vi = pmc["valu_wave_insts_per_64_pairs"]
             floor2 = cmp_roof["pairs_walked"] / 64.0 * vi * VALU_CYCLES / (SIMDS * MAX_CLOCK_HZ) * 1e3
             cmp_roof["valu_bound"] = {"valu_wave_insts_per_64_pairs": vi, "floor_ms_at_2_cycles": floor2,

@@ -1540,10 +1540,18 @@ __global__ __launch_bounds__(256) void k_mask_max(const uint32_t* __restrict__ c
 }
 // per range: the words its busiest component needs (wn), the frequent words behind them, the offsets; and whether the masks
 // are worth building.  One workgroup; lane per range for the maximum over the components' counters.
+// (lazy_go: the plan walks tiles, the masks do not exist yet, and there are enough pairs that can share a hash for them to
+// pay -- building them is three passes over all pooled hashes, whatever part of the matrix this owner computes)
+__device__ __forceinline__ bool lazy_go(const PlanState* st, const uint32_t* built, uint32_t n) {
+  return !st->skip_tiled && !*built && st->pairs * 3ull >= (unsigned long long)n;
+}
 __global__ __launch_bounds__(1024) void k_mask_layout(const uint32_t* __restrict__ kmax, const uint32_t* __restrict__ fcnt,
                                                       const uint32_t* __restrict__ total, uint32_t R, uint32_t wmax,
-                                                      uint32_t* __restrict__ wn, uint32_t* __restrict__ woff, MaskInfo* __restrict__ info) {
+                                                      uint32_t* __restrict__ wn, uint32_t* __restrict__ woff, MaskInfo* __restrict__ info,
+                                                      const PlanState* __restrict__ plan = nullptr, const uint32_t* __restrict__ built = nullptr,
+                                                      uint32_t n_lazy = 0) {
   __shared__ uint32_t wt[16], st[16];
+  if (plan && !lazy_go(plan, built, n_lazy)) return;
   const uint32_t per = (R + 1023) / 1024, r0 = min(threadIdx.x * per, R), r1 = min(r0 + per, R);
   __shared__ uint32_t wide;
   if (threadIdx.x == 0) wide = 0;
@@ -1646,6 +1654,73 @@ __global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t shar
   ds->nfreq = nf;
   ds->part_built = 0;
   ds->overflow = 0;
+}
+// ---- the same bits from an ASSEMBLED dictionary (built by `world` owners, each sorting one slice of hash space): there are no
+// runs to look at -- every owner has the ranks of all elements, the roots and the crossings, and builds the masks of all
+// sketches from those: how often every rank occurs (a histogram: 20 M atomic adds on ~10 M words), then ONE element of
+// every rank that occurs twice or more claims the rank's bit (atomicCAS), takes it from the counter of its (component,
+// range) -- the range by a search of its sketch's crossings -- and every element reads its rank's bit.
+__global__ __launch_bounds__(256) void k_lazy_clear(uint32_t* __restrict__ a, uint32_t va, uint64_t na, uint32_t* __restrict__ b, uint32_t vb,
+                                                    uint64_t nb, uint32_t n, const PlanState* __restrict__ st,
+                                                    const uint32_t* __restrict__ built, MaskInfo* __restrict__ info) {
+  if (!lazy_go(st, built, n)) return;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = va;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = vb;
+  (void)info;
+}
+__global__ __launch_bounds__(256) void k_rank_histogram(const uint32_t* __restrict__ rank, uint32_t n, uint32_t* __restrict__ cntv,
+                                                        const PlanState* __restrict__ st, const uint32_t* __restrict__ built) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n || !lazy_go(st, built, n)) return;
+  atomicAdd(&cntv[rank[t]], 1u);
+}
+constexpr uint32_t kBitClaimed = 0xfffffffeu;
+__global__ __launch_bounds__(256) void k_claim_bits(const uint32_t* __restrict__ rank, const uint64_t* __restrict__ hashes,
+                                                    const uint64_t* __restrict__ off, const uint32_t* __restrict__ part,
+                                                    const uint32_t* __restrict__ roots, const DictState* __restrict__ ds, uint32_t nsk,
+                                                    uint32_t R, uint32_t n, const uint32_t* __restrict__ cntv, uint32_t* __restrict__ bitof,
+                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ fcnt, uint32_t split,
+                                                    const PlanState* __restrict__ st, const uint32_t* __restrict__ built) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n || !lazy_go(st, built, n)) return;
+  const uint32_t id = rank[t];
+  if (cntv[id] < 2u) return;
+  if (atomicCAS(&bitof[id], kSidNone, kBitClaimed) != kSidNone) return;       // another element of this rank does it
+  // my sketch (last s with off[s] <= t), my place in it, the range that place falls into (last r with part[s][r] <= place)
+  uint32_t lo = 0, hi = nsk;
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+  const uint32_t sk = lo, place = t - (uint32_t)off[sk];
+  const uint32_t* p = part + (size_t)sk * (R + 1);
+  lo = 0; hi = R;
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (p[mid] <= place) lo = mid; else hi = mid; }
+  const uint32_t r = lo;
+  bool freq = false;
+  if (split) {
+    const uint64_t h = hashes[t];
+    const uint32_t nf = ds->nfreq;
+    for (uint32_t k = 0; k < nf; k++) freq = freq || ds->freq_hash[k] == h;
+  }
+  bitof[id] = freq ? (atomicAdd(&fcnt[r], 1u) | 0x80000000u) : atomicAdd(&cnt[(size_t)roots[sk] * R + r], 1u);
+}
+__global__ __launch_bounds__(256) void k_elem_bits(const uint32_t* __restrict__ rank, uint32_t n, const uint32_t* __restrict__ cntv,
+                                                   const uint32_t* __restrict__ bitof, uint16_t* __restrict__ ebit,
+                                                   const PlanState* __restrict__ st, const uint32_t* __restrict__ built) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n || !lazy_go(st, built, n)) return;
+  const uint32_t id = rank[t];
+  uint32_t b = kSidNone;
+  if (cntv[id] >= 2u) b = bitof[id];
+  ebit[t] = b == kSidNone ? (uint16_t)0xffffu : (uint16_t)((b & 0x7fffu) | ((b >> 31) << 15));
+}
+// (the two single-launch steps of the layout, for the lazily built masks: nothing when the plan skips the tiles or they exist)
+__global__ __launch_bounds__(256) void k_mask_max_lazy(const uint32_t* __restrict__ cnt, uint64_t m, uint32_t R, uint32_t* __restrict__ kmax,
+                                                       uint32_t* __restrict__ total, const PlanState* __restrict__ st,
+                                                       const uint32_t* __restrict__ built, uint32_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !lazy_go(st, built, n)) return;
+  const uint32_t v = cnt[i];
+  if (v) { atomicMax(&kmax[i % R], v); atomicAdd(total, v); }
 }
 // rank of every element of the collection, in collection order, from the slices' local ranks: a workgroup per sketch
 // (its slice boundaries and the slices' segment starts sit in LDS; no search per element)
@@ -2052,7 +2127,7 @@ __global__ __launch_bounds__(256) void k_flag_tiles(TileTest t, uint32_t wpb, ui
 // temporaries of building a dictionary and of planning one block compare: process-wide, grow-only, used under the device mutex
 struct TiledScratch {
   DeviceBuffer keys0, keys1, org0, org1, uniq, starts, node, parent, tiles, work, plan, pk0, pk1, pk2, pk3, rng, cnt, runid, isfreq,
-      sample0, sample1, rstate, cat, wroots, ties;
+      sample0, sample1, rstate, cat, wroots, ties, mv0, mv1;
 };
 TiledScratch& tiled_scratch() {
   static TiledScratch* t = new TiledScratch();
@@ -2104,7 +2179,7 @@ void release_compare_scratch() {
   TiledScratch& T = tiled_scratch();
   for (DeviceBuffer* b : {&T.keys0, &T.keys1, &T.org0, &T.org1, &T.uniq, &T.starts, &T.node, &T.parent, &T.tiles, &T.work, &T.plan,
                           &T.pk0, &T.pk1, &T.pk2, &T.pk3, &T.rng, &T.cnt, &T.runid, &T.isfreq, &T.sample0, &T.sample1, &T.rstate,
-                          &T.cat, &T.wroots, &T.ties})
+                          &T.cat, &T.wroots, &T.ties, &T.mv0, &T.mv1})
     b->release();
   release_implicit_dict();
 }
@@ -2146,7 +2221,8 @@ struct CollectionDict {
   // what k_mask_layout decided, the masks and the crossings range-major (built with the partition table)
   DeviceBuffer sid, sb, woff, minfo, masks, partT;
   uint32_t mask_words_max = 0;
-  bool has_masks = false;
+  bool has_masks = false;             // one owner: built with the dictionary
+  bool lazy_tried = false;            // several owners: built by the first block compare that may walk tiles (k_rank_histogram ...)
   std::vector<uint64_t> rel_off;
 };
 
@@ -2424,6 +2500,11 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
     hipLaunchKernelGGL(k_freq_records, dim3((n + 255) / 256), dim3(256), 0, s, D.hashes, off, n, ds,
                        D.fmask.as<unsigned long long>(), D.fpos.as<uint32_t>());
   }
+  if (G > 1) {
+    D.minfo.ensure(sizeof(MaskInfo));
+    HIP_CHECK(hipMemsetAsync(D.minfo.ptr, 0, sizeof(MaskInfo), s));      // (no masks until a block compare has built them)
+    D.lazy_tried = false;
+  }
   D.part.ensure((size_t)n * (D.R + 1) * 4);    // filled by the first block compare that may take the tiled route
   HIP_CHECK(hipGetLastError());
   D.finished = true;
@@ -2617,7 +2698,37 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     DictState* ds = D.dstate.as<DictState>();
     hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, D.n,
                        D.hbound_ptr, R, D.part.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
-    const bool use_masks = D.has_masks && tune.no_range_masks == 0 && !ex.no_masks;
+    // a sliced dictionary (world > 1) has its masks built here, from the assembled ranks, roots and crossings
+    const bool lazy_masks = D.world > 1 && tune.no_range_masks == 0 && !ex.no_masks && (uint64_t)D.n * R <= (8ull << 20) && D.total > 0;
+    const bool use_masks = (D.has_masks || lazy_masks) && tune.no_range_masks == 0 && !ex.no_masks;
+    if (lazy_masks && !D.lazy_tried) {
+      // (once per dictionary: a later block compare finds the masks, or -- the plan of this one skipped the tiles -- walks)
+      D.lazy_tried = true;
+      const size_t ids = (size_t)D.total + 1;                    // (ranks are below the number of pooled hashes)
+      T.mv0.ensure(ids * 4); T.mv1.ensure(ids * 4);
+      T.cnt.ensure(((size_t)D.n * R + 3 * R + 8) * 4);
+      uint32_t* cnt = T.cnt.as<uint32_t>();
+      uint32_t* fcnt = cnt + (size_t)D.n * R;
+      uint32_t* kmax = fcnt + R;
+      uint32_t* total = kmax + R;
+      D.sid.ensure((size_t)D.total * 2);
+      D.sb.ensure((size_t)(R + 1) * 4); D.woff.ensure((size_t)(R + 2) * 4); D.minfo.ensure(sizeof(MaskInfo));
+      D.mask_words_max = 2 * R + kMaskWordsExtra;
+      HIP_CHECK(hipMemsetAsync(cnt, 0, ((size_t)D.n * R + 2 * R + 4) * 4, s));
+      const uint32_t nt = (uint32_t)D.total;
+      hipLaunchKernelGGL(k_lazy_clear, dim3((unsigned)dev.cu_count() * 8), dim3(256), 0, s, T.mv0.as<uint32_t>(), 0u, (uint64_t)ids,
+                         T.mv1.as<uint32_t>(), kSidNone, (uint64_t)ids, nt, st, &ds->part_built, D.minfo.as<MaskInfo>());
+      const unsigned gb = (unsigned)((D.total + 255) / 256);
+      hipLaunchKernelGGL(k_rank_histogram, dim3(gb), dim3(256), 0, s, D.rank_ptr, nt, T.mv0.as<uint32_t>(), st, &ds->part_built);
+      hipLaunchKernelGGL(k_claim_bits, dim3(gb), dim3(256), 0, s, D.rank_ptr, D.hashes, off, D.part.as<uint32_t>(), D.root_ptr, ds, D.n, R,
+                         nt, T.mv0.as<uint32_t>(), T.mv1.as<uint32_t>(), cnt, fcnt, D.split ? 1u : 0u, st, &ds->part_built);
+      hipLaunchKernelGGL(k_elem_bits, dim3(gb), dim3(256), 0, s, D.rank_ptr, nt, T.mv0.as<uint32_t>(), T.mv1.as<uint32_t>(),
+                         D.sid.as<uint16_t>(), st, &ds->part_built);
+      hipLaunchKernelGGL(k_mask_max_lazy, dim3((unsigned)(((uint64_t)D.n * R + 255) / 256)), dim3(256), 0, s, cnt, (uint64_t)D.n * R, R, kmax,
+                         total, st, &ds->part_built, nt);
+      hipLaunchKernelGGL(k_mask_layout, dim3(1), dim3(1024), 0, s, kmax, fcnt, total, R, D.mask_words_max, D.sb.as<uint32_t>(),
+                         D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>(), st, &ds->part_built, nt);
+    }
     if (use_masks) {
       D.masks.ensure((size_t)D.n * D.mask_words_max * 8);
       D.partT.ensure((size_t)D.n * (R + 1) * 4);
