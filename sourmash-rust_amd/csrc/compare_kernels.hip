@@ -405,6 +405,15 @@ struct PlanState {
   uint32_t pf_after_halving;     // ... tiles in which a table was built from PREFETCHED boundary crossings after such a rebuild
   uint32_t bad_tables;           // a segment that would end before it starts (never, unless a table was built from crossings of the wrong boundary)
 };
+// Workgroups are dealt to the 8 XCDs round-robin.  A kernel that goes through the SORTED positions and touches arrays in
+// collection order (by origin) touches, at any time, one line per sketch -- consecutive elements of a sketch are ~n sorted
+// positions apart -- and every such line is touched again by the positions that follow.  Give every XCD ONE contiguous
+// stretch of the sorted positions and those lines are completed inside its own L2 instead of travelling to memory in
+// pieces from all eight.
+__device__ __forceinline__ uint32_t xcd_chunked_block() {
+  const uint32_t b = blockIdx.x, per = gridDim.x >> 3;
+  return b < per * 8u ? (b & 7u) * per + (b >> 3) : b;
+}
 // What the owner of one slice of hash space finds in it (see "collection dictionary" below)
 struct RangeState {
   uint32_t nruns;                // distinct hashes of the slice (local dense ranks)
@@ -414,6 +423,8 @@ struct RangeState {
   uint32_t overflow;             // the four-pass sort gave up (keys that tie in the sorted bits and could not be put in order by
                                  // k_tie_fix / k_tie_sort): the slice is built again with all eight passes
   uint32_t sort_shift;           // the four-pass sort: its lowest bit (k_key_span)
+  uint32_t span_done;            // k_key_span: workgroups that have added their part
+  unsigned long long span_or;    // k_key_span: OR of (segment end ^ one reference key): its highest bit is the highest bit that varies
 };
 constexpr uint32_t kMaxFreq = 64;
 
@@ -1312,38 +1323,30 @@ __device__ __forceinline__ uint32_t bk_seg(const BkSeg& g, uint32_t s) { return 
 // their original order; the lane at the head of a group of at most 4 sorts it in registers, runs of EQUAL keys need nothing,
 // and a longer group that is out of order raises rs->overflow -- the slice is then sorted again with all eight passes
 // (never seen on hashed keys; keys crafted to differ only in their low bits pay for it).
-__global__ __launch_bounds__(1024) void k_key_span(const uint64_t* __restrict__ keys, BkSeg seg, uint32_t nsk, RangeState* rs) {
-  __shared__ unsigned long long red[2][16];
-  const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-  unsigned long long mn = ~0ull, mx = 0ull;
-  for (uint32_t s0 = 0; s0 < nsk; s0 += 8 * 1024) {      // a segment is sorted: its ends are its extremes
-    // (eight sketches per lane and turn, every load of a turn in flight before the first is used)
-    uint32_t a[8], b[8];
-    unsigned long long ka[8], kb[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t s = s0 + (uint32_t)j * 1024 + t;
-      a[j] = s < nsk ? bk_seg(seg, s) : 0u;
-      b[j] = s < nsk ? bk_seg(seg, s + 1) : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      ka[j] = b[j] > a[j] ? keys[a[j]] : ~0ull;
-      kb[j] = b[j] > a[j] ? keys[b[j] - 1] : 0ull;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) { mn = min(mn, ka[j]); mx = max(mx, kb[j]); }
+// A segment (sketch) is sorted, so its two ends are its extremes, and the highest bit in which ANY two keys of the slice
+// differ is the highest bit of OR(end ^ reference) over all segment ends.  A lane per sketch; the last workgroup to finish
+// turns the OR into the shift.  (One workgroup looping over 10 000 sketches took 47 us: two dependent loads per turn, most of
+// them TLB misses in a 160 MB array.)
+__global__ __launch_bounds__(256) void k_key_span(const uint64_t* __restrict__ keys, BkSeg seg, uint32_t nsk, uint32_t n, RangeState* rs) {
+  const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long d = 0ull;
+  if (sidx < nsk) {
+    const uint32_t a = bk_seg(seg, sidx), b = bk_seg(seg, sidx + 1);
+    if (b > a) { const unsigned long long ref = keys[n - 1]; d = (keys[a] ^ ref) | (keys[b - 1] ^ ref); }
   }
-  for (int off = 32; off; off >>= 1) {
-    mn = min(mn, (unsigned long long)__shfl_xor(mn, off));
-    mx = max(mx, (unsigned long long)__shfl_xor(mx, off));
-  }
-  if (lane == 0) { red[0][w] = mn; red[1][w] = mx; }
+  for (int off = 32; off; off >>= 1) d |= (unsigned long long)__shfl_xor(d, off);
+  __shared__ unsigned long long red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
   __syncthreads();
-  if (t == 0) {
-    for (int ww = 0; ww < 16; ww++) { mn = min(mn, red[0][ww]); mx = max(mx, red[1][ww]); }
-    const uint32_t hb = (mx > mn) ? 64u - (uint32_t)__builtin_clzll(mn ^ mx) : 0u;    // bits below the common prefix
-    rs->sort_shift = hb > 32u ? hb - 32u : 0u;
+  if (threadIdx.x == 0) {
+    d = red[0] | red[1] | red[2] | red[3];
+    if (d) atomicOr(&rs->span_or, d);
+    __threadfence();
+    if (atomicAdd(&rs->span_done, 1u) == gridDim.x - 1) {
+      const unsigned long long all = __hip_atomic_load(&rs->span_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t hb = all ? 64u - (uint32_t)__builtin_clzll(all) : 0u;    // bits below the common prefix
+      rs->sort_shift = hb > 32u ? hb - 32u : 0u;
+    }
   }
 }
 // first / one-past-last sorted position whose key has the bits above `sh` of `p`
@@ -1524,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_shared_bits(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_rank_bit_scatter(const uint32_t* __restrict__ runid, const uint32_t* __restrict__ origin,
                                                           const uint32_t* __restrict__ runbit, uint32_t n, uint32_t* __restrict__ rank,
                                                           uint16_t* __restrict__ ebit) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = xcd_chunked_block() * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t run = runid[i], o = origin[i], b = runbit[run];
   rank[o] = run;
@@ -1783,22 +1786,50 @@ __global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
 // connects nearly everything; the later launches (fresh caches) look at more pairs with ORDINARY
 // cached loads first -- a stale parent word still names an ancestor, so equal roots in a cached
 // view prove the two are connected -- and only the few that are not go to the atomic path.
+// Position i-1's sketch and parent are what the lane to the left has just loaded for ITS position (Shift == 0): a lane
+// gathers one sketch id and one parent word instead of two of each -- the kernel is bound by the number of scattered lines
+// its loads touch (one line per lane and cycle per CU), not by their bytes.
 template <int Shift, bool Filter>
 __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
                                                  const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent,
                                                  const uint32_t* __restrict__ runid, const uint8_t* __restrict__ isfreq) {
-  uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) << Shift;
-  if (i == 0 || i >= n) return;
-  if (keys[i] != keys[i - 1]) return;
-  if (isfreq && isfreq[runid[i]]) return;   // a frequent hash connects nothing (see "frequent hashes" below)
-  uint32_t a = node[origin[i]], b = node[origin[i - 1]];
-  if (a == b) return;
-  if (Filter) {
-    for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[a]; if (p == a) break; a = p; }
-    for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[b]; if (p == b) break; b = p; }
+  const uint64_t i = ((uint64_t)xcd_chunked_block() * blockDim.x + threadIdx.x) << Shift;
+  const bool in = i < n;                                  // (whole waves stay for the shuffles)
+  const int lane = threadIdx.x & 63;
+  const uint64_t k0 = in ? keys[i] : 0ull;
+  bool eq = in && i != 0 && keys[i - 1] == k0;
+  if (eq && isfreq && isfreq[runid[i]]) eq = false;       // a frequent hash connects nothing (see "frequent hashes" below)
+  uint32_t a, b;
+  if (Shift == 0) {
+    const uint64_t want = __ballot(eq);                   // my own sketch is wanted by me or by the lane to my right
+    const bool load = eq || ((want >> 1) >> lane) & 1ull;
+    a = load ? node[origin[i]] : 0u;
+    b = (uint32_t)__shfl_up((int)a, 1);
+    if (eq && lane == 0) b = node[origin[i - 1]];
+    eq = eq && a != b;
+    if (Filter) {
+      const uint64_t want2 = __ballot(eq);
+      const bool load2 = eq || ((want2 >> 1) >> lane) & 1ull;
+      uint32_t pa = load2 ? parent[a] : a;
+      uint32_t pb = (uint32_t)__shfl_up((int)pa, 1);
+      if (eq) {
+        if (lane == 0) pb = parent[b];
+        for (int hop = 0; hop < 64 && pa != a; hop++) { a = pa; pa = parent[a]; }
+        for (int hop = 0; hop < 64 && pb != b; hop++) { b = pb; pb = parent[b]; }
+        if (a == b) eq = false;
+      }
+    }
+  } else {
+    if (!eq) return;
+    a = node[origin[i]]; b = node[origin[i - 1]];
     if (a == b) return;
+    if (Filter) {
+      for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[a]; if (p == a) break; a = p; }
+      for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[b]; if (p == b) break; b = p; }
+      if (a == b) return;
+    }
   }
-  uf_union(parent, a, b);
+  if (eq) uf_union(parent, a, b);
 }
 // The first sample of the neighbour pairs for a collection of at most kUfLdsNodes sketches: ONE workgroup, the forest in
 // LDS.  The unions of related sketches all meet at the same few parent words; in LDS that contention costs nanoseconds,
@@ -1843,7 +1874,12 @@ __global__ __launch_bounds__(256) void k_uf_merge(const uint8_t* __restrict__ ga
   if (t >= (uint64_t)G * nsk) return;
   const uint32_t g = (uint32_t)(t / nsk), i = (uint32_t)(t % nsk);
   const uint32_t r = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * share_bytes + roots_at)[i];
-  if (r != i) uf_union(parent, i, r);
+  if (r == i) return;
+  // the forest before this one names the same root for i: its lane does this very union (related sketches have the same
+  // root -- their smallest index -- in nearly every forest, and all those unions would queue at that root's word: 37
+  // forests of one family of 10 000 took 200 us here)
+  if (g && reinterpret_cast<const uint32_t*>(gathered + (size_t)(g - 1) * share_bytes + roots_at)[i] == r) return;
+  uf_union(parent, i, r);
 }
 __global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, uint32_t* __restrict__ root) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2316,15 +2352,15 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     const uint32_t* shift_dev = D.force_radix ? nullptr : &rs->sort_shift;
     if (G == 1) {
       hipLaunchKernelGGL(k_whole_nodes, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, off, n, nm, T.node.as<uint32_t>(), T.parent.as<uint32_t>());
-      if (shift_dev) hipLaunchKernelGGL(k_key_span, dim3(1), dim3(1024), 0, s, D.hashes, BkSeg{off, nullptr}, n, rs);
+      if (shift_dev) hipLaunchKernelGGL(k_key_span, dim3((n + 255) / 256), dim3(256), 0, s, D.hashes, BkSeg{off, nullptr}, n, nm, rs);
       cur = radix_sort_u64_place(D.hashes, T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
                                  dev.scratch, s, mask, shift_dev);
     } else {
       hipLaunchKernelGGL(k_slice_gather, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
                          D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>(), T.parent.as<uint32_t>());
       if (shift_dev)
-        hipLaunchKernelGGL(k_key_span, dim3(1), dim3(1024), 0, s, T.keys0.as<uint64_t>(),
-                           BkSeg{nullptr, D.segoff.as<uint32_t>() + (size_t)rank * (n + 1)}, n, rs);
+        hipLaunchKernelGGL(k_key_span, dim3((n + 255) / 256), dim3(256), 0, s, T.keys0.as<uint64_t>(),
+                           BkSeg{nullptr, D.segoff.as<uint32_t>() + (size_t)rank * (n + 1)}, n, nm, rs);
       // (the first pass reads keys0 and writes keys1: keys0 is input and work buffer at once)
       cur = radix_sort_u64_place(T.keys0.as<uint64_t>(), T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(),
                                  T.org1.as<uint32_t>(), nm, dev.scratch, s, mask, shift_dev);

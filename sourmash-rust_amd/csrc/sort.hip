@@ -411,19 +411,23 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
   __shared__ uint32_t wcnt[kRleItems * NW];
   __shared__ uint32_t before_all[NW];
   if (skip && *skip) return;
+  // (with the scatter by origin: every XCD takes one contiguous stretch of the tiles, so that the lines of rank_out -- one
+  // per sketch at any time, revisited by the tiles that follow -- are completed inside its L2; workgroups go to the XCDs round-robin)
+  uint32_t bx = blockIdx.x;
+  if (rank_out) { const uint32_t per = gridDim.x >> 3; if (bx < per * 8u) bx = (bx & 7u) * per + (bx >> 3); }
   // self_sum_blocks != 0: bscan holds the blocks' head COUNTS, not their scan -- a few thousand of them at most: every
   // workgroup adds up the ones before its own (two launches less than scanning them first), the last one also the total
   uint32_t mine_before = 0;
   if (self_sum_blocks) {
     uint32_t acc = 0;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kRleThreads) acc += bscan[i];
+    for (uint32_t i = threadIdx.x; i < bx; i += kRleThreads) acc += bscan[i];
     for (int off = 32; off; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) before_all[threadIdx.x >> 6] = acc;
     __syncthreads();
     for (int i = 0; i < NW; i++) mine_before += before_all[i];
-    if (nruns_out && blockIdx.x + 1 == self_sum_blocks && threadIdx.x == 0) *nruns_out = mine_before + bscan[blockIdx.x];
+    if (nruns_out && bx + 1 == self_sum_blocks && threadIdx.x == 0) *nruns_out = mine_before + bscan[bx];
   }
-  const size_t tile0 = (size_t)blockIdx.x * kRleTile;
+  const size_t tile0 = (size_t)bx * kRleTile;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
   uint64_t k[kRleItems];
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
     if (threadIdx.x < kRleItems * NW) wcnt[threadIdx.x] = incl - v;
   }
   __syncthreads();
-  const uint32_t o0 = self_sum_blocks ? mine_before : bscan[blockIdx.x];
+  const uint32_t o0 = self_sum_blocks ? mine_before : bscan[bx];
 #pragma unroll
   for (int i = 0; i < kRleItems; i++) {
     const size_t idx = tile0 + (size_t)i * kRleThreads + threadIdx.x;
