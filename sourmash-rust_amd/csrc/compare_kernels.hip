@@ -1838,6 +1838,17 @@ constexpr uint32_t kUfLdsNodes = 16384;
 // Several workgroups: each takes every gridDim.x-th sampled pair, builds a forest of its own in LDS and leaves every
 // sketch's root in its row of `out` ([gridDim.x][nsk]); k_uf_merge then unites the forests (nsk unions per workgroup, most
 // of them between sketches the earlier forests have connected already).
+// (find with path halving, like uf_find: without it a forest that has taken many unions is walked hop by hop -- sixteen
+// positions per lane took 15 us per union)
+__device__ __forceinline__ uint32_t lds_uf_find(uint32_t* lpar, uint32_t x) {
+  uint32_t p = __hip_atomic_load(&lpar[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (p != x) {
+    const uint32_t gp = __hip_atomic_load(&lpar[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gp != p) __hip_atomic_store(&lpar[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // gp is an ancestor of x
+    x = p; p = gp;
+  }
+  return x;
+}
 template <int Shift>
 __global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
                                                       const uint32_t* __restrict__ node, uint64_t n, uint32_t nsk, uint32_t* __restrict__ out,
@@ -1845,18 +1856,43 @@ __global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict
   extern __shared__ uint32_t lpar[];
   for (uint32_t i = threadIdx.x; i < nsk; i += 1024) lpar[i] = i;
   __syncthreads();
-  for (uint64_t t = (uint64_t)blockIdx.x * 1024 + threadIdx.x + 1; (t << Shift) < n; t += (uint64_t)gridDim.x * 1024) {
-    const uint64_t i = t << Shift;
-    if (keys[i] != keys[i - 1]) continue;
-    if (isfreq && isfreq[runid[i]]) continue;
-    uint32_t x = node[origin[i]], y = node[origin[i - 1]];
-    while (true) {
-      // (relaxed workgroup-scope loads: other lanes are changing the forest)
-      while (true) { const uint32_t p = __hip_atomic_load(&lpar[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p == x) break; x = p; }
-      while (true) { const uint32_t p = __hip_atomic_load(&lpar[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (p == y) break; y = p; }
-      if (x == y) break;
-      if (x > y) { const uint32_t s = x; x = y; y = s; }
-      if (atomicCAS(&lpar[y], y, x) == y) break;      // the larger root goes under the smaller
+  // Eight sampled positions per lane and turn, every load of a step issued for all eight before the first is used: a
+  // position is a chain of three dependent loads (keys, origin, sketch), and one workgroup has to cover their latency itself
+  // (a lane's turns -- two at ~2 K positions per forest -- then cost as much as one).
+  const uint64_t stride = (uint64_t)gridDim.x * 1024;
+  for (uint64_t t0 = (uint64_t)blockIdx.x * 1024 + threadIdx.x + 1; (t0 << Shift) < n; t0 += stride * 8) {
+    uint64_t idx[8], k0[8], k1[8];
+    bool eq[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      idx[j] = (t0 + (uint64_t)j * stride) << Shift;
+      eq[j] = idx[j] < n;
+      if (!eq[j]) idx[j] = 1;                             // (t0 >= 1 and (t0 << Shift) < n: position 1 exists)
+      k0[j] = keys[idx[j]]; k1[j] = keys[idx[j] - 1];
+    }
+    uint32_t rid[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { eq[j] = eq[j] && k0[j] == k1[j]; rid[j] = (isfreq && eq[j]) ? runid[idx[j]] : 0u; }
+    if (isfreq) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (eq[j] && isfreq[rid[j]]) eq[j] = false;
+    }
+    uint32_t oa[8], ob[8], xs[8], ys[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { oa[j] = eq[j] ? origin[idx[j]] : 0u; ob[j] = eq[j] ? origin[idx[j] - 1] : 0u; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { xs[j] = eq[j] ? node[oa[j]] : 0u; ys[j] = eq[j] ? node[ob[j]] : 0u; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (!eq[j]) continue;
+      uint32_t x = xs[j], y = ys[j];
+      while (true) {
+        // (relaxed workgroup-scope loads: other lanes are changing the forest)
+        x = lds_uf_find(lpar, x); y = lds_uf_find(lpar, y);
+        if (x == y) break;
+        if (x > y) { const uint32_t sw = x; x = y; y = sw; }
+        if (atomicCAS(&lpar[y], y, x) == y) break;      // the larger root goes under the smaller
+      }
     }
   }
   __syncthreads();
@@ -1879,7 +1915,13 @@ __global__ __launch_bounds__(256) void k_uf_merge(const uint8_t* __restrict__ ga
   // root -- their smallest index -- in nearly every forest, and all those unions would queue at that root's word: 37
   // forests of one family of 10 000 took 200 us here)
   if (g && reinterpret_cast<const uint32_t*>(gathered + (size_t)(g - 1) * share_bytes + roots_at)[i] == r) return;
-  uf_union(parent, i, r);
+  // an ordinary (cached) look first: a stale parent word still names an ancestor, so equal roots in this view prove the two
+  // are connected already -- by a forest whose unions ran earlier in this launch
+  uint32_t a = i, b = r;
+  for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[a]; if (p == a) break; a = p; }
+  for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[b]; if (p == b) break; b = p; }
+  if (a == b) return;
+  uf_union(parent, a, b);
 }
 __global__ __launch_bounds__(256) void k_uf_roots(uint32_t* parent, uint32_t m, uint32_t* __restrict__ root) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2406,7 +2448,8 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       // (one rank's slice of the dense 10 000-sketch collection at 1/64: 207 us there), what they see costs LDS time
       int shift = 8;
       while (shift > 4 && ((uint64_t)nm >> shift) < 6ull * n) shift--;
-      // (~2 K sampled pairs per forest: a lane's pairs are chains of dependent loads, two of them take as long as one)
+      // (~2 K sampled positions per forest, two per lane: a forest is built by ONE CU, whose loads touch a line per lane and
+      // cycle -- 16 K positions per forest took 120-240 us)
       const uint32_t W = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)nm >> shift) / 2048));
       T.wroots.ensure((size_t)W * n * 4);
 #define SMH_UF(S_)                                                                                                            \
