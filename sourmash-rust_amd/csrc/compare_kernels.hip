@@ -1663,33 +1663,22 @@ __global__ void k_dict_state(const uint8_t* __restrict__ gathered, uint64_t shar
 // sketches from those: how often every rank occurs (a histogram: 20 M atomic adds on ~10 M words), then ONE element of
 // every rank that occurs twice or more claims the rank's bit (atomicCAS), takes it from the counter of its (component,
 // range) -- the range by a search of its sketch's crossings -- and every element reads its rank's bit.
-__global__ __launch_bounds__(256) void k_lazy_clear(uint32_t* __restrict__ a, uint32_t va, uint64_t na, uint32_t* __restrict__ b, uint32_t vb,
-                                                    uint64_t nb, uint32_t n, const PlanState* __restrict__ st,
-                                                    const uint32_t* __restrict__ built, MaskInfo* __restrict__ info) {
-  if (!lazy_go(st, built, n)) return;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) a[i] = va;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = vb;
-  (void)info;
-}
-__global__ __launch_bounds__(256) void k_rank_histogram(const uint32_t* __restrict__ rank, uint32_t n, uint32_t* __restrict__ cntv,
-                                                        const PlanState* __restrict__ st, const uint32_t* __restrict__ built) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n || !lazy_go(st, built, n)) return;
-  atomicAdd(&cntv[rank[t]], 1u);
-}
-constexpr uint32_t kBitClaimed = 0xfffffffeu;
+constexpr uint16_t kEbitShared = 0xfffeu, kEbitHead = 0xfffdu;   // (an element's state before its bit is known; 0xffff: no bit)
+// Masks of a sliced dictionary, built from the assembled ranks.  The owners of the slices have told, with every rank, whether
+// its hash is held more than once and which element is the first of its run (k_rle_write's rank flags, unpacked into ebit by
+// k_reassemble): the FIRST element of every shared hash hands out the bit (one atomic per shared hash on the counter of its
+// (component, range); frequent hashes number themselves per range), every other element reads it.  Two passes over the
+// pooled hashes.  (First version: a histogram of the ranks and a CAS per element to elect the one that claims -- 40 M atomics
+// at random addresses, 2.2 ms at 20 M hashes.)
 __global__ __launch_bounds__(256) void k_claim_bits(const uint32_t* __restrict__ rank, const uint64_t* __restrict__ hashes,
                                                     const uint64_t* __restrict__ off, const uint32_t* __restrict__ part,
                                                     const uint32_t* __restrict__ roots, const DictState* __restrict__ ds, uint32_t nsk,
-                                                    uint32_t R, uint32_t n, const uint32_t* __restrict__ cntv, uint32_t* __restrict__ bitof,
+                                                    uint32_t R, uint32_t n, const uint16_t* __restrict__ ebit, uint32_t* __restrict__ bitof,
                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ fcnt, uint32_t split,
                                                     const PlanState* __restrict__ st, const uint32_t* __restrict__ built) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n || !lazy_go(st, built, n)) return;
-  const uint32_t id = rank[t];
-  if (cntv[id] < 2u) return;
-  if (atomicCAS(&bitof[id], kSidNone, kBitClaimed) != kSidNone) return;       // another element of this rank does it
+  if (ebit[t] != kEbitHead) return;
   // my sketch (last s with off[s] <= t), my place in it, the range that place falls into (last r with part[s][r] <= place)
   uint32_t lo = 0, hi = nsk;
   while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
@@ -1704,17 +1693,16 @@ __global__ __launch_bounds__(256) void k_claim_bits(const uint32_t* __restrict__
     const uint32_t nf = ds->nfreq;
     for (uint32_t k = 0; k < nf; k++) freq = freq || ds->freq_hash[k] == h;
   }
-  bitof[id] = freq ? (atomicAdd(&fcnt[r], 1u) | 0x80000000u) : atomicAdd(&cnt[(size_t)roots[sk] * R + r], 1u);
+  bitof[rank[t]] = freq ? (atomicAdd(&fcnt[r], 1u) | 0x80000000u) : atomicAdd(&cnt[(size_t)roots[sk] * R + r], 1u);
 }
-__global__ __launch_bounds__(256) void k_elem_bits(const uint32_t* __restrict__ rank, uint32_t n, const uint32_t* __restrict__ cntv,
-                                                   const uint32_t* __restrict__ bitof, uint16_t* __restrict__ ebit,
-                                                   const PlanState* __restrict__ st, const uint32_t* __restrict__ built) {
+__global__ __launch_bounds__(256) void k_elem_bits(const uint32_t* __restrict__ rank, uint32_t n, const uint32_t* __restrict__ bitof,
+                                                   uint16_t* __restrict__ ebit, const PlanState* __restrict__ st,
+                                                   const uint32_t* __restrict__ built) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n || !lazy_go(st, built, n)) return;
-  const uint32_t id = rank[t];
-  uint32_t b = kSidNone;
-  if (cntv[id] >= 2u) b = bitof[id];
-  ebit[t] = b == kSidNone ? (uint16_t)0xffffu : (uint16_t)((b & 0x7fffu) | ((b >> 31) << 15));
+  if (ebit[t] == (uint16_t)0xffffu) return;
+  const uint32_t b = bitof[rank[t]];
+  ebit[t] = (uint16_t)((b & 0x7fffu) | ((b >> 31) << 15));
 }
 // (the two single-launch steps of the layout, for the lazily built masks: nothing when the plan skips the tiles or they exist)
 __global__ __launch_bounds__(256) void k_mask_max_lazy(const uint32_t* __restrict__ cnt, uint64_t m, uint32_t R, uint32_t* __restrict__ kmax,
@@ -1730,7 +1718,8 @@ __global__ __launch_bounds__(256) void k_mask_max_lazy(const uint32_t* __restric
 __global__ __launch_bounds__(256) void k_reassemble(const uint64_t* __restrict__ off, uint32_t nsk,
                                                     const uint32_t* __restrict__ spart, uint32_t G, const uint32_t* __restrict__ segoff,
                                                     const uint8_t* __restrict__ gathered, uint64_t share_bytes, uint64_t ranks_at,
-                                                    const DictState* __restrict__ ds, uint32_t* __restrict__ rank) {
+                                                    const DictState* __restrict__ ds, uint32_t* __restrict__ rank, uint32_t flags,
+                                                    uint16_t* __restrict__ eflag) {
   __shared__ uint32_t sp[65], so[64], rb[64];
   for (uint32_t s = blockIdx.x; s < nsk; s += gridDim.x) {
     __syncthreads();
@@ -1743,7 +1732,10 @@ __global__ __launch_bounds__(256) void k_reassemble(const uint64_t* __restrict__
       uint32_t g = 0;
       while (g + 1 < G && sp[g + 1] <= p) g++;     // last g with sp[g] <= p
       const uint32_t* seg = reinterpret_cast<const uint32_t*>(gathered + (size_t)g * share_bytes + ranks_at);
-      rank[base + p] = rb[g] + seg[so[g] + (p - sp[g])];
+      const uint32_t w = seg[so[g] + (p - sp[g])];
+      rank[base + p] = rb[g] + (flags ? (w & 0x3fffffffu) : w);
+      // (what k_claim_bits / k_elem_bits start from: not shared / shared / shared and the first of its run)
+      if (eflag) eflag[base + p] = (w >> 31) ? (((w >> 30) & 1u) ? kEbitHead : kEbitShared) : (uint16_t)0xffffu;
     }
   }
 }
@@ -2300,7 +2292,9 @@ struct CollectionDict {
   DeviceBuffer sid, sb, woff, minfo, masks, partT;
   uint32_t mask_words_max = 0;
   bool has_masks = false;             // one owner: built with the dictionary
-  bool lazy_tried = false;            // several owners: built by the first block compare that may walk tiles (k_rank_histogram ...)
+  bool lazy_tried = false;            // several owners: built by the first block compare that may walk tiles (k_claim_bits ...)
+  bool lazy_ready = false;            // several owners: the elements' states are in sid (k_reassemble): masks can be built on demand
+  bool share_flags = false;           // several owners: the shares' ranks carry "shared" / "first of its run" in bits 31 / 30
   std::vector<uint64_t> rel_off;
 };
 
@@ -2421,9 +2415,12 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   // (with the ranks: rank[origin[i]] = run of sorted position i goes out with the runs -- unless the range masks are built:
   // then the ranks leave together with the elements' bits, further down)
   D.has_masks = G == 1 && nm > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
+  // (several owners: every rank leaves with two flags -- its hash is held more than once; it is the first of its run -- so that
+  // whoever assembles the ranks can hand out the range masks' bits without counting; same decision on every owner)
+  D.share_flags = G > 1 && D.total < (1ull << 30);
   run_length_encode_u64_async(sk, nm, T.uniq.as<uint64_t>(), T.starts.as<uint32_t>(), dev.scratch, s, D.has_masks ? nullptr : so,
                               D.has_masks ? nullptr : reinterpret_cast<uint32_t*>(share + D.ranks_at), &rs->nruns, nullptr,
-                              T.runid.as<uint32_t>());
+                              T.runid.as<uint32_t>(), D.share_flags);
   // ---- frequent hashes: held by more than a quarter of the sketches (at least 16) -- see k_freq_mark
   const uint8_t* isfreq = nullptr;
   if (D.split && nm) {
@@ -2556,9 +2553,13 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
   } else {
     // ranks of every element, in collection order
     D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4);
+    // (with the flags of the shares, and if range masks may be wanted: the elements' states for k_claim_bits)
+    D.lazy_ready = D.share_flags && D.total > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
+    if (D.lazy_ready) D.sid.ensure((size_t)D.total * 2);
     if (D.total)
       hipLaunchKernelGGL(k_reassemble, dim3(std::min<uint32_t>(n, 65536)), dim3(256), 0, s, off, n, D.spart.as<uint32_t>(), G,
-                         D.segoff.as<uint32_t>(), gathered, D.share_bytes, D.ranks_at, ds, D.rankv.as<uint32_t>());
+                         D.segoff.as<uint32_t>(), gathered, D.share_bytes, D.ranks_at, ds, D.rankv.as<uint32_t>(), D.share_flags ? 1u : 0u,
+                         D.lazy_ready ? D.sid.as<uint16_t>() : (uint16_t*)nullptr);
     // components: the slices' forests united
     T.parent.ensure((size_t)n * 4);
     D.root.ensure((size_t)n * 4);
@@ -2778,31 +2779,27 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
     hipLaunchKernelGGL(k_partition, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.hashes, off, D.n,
                        D.hbound_ptr, R, D.part.as<uint32_t>(), &st->skip_tiled, &ds->part_built);
     // a sliced dictionary (world > 1) has its masks built here, from the assembled ranks, roots and crossings
-    const bool lazy_masks = D.world > 1 && tune.no_range_masks == 0 && !ex.no_masks && (uint64_t)D.n * R <= (8ull << 20) && D.total > 0;
+    const bool lazy_masks = D.world > 1 && D.lazy_ready && tune.no_range_masks == 0 && !ex.no_masks;
     const bool use_masks = (D.has_masks || lazy_masks) && tune.no_range_masks == 0 && !ex.no_masks;
     if (lazy_masks && !D.lazy_tried) {
       // (once per dictionary: a later block compare finds the masks, or -- the plan of this one skipped the tiles -- walks)
       D.lazy_tried = true;
       const size_t ids = (size_t)D.total + 1;                    // (ranks are below the number of pooled hashes)
-      T.mv0.ensure(ids * 4); T.mv1.ensure(ids * 4);
+      T.mv1.ensure(ids * 4);
       T.cnt.ensure(((size_t)D.n * R + 3 * R + 8) * 4);
       uint32_t* cnt = T.cnt.as<uint32_t>();
       uint32_t* fcnt = cnt + (size_t)D.n * R;
       uint32_t* kmax = fcnt + R;
       uint32_t* total = kmax + R;
-      D.sid.ensure((size_t)D.total * 2);
       D.sb.ensure((size_t)(R + 1) * 4); D.woff.ensure((size_t)(R + 2) * 4); D.minfo.ensure(sizeof(MaskInfo));
       D.mask_words_max = 2 * R + kMaskWordsExtra;
       HIP_CHECK(hipMemsetAsync(cnt, 0, ((size_t)D.n * R + 2 * R + 4) * 4, s));
       const uint32_t nt = (uint32_t)D.total;
-      hipLaunchKernelGGL(k_lazy_clear, dim3((unsigned)dev.cu_count() * 8), dim3(256), 0, s, T.mv0.as<uint32_t>(), 0u, (uint64_t)ids,
-                         T.mv1.as<uint32_t>(), kSidNone, (uint64_t)ids, nt, st, &ds->part_built, D.minfo.as<MaskInfo>());
       const unsigned gb = (unsigned)((D.total + 255) / 256);
-      hipLaunchKernelGGL(k_rank_histogram, dim3(gb), dim3(256), 0, s, D.rank_ptr, nt, T.mv0.as<uint32_t>(), st, &ds->part_built);
       hipLaunchKernelGGL(k_claim_bits, dim3(gb), dim3(256), 0, s, D.rank_ptr, D.hashes, off, D.part.as<uint32_t>(), D.root_ptr, ds, D.n, R,
-                         nt, T.mv0.as<uint32_t>(), T.mv1.as<uint32_t>(), cnt, fcnt, D.split ? 1u : 0u, st, &ds->part_built);
-      hipLaunchKernelGGL(k_elem_bits, dim3(gb), dim3(256), 0, s, D.rank_ptr, nt, T.mv0.as<uint32_t>(), T.mv1.as<uint32_t>(),
-                         D.sid.as<uint16_t>(), st, &ds->part_built);
+                         nt, D.sid.as<uint16_t>(), T.mv1.as<uint32_t>(), cnt, fcnt, D.split ? 1u : 0u, st, &ds->part_built);
+      hipLaunchKernelGGL(k_elem_bits, dim3(gb), dim3(256), 0, s, D.rank_ptr, nt, T.mv1.as<uint32_t>(), D.sid.as<uint16_t>(), st,
+                         &ds->part_built);
       hipLaunchKernelGGL(k_mask_max_lazy, dim3((unsigned)(((uint64_t)D.n * R + 255) / 256)), dim3(256), 0, s, cnt, (uint64_t)D.n * R, R, kmax,
                          total, st, &ds->part_built, nt);
       hipLaunchKernelGGL(k_mask_layout, dim3(1), dim3(1024), 0, s, kmax, fcnt, total, R, D.mask_words_max, D.sb.as<uint32_t>(),

@@ -127,7 +127,8 @@ int radix_sort_u64_place(const uint64_t* keys, uint64_t* k0, uint64_t* k1, uint3
 // skip (device, nullable): non-zero = the launches do nothing
 void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
                                  hipStream_t s, const uint32_t* origin, uint32_t* rank_out, uint32_t* nruns_dev,
-                                 const uint32_t* skip, uint32_t* runid_out = nullptr);   // runid_out[i] = run of sorted position i
+                                 const uint32_t* skip, uint32_t* runid_out = nullptr,    // runid_out[i] = run of sorted position i
+                                 bool rank_flags = false);   // rank_out values carry bit 31 = run longer than 1, bit 30 = first of its run
 // in-place exclusive scan of m u32 counters; *total (device, nullable) receives their sum
 void exclusive_scan_u32_dev(uint32_t* d, size_t m, uint32_t* total, DeviceBuffer& scratch, hipStream_t s);
 // unique keys + run start indices of a sorted array; returns the number of runs (syncs).

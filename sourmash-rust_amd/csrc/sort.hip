@@ -405,7 +405,8 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
                                                            uint32_t* __restrict__ rank_out,
                                                            const uint32_t* __restrict__ skip,
                                                            uint32_t* __restrict__ runid_out,
-                                                           uint32_t self_sum_blocks = 0, uint32_t* __restrict__ nruns_out = nullptr) {
+                                                           uint32_t self_sum_blocks = 0, uint32_t* __restrict__ nruns_out = nullptr,
+                                                           uint32_t rank_flags = 0) {
   constexpr int NW = kRleThreads / 64;
   static_assert(kRleItems * NW <= 64, "k_rle_write: one wave scans the per-row, per-wave head counts");
   __shared__ uint32_t wcnt[kRleItems * NW];
@@ -467,7 +468,16 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_write(const uint64_t* __res
       starts[o] = (uint32_t)idx;
     }
     const uint32_t run = o + (head ? 1u : 0u) - 1u;        // the run this item belongs to
-    if (rank_out) rank_out[origin[idx]] = run;
+    if (rank_out) {
+      // rank_flags: bit 31 = the run has more than one element (the hash is shared), bit 30 = this is the run's first element
+      // -- what a later owner of the assembled ranks needs to hand out the range masks' bits without counting anything
+      uint32_t v = run;
+      if (rank_flags) {
+        const bool shared = !head || (idx + 1 < n && keys[idx + 1] == k[i]);
+        v |= (shared ? 0x80000000u : 0u) | (head ? 0x40000000u : 0u);
+      }
+      rank_out[origin[idx]] = v;
+    }
     if (runid_out) runid_out[idx] = run;                   // the same by sorted position
   }
 }
@@ -668,8 +678,9 @@ int radix_sort_u64_keys(uint64_t* k0, uint64_t* k1, size_t n, DeviceBuffer& scra
 // skip (device, nullable): non-zero = do nothing (the caller's device-side plan does not need the result)
 void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq, uint32_t* starts, DeviceBuffer& scratch,
                                  hipStream_t s, const uint32_t* origin, uint32_t* rank_out, uint32_t* nruns_dev,
-                                 const uint32_t* skip, uint32_t* runid_out) {
+                                 const uint32_t* skip, uint32_t* runid_out, bool rank_flags) {
   if (n == 0) { HIP_CHECK(hipMemsetAsync(nruns_dev, 0, 4, s)); return; }
+  if (rank_flags && n >= (1ull << 30)) throw_internal("run_length_encode_u64: rank flags need fewer than 2^30 keys");
   if (n >= (1ull << 31)) throw_internal("run_length_encode_u64: more than 2^31 keys");
   const uint32_t nblocks = (uint32_t)((n + kRleTile - 1) / kRleTile);
   scratch.ensure((size_t)(nblocks + 1 + scan_tmp_entries(nblocks)) * sizeof(uint32_t));
@@ -678,13 +689,13 @@ void run_length_encode_u64_async(const uint64_t* keys, size_t n, uint64_t* uniq,
   if (nblocks <= 4096 && !skip) {
     // (launch-bound sizes: the write kernel adds up the block counts itself and leaves the total -- two launches instead of five)
     hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, (uint64_t*)nullptr, n, bc,
-                       uniq, starts, origin, rank_out, skip, runid_out, nblocks, nruns_dev);
+                       uniq, starts, origin, rank_out, skip, runid_out, nblocks, nruns_dev, rank_flags ? 1u : 0u);
     HIP_CHECK(hipGetLastError());
     return;
   }
   exclusive_scan_u32(bc, nblocks, bc + nblocks, bc + nblocks + 1, s);
   hipLaunchKernelGGL(k_rle_write, dim3(nblocks), dim3(kRleThreads), 0, s, keys, (const uint64_t*)nullptr, 0, (uint64_t*)nullptr, n, bc,
-                     uniq, starts, origin, rank_out, skip, runid_out, 0u, (uint32_t*)nullptr);
+                     uniq, starts, origin, rank_out, skip, runid_out, 0u, (uint32_t*)nullptr, rank_flags ? 1u : 0u);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(nruns_dev, bc + nblocks, sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
 }
