@@ -1544,9 +1544,11 @@ __global__ __launch_bounds__(256) void k_mask_max(const uint32_t* __restrict__ c
 // per range: the words its busiest component needs (wn), the frequent words behind them, the offsets; and whether the masks
 // are worth building.  One workgroup; lane per range for the maximum over the components' counters.
 // (lazy_go: the plan walks tiles, the masks do not exist yet, and there are enough pairs that can share a hash for them to
-// pay -- building them is three passes over all pooled hashes, whatever part of the matrix this owner computes)
+// pay -- building them is two passes over ALL pooled hashes plus the masks themselves, whatever part of the matrix this owner
+// computes: ~0.35 ms at 20 M hashes, against ~0.35 ns saved per pair.  Measured on the 50-family collection: worth it for
+// one rank of two, a wash for one of four or eight.)
 __device__ __forceinline__ bool lazy_go(const PlanState* st, const uint32_t* built, uint32_t n) {
-  return !st->skip_tiled && !*built && st->pairs * 3ull >= (unsigned long long)n;
+  return !st->skip_tiled && !*built && st->pairs * 32ull >= (unsigned long long)n;
 }
 __global__ __launch_bounds__(1024) void k_mask_layout(const uint32_t* __restrict__ kmax, const uint32_t* __restrict__ fcnt,
                                                       const uint32_t* __restrict__ total, uint32_t R, uint32_t wmax,
