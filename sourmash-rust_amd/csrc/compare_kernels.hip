@@ -389,6 +389,16 @@ using LdsU32 = const __attribute__((address_space(3))) uint32_t*;
 
 // What the device-side plan of a block compare decides (see "device-side plan" below); the kernels
 // read it, the host reads it back once, at the end of the call.
+// Read-only data written by EARLIER launches, read with an address that is the same for all lanes: through the constant
+// address space the compiler uses scalar loads (s_load into scalar registers, the scalar cache) instead of vector loads.
+#define SMH_CONSTANT __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const SMH_CONSTANT T* as_constant(const T* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (const SMH_CONSTANT T*)p;
+#pragma clang diagnostic pop
+}
 struct PlanState {
   unsigned long long pairs;      // sum over the components of rows x columns: pairs that CAN share a hash
   unsigned long long ovf_steps;  // tiled: (tile, range) steps that did not fit the LDS stage and merged from global memory
@@ -953,26 +963,50 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     }
     const unsigned long long* mk = ka.masks;
     const uint32_t* pT = ka.partT;
+    // What is the same for all lanes -- the ranges' word offsets, the ROWS' words and crossings -- is read through the scalar
+    // cache into scalar registers (constant address space: written by earlier launches only), the column's words by vector
+    // loads; everything a range needs (up to kMW words per sketch; more: the tail loop) is requested before anything is used.
+    // (First version: every load a vector load followed by its own wait -- ~15 dependent round trips per range.)
+    const SMH_CONSTANT unsigned long long* mkc = as_constant(ka.masks);
+    const SMH_CONSTANT uint32_t* pTc = as_constant(ka.partT);
+    const SMH_CONSTANT uint32_t* woffc = as_constant(ka.woff);
+    const SMH_CONSTANT uint32_t* wnc = as_constant(ka.wn);
+    constexpr int kMW = 3;
+    uint32_t growS[kRowsPerWave];
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) growS[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)grow[q]);
     for (uint32_t r = 0; r < R; r++) {
-      const uint32_t w0 = ka.woff[r], w1 = ka.woff[r + 1], wf = w0 + ka.wn[r];
-      uint32_t prev[kRowsPerWave];                     // matches before this range
+      const uint32_t w0 = woffc[r], w1 = woffc[r + 1], wf = w0 + wnc[r];
+      unsigned long long cw[kMW], rw[kRowsPerWave][kMW];
+      uint32_t pa[kRowsPerWave];
 #pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++) prev[q] = mtot[q];
-      for (uint32_t wi = w0; wi < wf; wi++) {
-        const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
-#pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb) & samec[q];
-      }
-      for (uint32_t wi = wf; wi < w1; wi++) {          // (the range's frequent hashes, if it has any)
-        const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
-#pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mk[(size_t)wi * nsk + grow[q]] & mb);
-      }
+      for (int k = 0; k < kMW; k++) cw[k] = w0 + (uint32_t)k < w1 ? mk[(size_t)(w0 + (uint32_t)k) * nsk + gcol] : 0ull;
       const uint32_t pb = pT[(size_t)(r + 1) * nsk + gcol];
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; q++) {
-        const uint32_t pa = pT[(size_t)(r + 1) * nsk + grow[q]];
-        const uint32_t u = pa + pb - (((self >> q) & 1u) ? pa : mtot[q]);
+#pragma unroll
+        for (int k = 0; k < kMW; k++) rw[q][k] = w0 + (uint32_t)k < w1 ? mkc[(size_t)(w0 + (uint32_t)k) * nsk + growS[q]] : 0ull;
+        pa[q] = pTc[(size_t)(r + 1) * nsk + growS[q]];
+      }
+      uint32_t prev[kRowsPerWave];                     // matches before this range
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) prev[q] = mtot[q];
+#pragma unroll
+      for (int k = 0; k < kMW; k++) {
+        // (a component word counts for pairs of one component only; the range's frequent words, behind them, for every pair)
+        const uint32_t keep = w0 + (uint32_t)k < wf ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(rw[q][k] & cw[k]) & (samec[q] | keep);
+      }
+      for (uint32_t wi = w0 + kMW; wi < w1; wi++) {    // (rare: a range with more words)
+        const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
+        const uint32_t keep = wi < wf ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mkc[(size_t)wi * nsk + growS[q]] & mb) & (samec[q] | keep);
+      }
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) {
+        const uint32_t u = pa[q] + pb - (((self >> q) & 1u) ? pa[q] : mtot[q]);
         if (rstar[q] == R && u >= nq[q]) { rstar[q] = r; ipre[q] = prev[q]; }
       }
       // (count_common not wanted: a wave whose pairs have all found their range needs no more of the totals)
@@ -1008,19 +1042,28 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
           any = true;
         }
       }
+      // (no branch inside a step: the 2 x rows loads of a step are requested together -- an exhausted side or a finished pair
+      // reads element 0 and ignores it -- so a step is ONE round trip; with a branch per row it was one per row)
+      const uint32_t* rr = ka.rrank;
+      const uint32_t* cr = ka.crank;
       while (__any(any)) {
+        uint32_t av[kRowsPerWave], bv[kRowsPerWave];
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) {
+          av[q] = rr[ai[q] < ae[q] ? ai[q] : 0u];
+          bv[q] = cr[bi2[q] < be[q] ? bi2[q] : 0u];
+        }
         any = false;
 #pragma unroll
         for (int q = 0; q < kRowsPerWave; q++) {
-          if (left[q]) {
-            const uint32_t av = ai[q] < ae[q] ? ka.rrank[ai[q]] : kSentA;
-            const uint32_t bv = bi2[q] < be[q] ? ka.crank[bi2[q]] : kSent;
-            mm[q] += av == bv ? 1u : 0u;
-            ai[q] += av <= bv ? 1u : 0u;
-            bi2[q] += bv <= av ? 1u : 0u;
-            left[q] -= 1u;
-            any = any || left[q] != 0;
-          }
+          const uint32_t a1 = ai[q] < ae[q] ? av[q] : kSentA;
+          const uint32_t b1 = bi2[q] < be[q] ? bv[q] : kSent;
+          const uint32_t go = left[q] ? 1u : 0u;
+          mm[q] += (a1 == b1 ? 1u : 0u) & go;
+          ai[q] += (a1 <= b1 ? 1u : 0u) & go;
+          bi2[q] += (b1 <= a1 ? 1u : 0u) & go;
+          left[q] -= go;
+          any = any || left[q] != 0;
         }
       }
 #pragma unroll
