@@ -384,6 +384,8 @@ constexpr int kTB = 64;          // columns per tile (= lanes of a wave); rows p
 // A row's differs from a column's, so that when BOTH sides of a pair are exhausted the walk sees A < B: it keeps stepping
 // over A's padding without finding a match or moving B (the walks look for the end only every 4 steps).
 constexpr uint32_t kSentA = 0x7ffffffeu, kSent = 0x7fffffffu;
+// four consecutive ranks read with one load from ANY element position (dword-aligned; the arrays are padded by 16 bytes)
+struct __attribute__((aligned(4))) Rank4 { uint32_t x, y, z, w; };
 constexpr uint32_t kPad = 4;
 using LdsU32 = const __attribute__((address_space(3))) uint32_t*;
 
@@ -1023,52 +1025,67 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       if ((self >> q) & 1u) mtot[q] = pT[(size_t)R * nsk + grow[q]];
     }
     // ---- the ONE range in which a pair's union reaches its cut is walked by the pair's lane alone, straight from the
-    // rank arrays: ~40 steps of two cached loads each, a wave's rows side by side (independent chains); no stage, no
-    // table, no barrier -- everything before that range is known from the masks.
+    // rank arrays; no stage, no table, no barrier -- everything before that range is known from the masks.  The lanes of a
+    // wave read 64 different places, and a load instruction costs the memory pipe a cycle per lane whatever its width: so a
+    // lane reads FOUR ranks of either side per load (any alignment) and walks four steps out of registers -- the window of a
+    // side is shifted down when its head is consumed -- before it asks again: a quarter of the loads and of the round trips of
+    // an element-by-element walk.  Two rows of the wave at a time (two independent chains; four would not fit the registers).
     {
-      uint32_t ai[kRowsPerWave], ae[kRowsPerWave], bi2[kRowsPerWave], be[kRowsPerWave], left[kRowsPerWave], mm[kRowsPerWave];
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++) {
-        ai[q] = ae[q] = bi2[q] = be[q] = left[q] = mm[q] = 0;
-        if (!((nocut >> q) & 1u)) {
-          const uint32_t row = rowid[w * kRowsPerWave + q], rs = rstar[q];
-          const uint32_t pa = pT[(size_t)rs * nsk + grow[q]], pb = pT[(size_t)rs * nsk + gcol];
-          const uint32_t before = ((self >> q) & 1u) ? pa : ipre[q];
-          ai[q] = (uint32_t)ka.roff[row] + pa; ae[q] = (uint32_t)ka.roff[row] + pT[(size_t)(rs + 1) * nsk + grow[q]];
-          bi2[q] = (uint32_t)ka.coff[col] + pb; be[q] = (uint32_t)ka.coff[col] + pT[(size_t)(rs + 1) * nsk + gcol];
-          left[q] = nq[q] - (pa + pb - before);          // union elements still to go (> 0: the cut lies in this range)
-          mm[q] = before;
-          any = true;
-        }
-      }
-      // (no branch inside a step: the 2 x rows loads of a step are requested together -- an exhausted side or a finished pair
-      // reads element 0 and ignores it -- so a step is ONE round trip; with a branch per row it was one per row)
       const uint32_t* rr = ka.rrank;
       const uint32_t* cr = ka.crank;
-      while (__any(any)) {
-        uint32_t av[kRowsPerWave], bv[kRowsPerWave];
+      constexpr int kPair = kRowsPerWave >= 2 ? 2 : 1;
 #pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) {
-          av[q] = rr[ai[q] < ae[q] ? ai[q] : 0u];
-          bv[q] = cr[bi2[q] < be[q] ? bi2[q] : 0u];
-        }
-        any = false;
+      for (int q0 = 0; q0 < kRowsPerWave; q0 += kPair) {
+        uint32_t ai[kPair], ae[kPair], bi2[kPair], be[kPair], left[kPair], mm[kPair];
+        bool any = false;
 #pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) {
-          const uint32_t a1 = ai[q] < ae[q] ? av[q] : kSentA;
-          const uint32_t b1 = bi2[q] < be[q] ? bv[q] : kSent;
-          const uint32_t go = left[q] ? 1u : 0u;
-          mm[q] += (a1 == b1 ? 1u : 0u) & go;
-          ai[q] += (a1 <= b1 ? 1u : 0u) & go;
-          bi2[q] += (b1 <= a1 ? 1u : 0u) & go;
-          left[q] -= go;
-          any = any || left[q] != 0;
+        for (int j = 0; j < kPair; j++) {
+          const int q = q0 + j;
+          ai[j] = ae[j] = bi2[j] = be[j] = left[j] = mm[j] = 0;
+          if (!((nocut >> q) & 1u)) {
+            const uint32_t row = rowid[w * kRowsPerWave + q], rs = rstar[q];
+            const uint32_t pa = pT[(size_t)rs * nsk + grow[q]], pb = pT[(size_t)rs * nsk + gcol];
+            const uint32_t before = ((self >> q) & 1u) ? pa : ipre[q];
+            ai[j] = (uint32_t)ka.roff[row] + pa; ae[j] = (uint32_t)ka.roff[row] + pT[(size_t)(rs + 1) * nsk + grow[q]];
+            bi2[j] = (uint32_t)ka.coff[col] + pb; be[j] = (uint32_t)ka.coff[col] + pT[(size_t)(rs + 1) * nsk + gcol];
+            left[j] = nq[q] - (pa + pb - before);          // union elements still to go (> 0: the cut lies in this range)
+            mm[j] = before;
+            any = true;
+          }
         }
+        while (__any(any)) {
+          Rank4 va[kPair], vb[kPair];
+#pragma unroll
+          for (int j = 0; j < kPair; j++) {                // (a finished or absent pair reads the first ranks and ignores them)
+            va[j] = *reinterpret_cast<const Rank4*>(rr + (left[j] ? ai[j] : 0u));
+            vb[j] = *reinterpret_cast<const Rank4*>(cr + (left[j] ? bi2[j] : 0u));
+          }
+          any = false;
+#pragma unroll
+          for (int j = 0; j < kPair; j++) {
+            // what lies past the end of a segment is another range's (or sketch's): the side's sentinel instead
+            uint32_t a0 = ai[j] < ae[j] ? va[j].x : kSentA, a1 = ai[j] + 1 < ae[j] ? va[j].y : kSentA;
+            uint32_t a2 = ai[j] + 2 < ae[j] ? va[j].z : kSentA, a3 = ai[j] + 3 < ae[j] ? va[j].w : kSentA;
+            uint32_t b0 = bi2[j] < be[j] ? vb[j].x : kSent, b1 = bi2[j] + 1 < be[j] ? vb[j].y : kSent;
+            uint32_t b2 = bi2[j] + 2 < be[j] ? vb[j].z : kSent, b3 = bi2[j] + 3 < be[j] ? vb[j].w : kSent;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+              const bool go = left[j] != 0;
+              const bool ta = go && a0 <= b0, tb = go && b0 <= a0;      // (both: a match)
+              mm[j] += (ta && tb) ? 1u : 0u;
+              ai[j] += ta ? 1u : 0u;
+              bi2[j] += tb ? 1u : 0u;
+              left[j] -= go ? 1u : 0u;
+              a0 = ta ? a1 : a0; a1 = ta ? a2 : a1; a2 = ta ? a3 : a2; a3 = ta ? kSentA : a3;
+              b0 = tb ? b1 : b0; b1 = tb ? b2 : b1; b2 = tb ? b3 : b2; b3 = tb ? kSent : b3;
+            }
+            any = any || left[j] != 0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kPair; j++)
+          if (!((nocut >> (q0 + j)) & 1u)) { common[q0 + j] = mm[j]; ucount[q0 + j] = nq[q0 + j]; }
       }
-#pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++)
-        if (!((nocut >> q) & 1u)) { common[q] = mm[q]; ucount[q] = nq[q]; }
     }
     first_r = R;            // (nothing is left for the staged walk)
   }
@@ -2411,7 +2428,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   D.hbound_at = align8(D.roots_at + (uint64_t)n * 4);
   D.ranks_at = align8(D.hbound_at + (uint64_t)D.Rg * 8);
   D.share_bytes = align8(D.ranks_at + (uint64_t)D.n_max * 4);
-  D.share.ensure(D.share_bytes);
+  D.share.ensure(D.share_bytes + 16);      // (+16: the tiled kernel reads the ranks four at a time from any position)
   uint8_t* share = D.share.as<uint8_t>();
   T.rstate.ensure(sizeof(RangeState) + 64 * 4);
   RangeState* rs = T.rstate.as<RangeState>();
@@ -2597,7 +2614,7 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
     D.hbound_ptr = reinterpret_cast<const uint64_t*>(gathered + D.hbound_at);
   } else {
     // ranks of every element, in collection order
-    D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4);
+    D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4 + 16);   // (+16: read four at a time from any position)
     // (with the flags of the shares, and if range masks may be wanted: the elements' states for k_claim_bits)
     D.lazy_ready = D.share_flags && D.total > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
     if (D.lazy_ready) D.sid.ensure((size_t)D.total * 2);
