@@ -977,47 +977,81 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     uint32_t growS[kRowsPerWave];
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) growS[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)grow[q]);
+    // The usual tile -- every pair of one component, no sketch paired with itself -- takes the short forms: every word counts
+    // for every pair (two ANDs and two accumulating popcounts per word and row), the union so far is pa + pb - matches.
+    // rstar counts the ranges whose upper boundary the union has NOT reached (the union only grows: those are the first ones);
+    // ipre follows the matches while that lasts.
+    bool fastb = self == 0 && col_ok;
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) { fastb = fastb && samec[q] == 0xffffffffu; rstar[q] = 0; }
+    const bool fast = __all(fastb);
     for (uint32_t r = 0; r < R; r++) {
       const uint32_t w0 = woffc[r], w1 = woffc[r + 1], wf = w0 + wnc[r];
+      const uint32_t nw = w1 - w0;
       unsigned long long cw[kMW], rw[kRowsPerWave][kMW];
       uint32_t pa[kRowsPerWave];
 #pragma unroll
-      for (int k = 0; k < kMW; k++) cw[k] = w0 + (uint32_t)k < w1 ? mk[(size_t)(w0 + (uint32_t)k) * nsk + gcol] : 0ull;
+      for (int k = 0; k < kMW; k++) {
+        cw[k] = 0ull;
+        if ((uint32_t)k < nw) cw[k] = mk[(size_t)(w0 + (uint32_t)k) * nsk + gcol];
+      }
       const uint32_t pb = pT[(size_t)(r + 1) * nsk + gcol];
 #pragma unroll
       for (int q = 0; q < kRowsPerWave; q++) {
 #pragma unroll
-        for (int k = 0; k < kMW; k++) rw[q][k] = w0 + (uint32_t)k < w1 ? mkc[(size_t)(w0 + (uint32_t)k) * nsk + growS[q]] : 0ull;
+        for (int k = 0; k < kMW; k++) {
+          rw[q][k] = 0ull;
+          if ((uint32_t)k < nw) rw[q][k] = mkc[(size_t)(w0 + (uint32_t)k) * nsk + growS[q]];
+        }
         pa[q] = pTc[(size_t)(r + 1) * nsk + growS[q]];
       }
-      uint32_t prev[kRowsPerWave];                     // matches before this range
+      bool allfound = true;
+      if (fast) {
 #pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++) prev[q] = mtot[q];
+        for (int k = 0; k < kMW; k++) {
+          if ((uint32_t)k < nw) {
 #pragma unroll
-      for (int k = 0; k < kMW; k++) {
-        // (a component word counts for pairs of one component only; the range's frequent words, behind them, for every pair)
-        const uint32_t keep = w0 + (uint32_t)k < wf ? 0u : 0xffffffffu;
+            for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(rw[q][k] & cw[k]);
+          }
+        }
+        for (uint32_t wi = w0 + kMW; wi < w1; wi++) {    // (rare: a range with more words)
+          const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
 #pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(rw[q][k] & cw[k]) & (samec[q] | keep);
-      }
-      for (uint32_t wi = w0 + kMW; wi < w1; wi++) {    // (rare: a range with more words)
-        const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
-        const uint32_t keep = wi < wf ? 0u : 0xffffffffu;
+          for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mkc[(size_t)wi * nsk + growS[q]] & mb);
+        }
 #pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mkc[(size_t)wi * nsk + growS[q]] & mb) & (samec[q] | keep);
-      }
+        for (int q = 0; q < kRowsPerWave; q++) {
+          const bool below = pa[q] + pb - mtot[q] < nq[q];
+          rstar[q] += below ? 1u : 0u;
+          ipre[q] = below ? mtot[q] : ipre[q];
+          allfound = allfound && !below;
+        }
+      } else {
 #pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++) {
-        const uint32_t u = pa[q] + pb - (((self >> q) & 1u) ? pa[q] : mtot[q]);
-        if (rstar[q] == R && u >= nq[q]) { rstar[q] = r; ipre[q] = prev[q]; }
+        for (int k = 0; k < kMW; k++) {
+          if ((uint32_t)k < nw) {
+            // (a component word counts for pairs of one component only; the range's frequent words, behind them, for every pair)
+            const uint32_t keep = w0 + (uint32_t)k < wf ? 0u : 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(rw[q][k] & cw[k]) & (samec[q] | keep);
+          }
+        }
+        for (uint32_t wi = w0 + kMW; wi < w1; wi++) {
+          const unsigned long long mb = mk[(size_t)wi * nsk + gcol];
+          const uint32_t keep = wi < wf ? 0u : 0xffffffffu;
+#pragma unroll
+          for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(mkc[(size_t)wi * nsk + growS[q]] & mb) & (samec[q] | keep);
+        }
+#pragma unroll
+        for (int q = 0; q < kRowsPerWave; q++) {
+          const bool below = pa[q] + pb - (((self >> q) & 1u) ? pa[q] : mtot[q]) < nq[q];
+          rstar[q] += below ? 1u : 0u;
+          ipre[q] = below ? mtot[q] : ipre[q];
+          allfound = allfound && !below;
+        }
       }
       // (count_common not wanted: a wave whose pairs have all found their range needs no more of the totals)
-      if (!WantCC && (r & 7u) == 7u) {
-        bool all = true;
-#pragma unroll
-        for (int q = 0; q < kRowsPerWave; q++) all = all && rstar[q] != R;
-        if (__all(all)) break;
-      }
+      if (!WantCC && (r & 7u) == 7u && __all(allfound)) break;
     }
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) {
@@ -1036,18 +1070,18 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       constexpr int kPair = kRowsPerWave >= 2 ? 2 : 1;
 #pragma unroll
       for (int q0 = 0; q0 < kRowsPerWave; q0 += kPair) {
-        uint32_t ai[kPair], ae[kPair], bi2[kPair], be[kPair], left[kPair], mm[kPair];
+        uint32_t ai[kPair], bi2[kPair], aend[kPair], bend[kPair], left[kPair], mm[kPair];    // (aend, bend: the SKETCHES' ends)
         bool any = false;
 #pragma unroll
         for (int j = 0; j < kPair; j++) {
           const int q = q0 + j;
-          ai[j] = ae[j] = bi2[j] = be[j] = left[j] = mm[j] = 0;
+          ai[j] = aend[j] = bi2[j] = bend[j] = left[j] = mm[j] = 0;
           if (!((nocut >> q) & 1u)) {
             const uint32_t row = rowid[w * kRowsPerWave + q], rs = rstar[q];
             const uint32_t pa = pT[(size_t)rs * nsk + grow[q]], pb = pT[(size_t)rs * nsk + gcol];
             const uint32_t before = ((self >> q) & 1u) ? pa : ipre[q];
-            ai[j] = (uint32_t)ka.roff[row] + pa; ae[j] = (uint32_t)ka.roff[row] + pT[(size_t)(rs + 1) * nsk + grow[q]];
-            bi2[j] = (uint32_t)ka.coff[col] + pb; be[j] = (uint32_t)ka.coff[col] + pT[(size_t)(rs + 1) * nsk + gcol];
+            ai[j] = (uint32_t)ka.roff[row] + pa; aend[j] = (uint32_t)ka.roff[row + 1];
+            bi2[j] = (uint32_t)ka.coff[col] + pb; bend[j] = (uint32_t)ka.coff[col + 1];
             left[j] = nq[q] - (pa + pb - before);          // union elements still to go (> 0: the cut lies in this range)
             mm[j] = before;
             any = true;
@@ -1060,25 +1094,42 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
             va[j] = *reinterpret_cast<const Rank4*>(rr + (left[j] ? ai[j] : 0u));
             vb[j] = *reinterpret_cast<const Rank4*>(cr + (left[j] ? bi2[j] : 0u));
           }
+          // What lies past the end of a SEGMENT is the sketch's next range: larger than every rank of this range on either
+          // side, so it acts as the sentinel it stands for (it is never matched: the cut comes before both sides run out).
+          // Only past the end of the SKETCH do other ranks follow: there -- rarely -- the sentinels are put in by hand.
+          bool inside = true;
+#pragma unroll
+          for (int j = 0; j < kPair; j++) inside = inside && (left[j] == 0 || (ai[j] + 3 < aend[j] && bi2[j] + 3 < bend[j]));
+          if (!__all(inside)) {
+#pragma unroll
+            for (int j = 0; j < kPair; j++) {
+              va[j].x = ai[j] < aend[j] ? va[j].x : kSentA; va[j].y = ai[j] + 1 < aend[j] ? va[j].y : kSentA;
+              va[j].z = ai[j] + 2 < aend[j] ? va[j].z : kSentA; va[j].w = ai[j] + 3 < aend[j] ? va[j].w : kSentA;
+              vb[j].x = bi2[j] < bend[j] ? vb[j].x : kSent; vb[j].y = bi2[j] + 1 < bend[j] ? vb[j].y : kSent;
+              vb[j].z = bi2[j] + 2 < bend[j] ? vb[j].z : kSent; vb[j].w = bi2[j] + 3 < bend[j] ? vb[j].w : kSent;
+            }
+          }
           any = false;
 #pragma unroll
           for (int j = 0; j < kPair; j++) {
-            // what lies past the end of a segment is another range's (or sketch's): the side's sentinel instead
-            uint32_t a0 = ai[j] < ae[j] ? va[j].x : kSentA, a1 = ai[j] + 1 < ae[j] ? va[j].y : kSentA;
-            uint32_t a2 = ai[j] + 2 < ae[j] ? va[j].z : kSentA, a3 = ai[j] + 3 < ae[j] ? va[j].w : kSentA;
-            uint32_t b0 = bi2[j] < be[j] ? vb[j].x : kSent, b1 = bi2[j] + 1 < be[j] ? vb[j].y : kSent;
-            uint32_t b2 = bi2[j] + 2 < be[j] ? vb[j].z : kSent, b3 = bi2[j] + 3 < be[j] ? vb[j].w : kSent;
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-              const bool go = left[j] != 0;
-              const bool ta = go && a0 <= b0, tb = go && b0 <= a0;      // (both: a match)
-              mm[j] += (ta && tb) ? 1u : 0u;
-              ai[j] += ta ? 1u : 0u;
-              bi2[j] += tb ? 1u : 0u;
-              left[j] -= go ? 1u : 0u;
-              a0 = ta ? a1 : a0; a1 = ta ? a2 : a1; a2 = ta ? a3 : a2; a3 = ta ? kSentA : a3;
-              b0 = tb ? b1 : b0; b1 = tb ? b2 : b1; b2 = tb ? b3 : b2; b3 = tb ? kSent : b3;
+            uint32_t a0 = va[j].x, a1 = va[j].y, a2 = va[j].z, b0 = vb[j].x, b1 = vb[j].y, b2 = vb[j].z;
+            const uint32_t a3 = va[j].w, b3 = vb[j].w;
+            // four steps; the window of a side moves down when its head is consumed (only the slots a later step can reach)
+#define SMH_STEP(SHIFT_)                                                                  \
+            {                                                                             \
+              const bool go = left[j] != 0;                                               \
+              const bool ta = go && a0 <= b0, tb = go && b0 <= a0;      /* both: a match */ \
+              mm[j] += (ta && tb) ? 1u : 0u;                                              \
+              ai[j] += ta ? 1u : 0u;                                                      \
+              bi2[j] += tb ? 1u : 0u;                                                     \
+              left[j] -= go ? 1u : 0u;                                                    \
+              SHIFT_                                                                      \
             }
+            SMH_STEP(a0 = ta ? a1 : a0; a1 = ta ? a2 : a1; a2 = ta ? a3 : a2; b0 = tb ? b1 : b0; b1 = tb ? b2 : b1; b2 = tb ? b3 : b2;)
+            SMH_STEP(a0 = ta ? a1 : a0; a1 = ta ? a2 : a1; b0 = tb ? b1 : b0; b1 = tb ? b2 : b1;)
+            SMH_STEP(a0 = ta ? a1 : a0; b0 = tb ? b1 : b0;)
+            SMH_STEP(;)
+#undef SMH_STEP
             any = any || left[j] != 0;
           }
         }
