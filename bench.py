@@ -521,9 +521,8 @@ def main():
         cmp_roof = None
         if dense["rank0_kernel_ms"] > 0 and dense["route"] == "tiled":
             pmc, pmc_file = None, None
-            # (one owner's dictionary has range masks since round 4: counters of that kernel; a sliced dictionary -- N > 1 -- walks
-            # from the first range on: round 3's counters)
-            for name in (("r04_pmc_compare_tiled.json", "r03_pmc_compare_tiled.json") if world == 1 else ("r03_pmc_compare_tiled.json",)):
+            # (range masks since round 4, at every world size: counters of that kernel)
+            for name in ("r04_pmc_compare_tiled.json", "r03_pmc_compare_tiled.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                     pmc_file = name
@@ -531,7 +530,7 @@ def main():
                 except Exception:
                     continue
             walked, kms = dense["rank0_pairs_walked"], dense["rank0_kernel_ms"]
-            masked = bool(pmc and pmc.get("wait_any_share_of_wave_cycles")) and world == 1
+            masked = bool(pmc and pmc.get("bound") == "issue")
             lds_bytes = pmc.get("lds_bytes_per_walked_pair") * walked if pmc and pmc.get("lds_bytes_per_walked_pair") else None
             lds_achieved = lds_bytes / (kms * 1e-3) / 1e12 if lds_bytes else None
             cmp_roof = {"kernel": dense["rank0_kernel"] + (" (range masks)" if masked else ""), "kernel_ms_avg": kms, "pairs_walked": walked,
@@ -539,22 +538,30 @@ def main():
                         "effective_bytes": walked * ((NUM + NUM) * 8 + 8),
                         "effective_TBps": walked * ((NUM + NUM) * 8 + 8) / (kms * 1e-3) / 1e12,
                         "compulsory_hbm_bytes": sizes[0] * NUM * 8 + D.shard_range(sizes[0], world, 0)[2] * sizes[0] * 8,
-                        "counters_source": "profiles/%s (separate rocprofv3 --pmc passes of %s, committed; not measured in this run)"
+                        "counters_source": "profiles/%s (separate rocprofv3 --pmc passes of %s on the world-1 block, committed; not measured in this run)"
                                            % (pmc_file, pmc.get("kernel", "the kernel")) if pmc else None,
                         "valu_bound": None}
             if masked:
-                # one owner's dictionary carries range masks: per pair the range of its cut comes from popcounts and only that
-                # range is walked -- next to no LDS traffic, 13.7 x fewer VALU instructions; what bounds the kernel is the latency
-                # of its (L2-served) loads
-                cmp_roof.update({"bound": "memory latency (L2 round trips)", "unit": None, "peak": None, "achieved": None, "frac": None,
-                                 "wait_any_share_of_wave_cycles": pmc["wait_any_share_of_wave_cycles"],
+                # range masks (round 4; at world > 1 built from the flags the slice owners send): per pair the range of its cut comes
+                # from popcounts and only that range is walked -- next to no LDS traffic, few loads; what bounds the kernel is
+                # instruction issue, vector and scalar
+                vi, si = pmc["valu_wave_insts_per_64_pairs"], pmc.get("salu_wave_insts_per_64_pairs")
+                valu_rate = walked / 64.0 * vi / (kms * 1e-3) / 1e9                  # G wave-instructions per second, this run's time
+                valu_peak = SIMDS * MAX_CLOCK_HZ / VALU_CYCLES / 1e9
+                cmp_roof.update({"bound": "instruction issue (VALU + scalar)", "unit": "G VALU wave-instructions/s", "peak": valu_peak,
+                                 "achieved": valu_rate, "frac": valu_rate / valu_peak,
+                                 "scalar_unit_busy": (walked / 64.0 * si / 256.0) / (kms * 1e-3 * MAX_CLOCK_HZ) if si else None,
+                                 "wait_any_share_of_wave_cycles": pmc.get("wait_any_share_of_wave_cycles"),
                                  "vmem_loads_per_64_pairs": pmc.get("vmem_loads_per_64_pairs"),
                                  "memory_side_bytes": pmc.get("memory_side_bytes_per_launch"),
                                  "note": "integer compare/indexing, no MFMA.  The union of a pair is cut after `num` elements (reference "
                                          "src/lib.rs:470-499); where that happens follows from per-range bit masks of the shared hashes "
-                                         "(DESIGN.md 3.4 'range masks'), so a pair costs ~2 000 VALU wave-instructions per 64 pairs instead "
-                                         "of ~27 000 and a wave spends most of its cycles waiting for loads.  'effective' = SURVEY.md 8d's "
-                                         "(|A|+|B|)*8+8 B per compared pair over the kernel time (not traffic: most of those bytes are never read)"})
+                                         "(DESIGN.md 3.4 'range masks'), so a pair costs ~1 900 VALU + ~1 500 scalar wave-instructions per 64 "
+                                         "pairs instead of ~27 000 VALU.  `peak` = the guide's VALU issue rate (2 cycles per wave64 "
+                                         "instruction, 1024 SIMDs, 2.4 GHz); most of the kernel's VALU instructions are in the slow class "
+                                         "(~4.3 cycles measured), and the one scalar unit of a CU is busy `scalar_unit_busy` of the time.  "
+                                         "'effective' = SURVEY.md 8d's (|A|+|B|)*8+8 B per compared pair over the kernel time (not traffic: "
+                                         "most of those bytes are never read)"})
             else:
                 cmp_roof.update({"bound": "lds", "unit": "TB/s", "peak": LDS_READ_B32_PEAK_TBS,
                                  "achieved": lds_achieved, "frac": lds_achieved / LDS_READ_B32_PEAK_TBS if lds_achieved else None,

@@ -981,6 +981,16 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
     // for every pair (two ANDs and two accumulating popcounts per word and row), the union so far is pa + pb - matches.
     // rstar counts the ranges whose upper boundary the union has NOT reached (the union only grows: those are the first ones);
     // ipre follows the matches while that lasts.
+    const uint32_t nsk8 = nsk * 8u, nsk4 = nsk * 4u;         // (the masks stay below 4 GB: see has_masks / lazy_ready)
+    const char* colb = reinterpret_cast<const char*>(mk + gcol);
+    const char* colp = reinterpret_cast<const char*>(pT + gcol);
+    const SMH_CONSTANT char* rowb[kRowsPerWave];
+    const SMH_CONSTANT char* rowp[kRowsPerWave];
+#pragma unroll
+    for (int q = 0; q < kRowsPerWave; q++) {
+      rowb[q] = reinterpret_cast<const SMH_CONSTANT char*>(mkc + growS[q]);
+      rowp[q] = reinterpret_cast<const SMH_CONSTANT char*>(pTc + growS[q]);
+    }
     bool fastb = self == 0 && col_ok;
 #pragma unroll
     for (int q = 0; q < kRowsPerWave; q++) { fastb = fastb && samec[q] == 0xffffffffu; rstar[q] = 0; }
@@ -990,21 +1000,29 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
       const uint32_t nw = w1 - w0;
       unsigned long long cw[kMW], rw[kRowsPerWave][kMW];
       uint32_t pa[kRowsPerWave];
+      // The rows' loads are a constant base per row plus ONE 32-bit offset per word that all rows share -- the scalar unit,
+      // one per CU, was the busiest part of the kernel when every load had its own 64-bit address arithmetic.  The first word
+      // is read whether the range has it or not (the array is padded; what is not the range's is not counted), the others
+      // only when it has them: a range of the family collection has one word, and three times the loads cost it 0.35 ms.
+      const uint32_t ow = w0 * nsk8, op = (r + 1u) * nsk4;
 #pragma unroll
       for (int k = 0; k < kMW; k++) {
         cw[k] = 0ull;
-        if ((uint32_t)k < nw) cw[k] = mk[(size_t)(w0 + (uint32_t)k) * nsk + gcol];
+        if (k == 0 || (uint32_t)k < nw) cw[k] = *reinterpret_cast<const unsigned long long*>(colb + (ow + (uint32_t)k * nsk8));
       }
-      const uint32_t pb = pT[(size_t)(r + 1) * nsk + gcol];
+      const uint32_t pb = *reinterpret_cast<const uint32_t*>(colp + op);
 #pragma unroll
-      for (int q = 0; q < kRowsPerWave; q++) {
+      for (int k = 0; k < kMW; k++) {
+        if (k == 0 || (uint32_t)k < nw) {
 #pragma unroll
-        for (int k = 0; k < kMW; k++) {
-          rw[q][k] = 0ull;
-          if ((uint32_t)k < nw) rw[q][k] = mkc[(size_t)(w0 + (uint32_t)k) * nsk + growS[q]];
+          for (int q = 0; q < kRowsPerWave; q++) rw[q][k] = *reinterpret_cast<const SMH_CONSTANT unsigned long long*>(rowb[q] + (ow + (uint32_t)k * nsk8));
+        } else {
+#pragma unroll
+          for (int q = 0; q < kRowsPerWave; q++) rw[q][k] = 0ull;
         }
-        pa[q] = pTc[(size_t)(r + 1) * nsk + growS[q]];
       }
+#pragma unroll
+      for (int q = 0; q < kRowsPerWave; q++) pa[q] = *reinterpret_cast<const SMH_CONSTANT uint32_t*>(rowp[q] + op);
       bool allfound = true;
       if (fast) {
 #pragma unroll
@@ -1725,6 +1743,10 @@ __global__ __launch_bounds__(256) void k_build_masks(const uint32_t* __restrict_
   }
 }
 constexpr uint32_t kMaskWordsExtra = 64;       // words beyond two per range the masks may take
+// masks are kept for collections of at most 8 Mi (sketch, range) pairs whose mask table stays below 4 GB (32-bit byte offsets)
+static bool masks_fit(uint64_t n, uint64_t R) {
+  return n * R <= (8ull << 20) && n * (2 * R + kMaskWordsExtra + 3) * 8 < (1ull << 32);
+}
 
 // What an owner publishes about its slice.  The share is [SliceHeader][roots: nsk u32][hbound: Rg u64][ranks: nmax u32].
 struct SliceHeader {
@@ -2527,7 +2549,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   }
   // (with the ranks: rank[origin[i]] = run of sorted position i goes out with the runs -- unless the range masks are built:
   // then the ranks leave together with the elements' bits, further down)
-  D.has_masks = G == 1 && nm > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
+  D.has_masks = G == 1 && nm > 0 && compare_get_tuning().no_range_masks == 0 && masks_fit(n, D.R);
   // (several owners: every rank leaves with two flags -- its hash is held more than once; it is the first of its run -- so that
   // whoever assembles the ranks can hand out the range masks' bits without counting; same decision on every owner)
   D.share_flags = G > 1 && D.total < (1ull << 30);
@@ -2667,7 +2689,7 @@ void collection_finish(CollectionDict* Dp, const void* gathered_dev, Device& dev
     // ranks of every element, in collection order
     D.rankv.ensure(std::max<uint64_t>(D.total, 1) * 4 + 16);   // (+16: read four at a time from any position)
     // (with the flags of the shares, and if range masks may be wanted: the elements' states for k_claim_bits)
-    D.lazy_ready = D.share_flags && D.total > 0 && compare_get_tuning().no_range_masks == 0 && (uint64_t)n * D.R <= (8ull << 20);
+    D.lazy_ready = D.share_flags && D.total > 0 && compare_get_tuning().no_range_masks == 0 && masks_fit(n, D.R);
     if (D.lazy_ready) D.sid.ensure((size_t)D.total * 2);
     if (D.total)
       hipLaunchKernelGGL(k_reassemble, dim3(std::min<uint32_t>(n, 65536)), dim3(256), 0, s, off, n, D.spart.as<uint32_t>(), G,
@@ -2919,7 +2941,7 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
                          D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>(), st, &ds->part_built, nt);
     }
     if (use_masks) {
-      D.masks.ensure((size_t)D.n * D.mask_words_max * 8);
+      D.masks.ensure((size_t)D.n * (D.mask_words_max + 3) * 8);      // (+3 words: the kernel reads three words per range whatever it has)
       D.partT.ensure((size_t)D.n * (R + 1) * 4);
       hipLaunchKernelGGL(k_build_masks, dim3((unsigned)(((uint64_t)D.n * (R + 1) + 255) / 256)), dim3(256), 0, s, D.part.as<uint32_t>(), off,
                          D.sid.as<uint16_t>(), D.sb.as<uint32_t>(), D.woff.as<uint32_t>(), D.minfo.as<MaskInfo>(), D.n, R,
