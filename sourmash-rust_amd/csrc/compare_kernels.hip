@@ -1029,7 +1029,12 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
         for (int k = 0; k < kMW; k++) {
           if ((uint32_t)k < nw) {
 #pragma unroll
-            for (int q = 0; q < kRowsPerWave; q++) mtot[q] += (uint32_t)__popcll(rw[q][k] & cw[k]);
+            for (int q = 0; q < kRowsPerWave; q++) {
+              // (two accumulating popcounts: v_bcnt_u32_b32 adds its third operand)
+              const unsigned long long x = rw[q][k] & cw[k];
+              mtot[q] = (uint32_t)__popc((uint32_t)x) + mtot[q];
+              mtot[q] = (uint32_t)__popc((uint32_t)(x >> 32)) + mtot[q];
+            }
           }
         }
         for (uint32_t wi = w0 + kMW; wi < w1; wi++) {    // (rare: a range with more words)

@@ -273,6 +273,55 @@ def _profile_count(pkg, name):
     return k.value
 
 
+@pytest.mark.parametrize("num", [0, 150, 400])
+def test_range_masks_with_many_words_per_range_and_cuts_near_a_sketch_end(num, pkg, coracle):
+    """The corners of the masked tiled kernel ("Range masks"): (i) components whose sketches draw from a pool
+    twenty times their length -- hundreds of shared hashes per range, so a range's words exceed the three the kernel keeps
+    in registers (the tail loop); (ii) SHORT sketches next to long ones, cut by `num` close to their last element, so that
+    the four-ranks-at-a-time windows of the cut-range walk run past the end of a sketch (sentinels by hand) and past the end
+    of the rank array (the padding); (iii) two components in every 64-column tile plus unrelated sketches (per-component bits:
+    the short forms must not be taken); (iv) the all-vs-all block with its self pairs.  Every pair against the oracle, with
+    masks and without, symmetric and as a rows x columns block."""
+    import torch
+    rng = np.random.RandomState(11 + num)
+    pools = [np.unique(rng.randint(0, 1 << 62, size=9000, dtype=np.int64).astype(np.uint64))[:8000] for _ in range(2)]
+    sk = []
+    for i in range(150):
+        pool = pools[i % 2]
+        if i % 7 == 3:
+            ln = int(rng.randint(3, 40))                                  # short: its last range is its first
+        elif i % 7 == 5:
+            ln = int(rng.randint(num + 1, num + 6)) if num else 17        # the cut a step or two before the sketch's end
+        else:
+            ln = int(rng.randint(300, 420))
+        sk.append(np.sort(rng.choice(pool, ln, replace=False)))
+    for i in range(10):                                                   # sketches of their own (no component, no bit)
+        sk.append(np.unique(rng.randint(0, 1 << 62, size=200, dtype=np.int64).astype(np.uint64)))
+    order = rng.permutation(len(sk))
+    sk = [sk[i] for i in order]
+    # the last sketch of the collection ends the rank array: make it one whose cut is near its end
+    sk.append(np.sort(rng.choice(pools[0], (num + 2) if num else 9, replace=False)))
+    flat, off = pkg.matrix.csr_from_sketches(sk)
+    t = torch.from_numpy(flat.view(np.int64)).cuda()
+    ocommon, osize, ojac = coracle.compare_matrix(sk, sk, num, 21, 0)
+    occ = np.array([[len(np.intersect1d(a, b, assume_unique=True)) for b in sk] for a in sk], dtype=np.int64)
+    rows = list(range(5, 61))
+    rflat, roff = pkg.matrix.csr_from_sketches([sk[i] for i in rows])
+    tr = torch.from_numpy(rflat.view(np.int64)).cuda()
+    for tune in (dict(route="tiled"), dict(route="tiled", range_masks=False), dict(route="tiled", use_symmetry=False),
+                 dict(route="tiled", visit_all_tiles=True), dict(route="tiled", dictionary="full"), dict()):
+        with pkg.matrix.tuning(**tune):
+            out = pkg.matrix.compare_block_dev(t, off, t, off, num, want=("jaccard", "common", "size", "count_common"))
+            blk = pkg.matrix.compare_block_dev(tr, roff, t, off, num, want=("jaccard", "common", "count_common"))
+        assert (out["jaccard"].cpu().numpy() == ojac).all(), tune
+        assert (out["common"].cpu().numpy().view(np.uint64) == ocommon).all(), tune
+        assert (out["size"].cpu().numpy().view(np.uint64) == osize).all(), tune
+        assert (out["count_common"].cpu().numpy() == occ).all(), tune
+        assert (blk["jaccard"].cpu().numpy() == ojac[rows]).all(), tune
+        assert (blk["common"].cpu().numpy().view(np.uint64) == ocommon[rows]).all(), tune
+        assert (blk["count_common"].cpu().numpy() == occ[rows]).all(), tune
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_four_pass_dictionary_equals_the_full_sort_dictionary(seed, pkg, coracle):
     """The pooled hashes of the dictionary are sorted by the 32 most significant bits that vary, and the keys that tie there
