@@ -207,7 +207,8 @@ typedef struct SmhCompareTuning {
   uint32_t route;             /* SmhCompareRoute; default AUTO */
   uint32_t visit_all_tiles;   /* tiled route: 1 = launch every tile, not only those that can hold pairs sharing a hash */
   uint32_t use_symmetry;      /* default 1: all-vs-all with one num computes the upper triangle and mirrors it */
-  uint64_t comp_pairs_limit;  /* AUTO: at most this many sharing pairs -> per-component pair kernel (default 96 Ki) */
+  uint64_t comp_pairs_limit;  /* AUTO: at most this many sharing pairs -> per-component pair kernel (default 96 Ki; the library
+                                 lowers it to 16 Ki for a dictionary that carries range masks) */
   uint32_t split_frequent;    /* default 1: hashes held by more than a quarter of the sketches (at most 64 of them) do not
                                  connect sketches; pairs that share only such hashes are decided from per-sketch records
                                  instead of being walked */

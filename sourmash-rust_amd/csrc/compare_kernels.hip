@@ -1748,6 +1748,7 @@ __global__ __launch_bounds__(256) void k_build_masks(const uint32_t* __restrict_
   }
 }
 constexpr uint32_t kMaskWordsExtra = 64;       // words beyond two per range the masks may take
+constexpr uint64_t kCompPairsWithMasks = 16ull << 10;   // the AUTO route's pair limit when the dictionary has (or can build) masks
 // masks are kept for collections of at most 8 Mi (sketch, range) pairs whose mask table stays below 4 GB (32-bit byte offsets)
 static bool masks_fit(uint64_t n, uint64_t R) {
   return n * R <= (8ull << 20) && n * (2 * R + kMaskWordsExtra + 3) * 8 < (1ull << 32);
@@ -2785,7 +2786,12 @@ void collection_compare(CollectionDict* Dp, uint32_t row_lo, uint32_t row_hi, ui
   // the AUTO route's pair limit, clamped ONCE so that the work list sized from it always holds what the device-side
   // choice (k_plan_route, same value) can produce: a tuning value never changes a result or raises
   const uint64_t kWorkCapMax = 1ull << 26;
-  const uint64_t comp_limit = std::min<uint64_t>(tune.comp_pairs_limit, kWorkCapMax > ncols ? kWorkCapMax - ncols : 0);
+  uint64_t comp_limit = std::min<uint64_t>(tune.comp_pairs_limit, kWorkCapMax > ncols ? kWorkCapMax - ncols : 0);
+  // (with range masks a tile is a prologue and one short walk, ~0.1 ms for a round of tiles however few: the pair kernel,
+  // ~7 ns per pair of num = 2000 sketches, only wins below ~16 Ki sharing pairs -- 2 000 sketches in 50 families, 80 000 pairs:
+  // 1.10 -> 0.81 ms; without masks a tile's chain of staged stretches lasts ~0.4 ms and the tuning's limit stands)
+  // (one owner's dictionary only: a sliced one builds its masks when the block has MANY sharing pairs -- lazy_go)
+  if (compare_get_tuning().no_range_masks == 0 && D.has_masks) comp_limit = std::min<uint64_t>(comp_limit, kCompPairsWithMasks);
   // ---- every pair as if it shared nothing but frequent hashes; the compare kernels overwrite the pairs they walk
   // (with every tile launched nothing would be left: skipped).  It needs nothing the plan makes and is bound by its writes
   // (800 MB at 10 000 x 10 000), so it runs on the library's second stream beside the plan's small launches and is
