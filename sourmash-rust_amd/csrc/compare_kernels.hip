@@ -938,9 +938,9 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_compare_tiled_pf(TiledArgs a
 
   // ---- range masks: where every pair's union reaches its cut, without walking (see "range masks" further down).
   // Pass 1, range by range: matches so far = popcounts of the ANDed words; union so far = the two sketches' crossings of the
-  // range's upper boundary minus the matches; the first range in which that reaches the row's cut is the pair's.  The tile
-  // starts walking at the earliest such range of its pairs (pass 2: the matches before it, for the walk's counters); pairs
-  // that never reach a cut are final as they are.
+  // range's upper boundary minus the matches; the first range in which that reaches the row's cut is the pair's.  Pass 2:
+  // that ONE range is walked by the pair's lane alone, from the rank arrays (the staged stretch loop below is not entered
+  // when the masks exist); pairs that never reach a cut are final as they are.
   const bool use_masks = ka.masks != nullptr && ka.minfo->ok != 0;      // (uniform)
   uint32_t first_r = 0;                 // the first range the tile walks (R: none)
   uint32_t mtot[kRowsPerWave];          // matches over all ranges
@@ -1599,17 +1599,17 @@ __global__ __launch_bounds__(kBsThreads) void k_tie_sort(uint64_t* __restrict__ 
 
 // ---- range masks: how many hashes two sketches share in every range, without walking them --------------------------------
 // A hash held by ONE sketch of the collection can never be a match.  The hashes held by two or more (the runs of length >= 2
-// of the pooled sort) are numbered in hash order -- sid -- and every range r of the tiled kernel gets the ones that fall
-// into it as bit positions: sid - sb[r], in ceil(K_r / 64) 64-bit words.  mask[w][s] = which of them sketch s holds.  Then
+// of the pooled sort) get a bit each, distinct among the shared hashes of their (component, range) -- see below -- in
+// ceil(K_r / 64) 64-bit words per range r of the tiled kernel.  mask[w][s] = which of them sketch s holds.  Then
 //     |A and B in range r|  =  popcount(mask[.][A] & mask[.][B])  over the range's words,
 // and with the sketches' crossings of the range boundaries (part) the size of the union up to any boundary follows without
 // touching a rank: U_r = part[A][r+1] + part[B][r+1] - matches up to r.  The tiled kernel uses that to find, for every pair
 // of a tile, the ONE range in which the union reaches the pair's cut (src/lib.rs:470-499: the walk ends after `num` union
-// elements) and starts its walk at the earliest such range of the tile, with the counts the masks give for everything
-// before -- a few stretches instead of all of them; pairs that never reach a cut (scaled sketches: num = 0) are not walked at
-// all, and count_common is the popcount over all ranges.  One family of related genomes has a few dozen shared hashes per
-// range: one word.  A component of many unrelated families would need many words per range for sparse masks: beyond
-// kMaskWordsMax words in all the masks are not built and the kernel walks as before.
+// elements); the pair's lane then walks that range alone, with the counts the masks give for everything before it; pairs
+// that never reach a cut (scaled sketches: num = 0) are not walked at all, and count_common is the popcount over all
+// ranges.  One family of related genomes has a few dozen shared hashes per range: one word.  A component of many unrelated
+// families would need many words per range for sparse masks: beyond 2 R + kMaskWordsExtra words per sketch the masks are
+// not built (MaskInfo.ok = 0) and the kernel walks as before.
 constexpr uint32_t kSidNone = 0xffffffffu;
 // Bits only have to be DISTINCT among the hashes two comparable sketches can share in a range, so they are handed out per
 // (component, range) by a counter: bit = how many shared hashes of that component and range came before (in any order).
