@@ -1387,12 +1387,13 @@ __global__ __launch_bounds__(1024) void k_slice_scan(const uint32_t* __restrict_
   if (tid == 1023) { dst[nsk] = part_sum[1023]; sizes[g] = part_sum[1023]; }
 }
 // slice g of every sketch, sketch after sketch: keys[t], node[t] = its sketch, org[t] = t
-__global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
-                                                      const uint32_t* __restrict__ spart, uint32_t G, uint32_t g,
-                                                      const uint32_t* __restrict__ segoff_g, uint32_t n,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ node, uint32_t* __restrict__ parent) {
+__global__ __launch_bounds__(256) void k_slice_gather_pos(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                                                          const uint32_t* __restrict__ spart, uint32_t G, uint32_t g,
+                                                          const uint32_t* __restrict__ segoff_g, uint32_t n,
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ node, uint32_t* __restrict__ parent) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nsk; i += gridDim.x * blockDim.x) parent[i] = i;   // (the union-find forest's start)
-  // a lane takes 8 consecutive slice positions: one search for the sketch of the first, then a walk (the sort numbers the keys)
+  // a lane takes 8 consecutive slice positions: one search for the sketch of the first, then a walk (the sort numbers the keys).
+  // Indifferent to how long a sketch is: the form for collections with sketches far longer than the others.
   const uint32_t t0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8u;
   if (t0 >= n) return;
   uint32_t lo = 0, hi = nsk;   // last s with segoff_g[s] <= t0  (its segment is not empty: t0 < n)
@@ -1412,6 +1413,20 @@ __global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict
     keys[t] = src[t - seg0];
     node[t] = lo;
   }
+}
+__global__ __launch_bounds__(256) void k_slice_gather(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ off, uint32_t nsk,
+                                                      const uint32_t* __restrict__ spart, uint32_t G, uint32_t g,
+                                                      const uint32_t* __restrict__ segoff_g, uint32_t n,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ node, uint32_t* __restrict__ parent) {
+  // a wavefront per sketch: its piece of the slice is a contiguous stretch of the sketch, copied by consecutive lanes
+  // (a lane per 8 slice positions -- a search and eight dependent loads each -- took 63 us for 2.5 M keys)
+  const uint32_t sk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (sk >= nsk) return;
+  if (lane == 0) parent[sk] = sk;                          // (the union-find forest's start)
+  const uint32_t a = segoff_g[sk], b = segoff_g[sk + 1];
+  const uint64_t* src = hashes + off[sk] + spart[(size_t)sk * (G + 1) + g];
+  for (uint32_t e = lane; e < b - a; e += 64u) { keys[a + e] = src[e]; node[a + e] = sk; }
+  (void)n;
 }
 // world == 1: the one slice is the collection itself, in its own order (the sort reads it in place and numbers it); what is
 // left to make is node[t] = the sketch of element t.  A lane takes 8 consecutive elements: one search, then a walk.
@@ -2596,8 +2611,13 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       cur = radix_sort_u64_place(D.hashes, T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
                                  dev.scratch, s, mask, shift_dev);
     } else {
-      hipLaunchKernelGGL(k_slice_gather, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
-                         D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>(), T.parent.as<uint32_t>());
+      // (a wavefront per sketch while no sketch is longer than 64 turns of it; else a lane per 8 slice positions)
+      if (D.max_len <= 4096u)
+        hipLaunchKernelGGL(k_slice_gather, dim3((n + 3) / 4), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
+                           D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>(), T.parent.as<uint32_t>());
+      else
+        hipLaunchKernelGGL(k_slice_gather_pos, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, D.hashes, off, n, D.spart.as<uint32_t>(), G, rank,
+                           D.segoff.as<uint32_t>() + (size_t)rank * (n + 1), nm, T.keys0.as<uint64_t>(), T.node.as<uint32_t>(), T.parent.as<uint32_t>());
       if (shift_dev)
         hipLaunchKernelGGL(k_key_span, dim3((n + 255) / 256), dim3(256), 0, s, T.keys0.as<uint64_t>(),
                            BkSeg{nullptr, D.segoff.as<uint32_t>() + (size_t)rank * (n + 1)}, n, nm, rs);
