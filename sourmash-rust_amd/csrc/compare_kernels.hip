@@ -1461,6 +1461,16 @@ __global__ __launch_bounds__(256) void k_whole_nodes(const uint64_t* __restrict_
 // where the segments (sketches) of a slice start inside its key array: the collection's own offsets (one owner) or the
 // slice's table (k_slice_scan)
 struct BkSeg { const uint64_t* off64; const uint32_t* off32; };
+// the sketch of pooled element o: a table -- or, when one owner's sketches all have the same length (bottom-num sketches:
+// the usual case), a multiplication: the table's entries are scattered reads, and the kernels that go through the sorted
+// positions are bound by the scattered lines they touch
+struct NodeMap { const uint32_t* node; uint32_t len, magic; };        // len == 0: use the table; magic = floor(2^32 / len)
+__device__ __forceinline__ uint32_t node_of(const NodeMap& m, uint32_t o) {
+  if (m.len == 0) return m.node[o];
+  uint32_t q = __umulhi(o, m.magic);                     // floor(o / len) or one less
+  if (o - q * m.len >= m.len) q++;
+  return q;
+}
 __device__ __forceinline__ uint32_t bk_seg(const BkSeg& g, uint32_t s) { return g.off64 ? (uint32_t)g.off64[s] : g.off32[s]; }
 
 // ---- the pooled sort in four passes instead of eight -------------------------------------------------------------------
@@ -1653,7 +1663,7 @@ __global__ __launch_bounds__(256) void k_range_runs(const uint32_t* __restrict__
 // runbit[run] = the bit of a run held by two sketches or more (bit 31: one of the range's frequent bits), kSidNone for a
 // run of one.  cnt[root * R + range] / fcnt[range]: the counters.
 __global__ __launch_bounds__(256) void k_shared_bits(const uint32_t* __restrict__ starts, const RangeState* __restrict__ rs, uint32_t n,
-                                                     const uint32_t* __restrict__ origin, const uint32_t* __restrict__ node,
+                                                     const uint32_t* __restrict__ origin, NodeMap node,
                                                      const uint32_t* __restrict__ roots, const uint8_t* __restrict__ isfreq,
                                                      const uint32_t* __restrict__ rlo, uint32_t R, uint32_t* __restrict__ cnt,
                                                      uint32_t* __restrict__ fcnt, uint32_t* __restrict__ runbit) {
@@ -1668,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_shared_bits(const uint32_t* __restrict_
     if (rlo[mid] <= r) lo = mid; else hi = mid;
   }
   if (isfreq && isfreq[r]) runbit[r] = atomicAdd(&fcnt[lo], 1u) | 0x80000000u;
-  else runbit[r] = atomicAdd(&cnt[(size_t)roots[node[origin[a]]] * R + lo], 1u);
+  else runbit[r] = atomicAdd(&cnt[(size_t)roots[node_of(node, origin[a])] * R + lo], 1u);
 }
 // rank and bit of every element, in collection order, in ONE pass over the sorted positions (the runs' bits are read in
 // run order; the scatter by origin is the one the ranks need anyway -- with masks it runs here instead of inside the
@@ -1947,7 +1957,7 @@ __global__ __launch_bounds__(256) void k_uf_init(uint32_t* parent, uint32_t m) {
 // its loads touch (one line per lane and cycle per CU), not by their bytes.
 template <int Shift, bool Filter>
 __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
-                                                 const uint32_t* __restrict__ node, uint64_t n, uint32_t* parent,
+                                                 NodeMap node, uint64_t n, uint32_t* parent,
                                                  const uint32_t* __restrict__ runid, const uint8_t* __restrict__ isfreq) {
   const uint64_t i = ((uint64_t)xcd_chunked_block() * blockDim.x + threadIdx.x) << Shift;
   const bool in = i < n;                                  // (whole waves stay for the shuffles)
@@ -1959,9 +1969,9 @@ __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ ke
   if (Shift == 0) {
     const uint64_t want = __ballot(eq);                   // my own sketch is wanted by me or by the lane to my right
     const bool load = eq || ((want >> 1) >> lane) & 1ull;
-    a = load ? node[origin[i]] : 0u;
+    a = load ? node_of(node, origin[i]) : 0u;
     b = (uint32_t)__shfl_up((int)a, 1);
-    if (eq && lane == 0) b = node[origin[i - 1]];
+    if (eq && lane == 0) b = node_of(node, origin[i - 1]);
     eq = eq && a != b;
     if (Filter) {
       const uint64_t want2 = __ballot(eq);
@@ -1977,7 +1987,7 @@ __global__ __launch_bounds__(256) void k_uf_runs(const uint64_t* __restrict__ ke
     }
   } else {
     if (!eq) return;
-    a = node[origin[i]]; b = node[origin[i - 1]];
+    a = node_of(node, origin[i]); b = node_of(node, origin[i - 1]);
     if (a == b) return;
     if (Filter) {
       for (int hop = 0; hop < 64; hop++) { const uint32_t p = parent[a]; if (p == a) break; a = p; }
@@ -2007,7 +2017,7 @@ __device__ __forceinline__ uint32_t lds_uf_find(uint32_t* lpar, uint32_t x) {
 }
 template <int Shift>
 __global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ origin,
-                                                      const uint32_t* __restrict__ node, uint64_t n, uint32_t nsk, uint32_t* __restrict__ out,
+                                                      NodeMap node, uint64_t n, uint32_t nsk, uint32_t* __restrict__ out,
                                                       const uint32_t* __restrict__ runid, const uint8_t* __restrict__ isfreq) {
   extern __shared__ uint32_t lpar[];
   for (uint32_t i = threadIdx.x; i < nsk; i += 1024) lpar[i] = i;
@@ -2037,7 +2047,7 @@ __global__ __launch_bounds__(1024) void k_uf_runs_lds(const uint64_t* __restrict
 #pragma unroll
     for (int j = 0; j < 8; j++) { oa[j] = eq[j] ? origin[idx[j]] : 0u; ob[j] = eq[j] ? origin[idx[j] - 1] : 0u; }
 #pragma unroll
-    for (int j = 0; j < 8; j++) { xs[j] = eq[j] ? node[oa[j]] : 0u; ys[j] = eq[j] ? node[ob[j]] : 0u; }
+    for (int j = 0; j < 8; j++) { xs[j] = eq[j] ? node_of(node, oa[j]) : 0u; ys[j] = eq[j] ? node_of(node, ob[j]) : 0u; }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if (!eq[j]) continue;
@@ -2510,6 +2520,7 @@ struct CollectionDict {
   uint32_t mask_words_max = 0;
   bool has_masks = false;             // one owner: built with the dictionary
   bool lazy_tried = false;            // several owners: built by the first block compare that may walk tiles (k_claim_bits ...)
+  uint32_t uniform_len = 0;           // the sketches' common length (0: they differ)
   bool lazy_ready = false;            // several owners: the elements' states are in sid (k_reassemble): masks can be built on demand
   bool share_flags = false;           // several owners: the shares' ranks carry "shared" / "first of its run" in bits 31 / 30
   std::vector<uint64_t> rel_off;
@@ -2546,6 +2557,9 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   D.total = offsets_host[n] - base;
   if (D.total >= (1ull << 31) - 2) throw_internal("compare block: more than 2^31 hashes");   // (ranks stay below the sentinels)
   for (uint32_t i = 0; i < n; i++) D.max_len = std::max<uint32_t>(D.max_len, (uint32_t)(offsets_host[i + 1] - offsets_host[i]));
+  D.uniform_len = D.max_len;
+  for (uint32_t i = 0; i < n; i++)
+    if (offsets_host[i + 1] - offsets_host[i] != D.max_len) { D.uniform_len = 0; break; }
   // offsets relative to the first element (a copy the dictionary owns: the caller's array may be reused)
   D.off.ensure((size_t)(n + 1) * 8);
   if (offsets_host != D.rel_off.data()) {
@@ -2611,6 +2625,9 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
   uint32_t* so = T.org0.as<uint32_t>();
   D.split = compare_get_tuning().split_frequent != 0 && n >= 32;
   const uint32_t threshold = std::max<uint32_t>(16u, n / 4);
+  // one owner whose sketches all have the same length (> 1): the sketch of an element is a multiplication, not a table
+  NodeMap nmap{T.node.as<uint32_t>(), 0u, 0u};
+  if (G == 1 && D.uniform_len > 1) { nmap.len = D.uniform_len; nmap.magic = (uint32_t)((1ull << 32) / D.uniform_len); }
   if (nm) {
     // hashes are uniform over their span: the 32 most significant bits that vary decide the order of all but a few of them
     // (four passes, then k_tie_fix); all eight passes only when that has failed once for this collection
@@ -2618,7 +2635,8 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     const uint32_t mask = D.force_radix ? 0xffu : 0x0fu;
     const uint32_t* shift_dev = D.force_radix ? nullptr : &rs->sort_shift;
     if (G == 1) {
-      hipLaunchKernelGGL(k_whole_nodes, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, off, n, nm, T.node.as<uint32_t>(), T.parent.as<uint32_t>());
+      if (nmap.len) hipLaunchKernelGGL(k_uf_init, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n);   // (no table to make)
+      else hipLaunchKernelGGL(k_whole_nodes, dim3((nm / 8 + 256) / 256), dim3(256), 0, s, off, n, nm, T.node.as<uint32_t>(), T.parent.as<uint32_t>());
       if (shift_dev) hipLaunchKernelGGL(k_key_span, dim3((n + 255) / 256), dim3(256), 0, s, D.hashes, BkSeg{off, nullptr}, n, nm, rs);
       cur = radix_sort_u64_place(D.hashes, T.keys0.as<uint64_t>(), T.keys1.as<uint64_t>(), T.org0.as<uint32_t>(), T.org1.as<uint32_t>(), nm,
                                  dev.scratch, s, mask, shift_dev);
@@ -2687,7 +2705,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       T.wroots.ensure((size_t)W * n * 4);
 #define SMH_UF(S_)                                                                                                            \
   if (shift == S_)                                                                                                            \
-    hipLaunchKernelGGL((k_uf_runs_lds<S_>), dim3(W), dim3(1024), (size_t)n * 4, s, sk, so, T.node.as<uint32_t>(), (uint64_t)nm, n, \
+    hipLaunchKernelGGL((k_uf_runs_lds<S_>), dim3(W), dim3(1024), (size_t)n * 4, s, sk, so, nmap, (uint64_t)nm, n, \
                        T.wroots.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
       SMH_UF(4) SMH_UF(5) SMH_UF(6) SMH_UF(7) SMH_UF(8)
 #undef SMH_UF
@@ -2697,19 +2715,19 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
       // a large slice of several owners' dictionary: 1/16 of the pairs through the cached filter before all of them (half of a
       // dense 10 000-sketch pool: slice 1.47 -> 1.30 ms; one owner's whole pool is no faster for it: 3.45 -> 3.39 ms without)
       if (nm > (1u << 22) && G > 1) {
-        hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+        hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, nmap,
                            (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
         hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
       }
     } else {
-      hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+      hipLaunchKernelGGL((k_uf_runs<8, false>), dim3((unsigned)((nm / 256 + 256) / 256)), dim3(256), 0, s, sk, so, nmap,
                          (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
       hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
-      hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+      hipLaunchKernelGGL((k_uf_runs<4, true>), dim3((unsigned)((nm / 16 + 256) / 256)), dim3(256), 0, s, sk, so, nmap,
                          (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
       hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, T.parent.as<uint32_t>());
     }
-    hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, sk, so, T.node.as<uint32_t>(),
+    hipLaunchKernelGGL((k_uf_runs<0, true>), dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, sk, so, nmap,
                        (uint64_t)nm, T.parent.as<uint32_t>(), T.runid.as<uint32_t>(), isfreq);
   }
   hipLaunchKernelGGL(k_uf_roots, dim3((n + 255) / 256), dim3(256), 0, s, T.parent.as<uint32_t>(), n, roots);
@@ -2736,7 +2754,7 @@ static void collection_begin_into(CollectionDict& D, const uint64_t* hashes_dev,
     D.mask_words_max = 2 * R + kMaskWordsExtra;            // (a range's bits stay below 2^15 whatever it is: k_mask_layout checks)
     HIP_CHECK(hipMemsetAsync(cnt, 0, ((size_t)n * R + 2 * R + 4) * 4, s));
     hipLaunchKernelGGL(k_range_runs, dim3((R + 256) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, R, rlo);
-    hipLaunchKernelGGL(k_shared_bits, dim3((nm + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, so, T.node.as<uint32_t>(),
+    hipLaunchKernelGGL(k_shared_bits, dim3((nm + 255) / 256), dim3(256), 0, s, T.starts.as<uint32_t>(), rs, nm, so, nmap,
                        roots, isfreq, rlo, R, cnt, fcnt, runbit);
     hipLaunchKernelGGL(k_rank_bit_scatter, dim3((nm + 255) / 256), dim3(256), 0, s, T.runid.as<uint32_t>(), so, runbit, nm,
                        reinterpret_cast<uint32_t*>(share + D.ranks_at), D.sid.as<uint16_t>());
