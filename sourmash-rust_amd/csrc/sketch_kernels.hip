@@ -1572,12 +1572,14 @@ static void launch_rolling(const SeqBatch& b, const HashParams& p, const CandSin
       int mw = 0, hb = 0;
       if (sscanf(e, "%d,%d", &mw, &hb) == 2) {
 #define SMH_PKV(M_, H_) if (mw == M_ && hb == H_) { hipLaunchKernelGGL((k_dna_rolling<KT, 512, H_, L, false, true, M_>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap); return; }
-        SMH_PKV(8, 1) SMH_PKV(6, 1) SMH_PKV(6, 2) SMH_PKV(5, 2) SMH_PKV(4, 2) SMH_PKV(8, 4) SMH_PKV(6, 4)
+        SMH_PKV(8, 1) SMH_PKV(7, 1) SMH_PKV(6, 1) SMH_PKV(5, 1) SMH_PKV(4, 1) SMH_PKV(8, 2) SMH_PKV(6, 2) SMH_PKV(5, 2) SMH_PKV(4, 2) SMH_PKV(8, 4) SMH_PKV(6, 4)
 #undef SMH_PKV
       }
     }
 #endif
-    hipLaunchKernelGGL((k_dna_rolling<KT, 512, 2, L, false, true>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
+    // (six waves per SIMD, one hash per block: 80 vector registers keep the scalar values out of vector lanes; 27.2 against
+    // 27.6 ms per 10 GB with eight waves and two hashes per block, profiles/r04_pmc_dna_rolling.json "variants_measured")
+    hipLaunchKernelGGL((k_dna_rolling<KT, 512, 1, L, false, true, 6>), dim3(grid), dim3(512), lds, s, b, p, sink, logR, stage_cap);
     return;
   }
 #ifdef SMH_EXPERIMENTS
